@@ -1,0 +1,90 @@
+"""ctypes binding of the C-ABI (include/bayesfilt.h).
+
+The shared library is built in-tree by ``bayesianfiltering_amd/csrc/Makefile`` (or
+``__graft_entry__.build()``).  There is NO fallback: if the library is missing, or a filter is
+called without a gfx950 device, the call raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbayesfilt_hip.so")
+
+BF_OK, BF_EINVAL, BF_EUNSUPPORTED, BF_EHIP, BF_ENOGPU = 0, -1, -2, -3, -4
+
+
+class BayesFiltError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"bayesfilt error {code}: {msg}")
+        self.code = code
+
+
+class bf_stream(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("sB", C.c_int64), ("sK", C.c_int64), ("sT", C.c_int64), ("sE", C.c_int64)]
+
+
+class bf_cstream(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("sB", C.c_int64), ("sK", C.c_int64), ("sT", C.c_int64), ("sE", C.c_int64)]
+
+
+class bf_out_desc(C.Structure):
+    _fields_ = [("weights", bf_stream), ("means", bf_stream), ("covs", bf_stream), ("pred_means", bf_stream),
+                ("pred_covs", bf_stream), ("loglik", bf_stream)]
+
+
+class bf_carry(C.Structure):
+    _fields_ = [("w_in", C.c_void_p), ("m_in", C.c_void_p), ("P_in", C.c_void_p),
+                ("w_out", C.c_void_p), ("m_out", C.c_void_p), ("P_out", C.c_void_p)]
+
+
+_FP = C.POINTER(C.c_float)
+
+
+class bf_lgssm(C.Structure):
+    _fields_ = [("n", C.c_int32), ("dq", C.c_int32), ("m", C.c_int32), ("dr", C.c_int32),
+                ("A", _FP), ("G", _FP), ("H", _FP), ("D", _FP), ("q0", _FP), ("r0", _FP), ("Q", _FP), ("R", _FP),
+                ("Q_steps", C.c_int32), ("R_steps", C.c_int32)]
+
+
+# every symbol include/bayesfilt.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "bf_version": (C.c_int, []),
+    "bf_last_error": (C.c_char_p, []),
+    "bf_device_count": (C.c_int, []),
+    "bf_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "bf_bytes_per_step": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(bf_out_desc)]),
+    "bf_kalman_filter_f32": (C.c_int, [C.POINTER(bf_lgssm), C.POINTER(bf_cstream), C.c_int64, C.c_int64,
+                                       C.POINTER(bf_carry), C.POINTER(bf_out_desc), C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C bayesianfiltering_amd/csrc` "
+            "(or __graft_entry__.build()).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != BF_OK:
+        raise BayesFiltError(code, load().bf_last_error().decode())
+
+
+def require_gpu():
+    lib = load()
+    if lib.bf_device_count() < 1:
+        raise BayesFiltError(BF_ENOGPU, "no gfx950 (MI355X) device visible; the filters only run on the HIP path")
+    return lib

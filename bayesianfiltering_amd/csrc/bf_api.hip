@@ -1,0 +1,84 @@
+// C-ABI entry points (include/bayesfilt.h).  Validation and dispatch only; the kernels live in
+// the kf_*/gsf_*/bpf_* translation units.
+#include <cstring>
+#include "bf_common.hpp"
+
+namespace bf {
+
+char* last_error_buf() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(last_error_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int launch_kf_small(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
+                    const bf_out_desc* out, hipStream_t stream, int force_mode);
+
+static int g_kf_emit_mode = -1;  // -1 = choose from the layout
+
+}  // namespace bf
+
+extern "C" {
+
+int bf_version(void) { return BF_VERSION; }
+
+const char* bf_last_error(void) { return bf::last_error_buf(); }
+
+int bf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int i = 0; i < n; ++i) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, i) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;
+  }
+  return ok;
+}
+
+int bf_set_option(const char* name, int value) {
+  if (name && std::strcmp(name, "kf_emit_mode") == 0) {
+    if (value < -1 || value > 2) return bf::set_error(BF_EINVAL, "kf_emit_mode must be -1..2");
+    bf::g_kf_emit_mode = value;
+    return BF_OK;
+  }
+  return bf::set_error(BF_EINVAL, "unknown option '%s'", name ? name : "(null)");
+}
+
+int64_t bf_bytes_per_step(int32_t n, int32_t m, int32_t K, const bf_out_desc* out) {
+  int64_t per = 0;
+  if (!out) {
+    per = 1 + 2 * (int64_t)n + 2 * (int64_t)n * n;
+  } else {
+    if (out->weights.ptr) per += 1;
+    if (out->means.ptr) per += n;
+    if (out->covs.ptr) per += (int64_t)n * n;
+    if (out->pred_means.ptr) per += n;
+    if (out->pred_covs.ptr) per += (int64_t)n * n;
+    if (out->loglik.ptr) per += 1;
+  }
+  return 4 * (int64_t)m + 4 * (int64_t)K * per;
+}
+
+int bf_kalman_filter_f32(const bf_lgssm* model, const bf_cstream* y, int64_t B, int64_t T, const bf_carry* carry,
+                         const bf_out_desc* out, void* stream) {
+  if (!model || !y || !carry || !out) return bf::set_error(BF_EINVAL, "NULL argument");
+  if (B <= 0 || T <= 0) return bf::set_error(BF_EINVAL, "B and T must be positive (B=%lld, T=%lld)", (long long)B, (long long)T);
+  if (model->n <= 0 || model->m <= 0 || model->dq <= 0 || model->dr <= 0)
+    return bf::set_error(BF_EINVAL, "non-positive model dimension");
+  if (!model->A || !model->H || !model->Q || !model->R) return bf::set_error(BF_EINVAL, "A, H, Q, R are required");
+  if (!model->G && model->dq != model->n) return bf::set_error(BF_EINVAL, "G == NULL requires dq == n");
+  if (!model->D && model->dr != model->m) return bf::set_error(BF_EINVAL, "D == NULL requires dr == m");
+  if (model->Q_steps < 1 || model->R_steps < 1) return bf::set_error(BF_EINVAL, "Q_steps / R_steps must be >= 1");
+  if (!y->ptr) return bf::set_error(BF_EINVAL, "observations pointer is NULL");
+  if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
+  return bf::launch_kf_small(model, y, B, T, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode);
+}
+
+}  // extern "C"

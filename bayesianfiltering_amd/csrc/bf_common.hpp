@@ -1,0 +1,51 @@
+// Internal helpers shared by the C-ABI translation units (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+#include "../../include/bayesfilt.h"
+
+namespace bf {
+
+// thread-local text for bf_last_error()
+char* last_error_buf();
+int set_error(int code, const char* fmt, ...);
+
+#define BF_HIP_CHECK(expr)                                                                   \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return ::bf::set_error(BF_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                             __FILE__, __LINE__);                                            \
+  } while (0)
+
+// Device-side view of one strided stream with the component axis folded in by the caller.
+struct SView {
+  float* p;
+  long long sB, sK, sT, sE;
+};
+struct CView {
+  const float* p;
+  long long sB, sT, sE;
+};
+
+inline SView make_sview(const bf_stream& s) { return SView{s.ptr, s.sB, s.sK, s.sT, s.sE}; }
+
+struct OutViews {
+  SView w, m, P, pm, pP, ll;
+};
+
+struct CarryView {
+  const float* w_in;
+  const float* m_in;
+  const float* P_in;
+  float* w_out;
+  float* m_out;
+  float* P_out;
+};
+
+// Layout classification of an output descriptor (see bayesfilt.h, bf_stream).
+enum Layout { LAYOUT_GENERIC = 0, LAYOUT_REFERENCE = 1, LAYOUT_BATCH_INNER = 2 };
+
+}  // namespace bf

@@ -1,0 +1,185 @@
+"""Model-function registry: the device-side replacement for the Python callables of the reference.
+
+In the reference, ``ParamsNLSSM.dynamics_function`` / ``emission_function`` are arbitrary Python
+lambdas ``f(x, q, u)``, ``h(x, r, u)`` (gaussfiltax/models.py:46-49) differentiated by ``jacfwd``
+(gaussfiltax/inference.py:328-329).  Python callables cannot cross the C-ABI, so the functions
+the reference actually uses are enumerated here; each factory returns a :class:`DeviceFunction`
+that (a) is callable on the host with the reference's signature (NumPy, for simulation and
+inspection only -- never used by the filters) and (b) carries the ``fn_id`` / ``theta`` the HIP
+kernels dispatch on, where value and analytic Jacobians are evaluated per lane.
+
+Catalogue (reference sources):
+  linear_dynamics / linear_emission   docs/experiments/adaptive_experiment.py:59-64,
+                                      docs/experiments/BOT_Experiment_script.py:31-41
+  lorenz96 / pick_even (f96 / g96)    gaussfiltax/nonlinearities.py:37-50
+  lorenz63                            docs/experiments/exp_lorentz63.py:37-41
+  maneuver_bot / bearing_range        docs/experiments/BOT_Experiment_script.py:31-44
+  sine / quadratic / growth           docs/notebooks/Experiment_TSP_2023.ipynb cell 2 (f1, g1, f3)
+  stoch_vol                           docs/experiments/adaptive_experiment.py:51-54 (glmsv)
+  gaussian_log_prob                   the ``*lp`` pattern, e.g. gaussfiltax/nonlinearities.py:51-52
+"""
+import numpy as np
+
+F32 = np.float32
+
+# fn_id values shared with csrc/models.hpp
+DYN_LINEAR, DYN_LORENZ96, DYN_LORENZ63, DYN_MANEUVER_BOT, DYN_SINE, DYN_GROWTH = 0, 1, 2, 3, 4, 5
+EMI_LINEAR, EMI_BEARING_RANGE, EMI_QUADRATIC, EMI_STOCH_VOL = 0, 1, 2, 3
+
+
+class DeviceFunction:
+    """A registry function: host-callable, and dispatchable on the device by (kind, fn_id, theta)."""
+
+    def __init__(self, kind, fn_id, in_dim, out_dim, noise_dim, theta, host_fn, name):
+        self.kind, self.fn_id = kind, int(fn_id)
+        self.in_dim, self.out_dim, self.noise_dim = int(in_dim), int(out_dim), int(noise_dim)
+        self.theta = np.ascontiguousarray(theta, dtype=F32).ravel()
+        self._host_fn, self.name = host_fn, name
+
+    def __call__(self, x, w, u=None):
+        x = np.asarray(x, dtype=F32)
+        w = np.broadcast_to(np.asarray(w, dtype=F32), (self.noise_dim,)) if np.ndim(w) == 0 else np.asarray(w, dtype=F32)
+        u0 = F32(0.0) if u is None else F32(np.asarray(u, dtype=F32).reshape(-1)[0])
+        return np.asarray(self._host_fn(x, w, u0), dtype=F32)
+
+    def __repr__(self):
+        return f"DeviceFunction({self.name}, kind={self.kind}, in={self.in_dim}, out={self.out_dim}, noise={self.noise_dim})"
+
+
+def _linear(kind, fid, M, N, name):
+    M = np.atleast_2d(np.asarray(M, dtype=F32))
+    N = np.eye(M.shape[0], dtype=F32) if N is None else np.atleast_2d(np.asarray(N, dtype=F32))
+    if N.shape[0] != M.shape[0]:
+        raise ValueError("noise matrix must have as many rows as the function has outputs")
+    fn = DeviceFunction(kind, fid, M.shape[1], M.shape[0], N.shape[1], np.concatenate([M.ravel(), N.ravel()]),
+                        lambda x, w, u: M @ x + N @ w, name)
+    fn.M, fn.N = M, N
+    return fn
+
+
+def linear_dynamics(A, G=None):
+    """f(x, q, u) = A x + G q   (G defaults to the identity)."""
+    return _linear("dynamics", DYN_LINEAR, A, G, "linear_dynamics")
+
+
+def linear_emission(H, D=None):
+    """h(x, r, u) = H x + D r   (D defaults to the identity)."""
+    return _linear("emission", EMI_LINEAR, H, D, "linear_emission")
+
+
+def lorenz96(state_dim, alpha=1.0, beta=1.0, gamma=8.0, dt=0.01, mode="matrix_power"):
+    """f96 of gaussfiltax/nonlinearities.py:49.  mode='matrix_power' is the intended Lorenz-96
+    ((Bx)_i = x_{i+1} - x_{i-2}); mode='as_written' reproduces the element-wise jnp.power of
+    :48, which makes B == 0."""
+    if mode not in ("matrix_power", "as_written"):
+        raise ValueError(mode)
+    a, b, g, h = F32(alpha), F32(beta), F32(gamma), F32(dt)
+    mp = mode == "matrix_power"
+
+    def host(x, q, u):
+        ax = np.roll(x, 1)
+        bx = (np.roll(x, -1) - np.roll(x, 2)) if mp else np.zeros_like(x)
+        return x + h * (a * ax * bx - b * x + g) + q
+    return DeviceFunction("dynamics", DYN_LORENZ96, state_dim, state_dim, state_dim,
+                          [alpha, beta, gamma, dt, 1.0 if mp else 0.0], host, f"lorenz96[{mode}]")
+
+
+def pick_even(state_dim):
+    """g96 of gaussfiltax/nonlinearities.py:42-45,50: observe the even-indexed states, m = n/2."""
+    m = state_dim // 2
+    H = np.zeros((m, state_dim), dtype=F32)
+    H[np.arange(m), 2 * np.arange(m)] = 1.0
+    return linear_emission(H)
+
+
+def lorenz63(sigma=10.0, rho=28.0, beta=2.667, dt=0.01):
+    s, r, b, h = F32(sigma), F32(rho), F32(beta), F32(dt)
+
+    def host(x, q, u):
+        return np.array([x[0] + h * s * (x[1] - x[0]),
+                         x[1] + h * (x[0] * r - x[1] - x[0] * x[2]),
+                         x[2] + h * (x[0] * x[1] - b * x[2])], dtype=F32) + q
+    return DeviceFunction("dynamics", DYN_LORENZ63, 3, 3, 3, [sigma, rho, beta, dt], host, "lorenz63")
+
+
+def maneuver_bot(dt=0.5, acc=0.5):
+    """fManBOT of docs/experiments/BOT_Experiment_script.py:31-42; u in {0, 1, 2} selects
+    constant-velocity / left turn / right turn."""
+    h, a = F32(dt), F32(acc)
+    G = np.array([[0.5, 0], [1, 0], [0, 0.5], [0, 1]], dtype=F32)
+    FCV = np.array([[1, h, 0, 0], [0, 1, 0, 0], [0, 0, 1, h], [0, 0, 0, 1]], dtype=F32)
+
+    def fct(x, aa):
+        om = F32(0.1) * aa / np.sqrt(x[1] ** 2 + x[3] ** 2)
+        sn, cs = np.sin(h * om), np.cos(h * om)
+        return np.array([[1, sn / om, 0, -(1 - cs) / om], [0, cs, 0, -sn],
+                         [0, (1 - cs) / om, 1, sn / om], [0, sn, 0, cs]], dtype=F32)
+
+    def host(x, q, u):
+        M = 0.5 * (u - 1) * (u - 2) * FCV - u * (u - 2) * fct(x, a) + 0.5 * u * (u - 1) * fct(x, -a)
+        return M.astype(F32) @ x + G @ q
+    return DeviceFunction("dynamics", DYN_MANEUVER_BOT, 4, 4, 2, [dt, acc], host, "maneuver_bot")
+
+
+def bearing_range():
+    """gBOT2 of docs/experiments/BOT_Experiment_script.py:44."""
+    return DeviceFunction("emission", EMI_BEARING_RANGE, 4, 2, 2, [],
+                          lambda x, r, u: np.array([np.arctan2(x[2], x[0]), np.sqrt(x[0] ** 2 + x[2] ** 2)], dtype=F32) + r,
+                          "bearing_range")
+
+
+def sine(state_dim, w0=10.0):
+    w0_ = F32(w0)
+    return DeviceFunction("dynamics", DYN_SINE, state_dim, state_dim, state_dim, [w0],
+                          lambda x, q, u: np.sin(w0_ * x) + q, "sine")
+
+
+def quadratic(state_dim, c=1.0):
+    c_ = F32(c)
+    return DeviceFunction("emission", EMI_QUADRATIC, state_dim, 1, 1, [c],
+                          lambda x, r, u: np.reshape(c_ * np.dot(x, x) + r, (1,)), "quadratic")
+
+
+def growth():
+    return DeviceFunction("dynamics", DYN_GROWTH, 1, 1, 1, [],
+                          lambda x, q, u: x / F32(2) + F32(25) * x / (1 + x * x) + u + q, "growth")
+
+
+def stoch_vol(state_dim, sigma=5.0, beta=0.5, c=0.1):
+    s, b, c_ = F32(sigma), F32(beta), F32(c)
+    return DeviceFunction("emission", EMI_STOCH_VOL, state_dim, state_dim, state_dim, [sigma, beta, c],
+                          lambda x, r, u: u * b * np.exp(x / s) * r + (1 - u) * (c_ * x + r), "stoch_vol")
+
+
+class GaussianLogProb:
+    """``lambda x, y, u: MVN(loc=h(x, r_eval, u), covariance_matrix=R).log_prob(y)``: the
+    emission log-density every ``*lp`` function of the reference's scripts has (e.g. g96lp,
+    gaussfiltax/nonlinearities.py:51-52).  The bootstrap particle filter evaluates it on the
+    device; this object only carries (h, R, r_eval)."""
+
+    def __init__(self, emission_function, covariance, r_eval=None):
+        if not isinstance(emission_function, DeviceFunction) or emission_function.kind != "emission":
+            raise TypeError("emission_function must be an emission DeviceFunction from this module")
+        self.emission_function = emission_function
+        self.covariance = np.asarray(covariance, dtype=F32)
+        self.r_eval = (np.zeros(emission_function.noise_dim, dtype=F32) if r_eval is None
+                       else np.asarray(r_eval, dtype=F32))
+
+    def __call__(self, x, y, u=None):
+        mu = self.emission_function(x, self.r_eval, u)
+        L = np.linalg.cholesky(self.covariance.astype(np.float64))
+        z = np.linalg.solve(L, np.asarray(y, dtype=np.float64) - mu)
+        return F32(-0.5 * z @ z - np.log(np.diag(L)).sum() - 0.5 * len(z) * np.log(2 * np.pi))
+
+
+def gaussian_log_prob(emission_function, covariance, r_eval=None):
+    return GaussianLogProb(emission_function, covariance, r_eval)
+
+
+def require_device_function(fn, kind, what):
+    if not isinstance(fn, DeviceFunction) or fn.kind != kind:
+        raise TypeError(
+            f"{what} must be a {kind} DeviceFunction from bayesianfiltering_amd.nonlinearities "
+            f"(got {type(fn).__name__}): Python callables cannot run inside the HIP kernels, and "
+            "there is no CPU fallback.")
+    return fn

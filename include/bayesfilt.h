@@ -1,0 +1,125 @@
+/* bayesfilt.h -- C-ABI of the MI355X-native batched Bayesian-filtering engine.
+ *
+ * The reference (kostastsa/BayesianFiltering, package `gaussfiltax`) has no FFI/plugin
+ * interface; its boundary for the filtering hot path is the Python call surface
+ *
+ *   gaussian_sum_filter(params, emissions, num_components, num_iter, inputs)
+ *                                               gaussfiltax/inference.py:303-309
+ *   bootstrap_particle_filter(params, emissions, num_particles, key, inputs, ess_threshold)
+ *                                               gaussfiltax/inference.py:1302-1309
+ *
+ * Each entry point below replaces the `lax.scan` body of one of those drivers
+ * (inference.py:333-371 and :1330-1377) for a whole batch of independent trajectories.
+ * Conventions: extern "C", plain pointers and sizes, no exceptions; every function returns an
+ * int status (0 = BF_OK, negative = BF_E*; text via bf_last_error()).  All array arguments
+ * named `d_*` or carried in bf_stream/bf_cstream/bf_carry are DEVICE pointers owned by the
+ * caller; the engine never allocates outputs.  Model parameter structs hold HOST pointers to
+ * small row-major fp32 arrays which are copied into kernel arguments at launch.  `stream` is a
+ * hipStream_t passed as void* (NULL = the default stream).  Launches are asynchronous.
+ *
+ * Arithmetic is fp32 like the reference's JAX path (no jax_enable_x64 anywhere); the
+ * reference's quirks are reproduced: update -> reweight -> predict order,
+ * psd_solve = LU solve of (S + 1e-6 on every entry) (gaussfiltax/utils.py:256-259),
+ * P+ = P - K S K^T with the un-jittered S, log-likelihood by Cholesky of the un-jittered S,
+ * linear-domain weights.
+ */
+#ifndef BAYESFILT_H_
+#define BAYESFILT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BF_VERSION 100 /* 0.1.0 */
+
+#define BF_OK 0
+#define BF_EINVAL (-1)       /* bad argument (NULL pointer, non-positive size, misaligned) */
+#define BF_EUNSUPPORTED (-2) /* dimension / model / option not compiled into this build  */
+#define BF_EHIP (-3)         /* HIP runtime error (text in bf_last_error)                */
+#define BF_ENOGPU (-4)       /* no gfx950 device visible                                 */
+
+/* Strided view of an fp32 output stream.  Element (b, k, t, e) lives at
+ *   ptr[b*sB + k*sK + t*sT + e*sE]      (strides in ELEMENTS)
+ * where e indexes the row-major flattened event (vector entry i, or matrix entry i*n+j).
+ * ptr == NULL: the stream is not emitted.  Two layouts have tuned kernels:
+ *   "reference" [B][K][T][E] contiguous (sE = 1, sT = E, sK = T*E, sB = K*T*E): what the
+ *       reference returns per trajectory after swap_axes_on_values (inference.py:372), with
+ *       a leading batch axis;
+ *   "batch-inner" [K][T][E][B] (sB = 1): the scan-native order, perfectly coalesced.
+ * Any other stride set runs on the generic strided path. */
+typedef struct bf_stream {
+  float* ptr;
+  int64_t sB, sK, sT, sE;
+} bf_stream;
+
+typedef struct bf_cstream {
+  const float* ptr;
+  int64_t sB, sK, sT, sE; /* sK unused for observations / inputs */
+} bf_cstream;
+
+/* The five arrays of PosteriorGaussianSumFiltered (inference.py:29-39, emitted at
+ * :357-363) plus the per-step component log-likelihoods (the `lls` of :345, which the
+ * reference computes but does not return). */
+typedef struct bf_out_desc {
+  bf_stream weights;    /* E = 1    */
+  bf_stream means;      /* E = n    */
+  bf_stream covs;       /* E = n*n  */
+  bf_stream pred_means; /* E = n    */
+  bf_stream pred_covs;  /* E = n*n  */
+  bf_stream loglik;     /* E = 1    */
+} bf_out_desc;
+
+/* Scan carry (weights, pred_means, pred_covs) of inference.py:334,356: the state the filter
+ * starts from and (optionally) the state it ends with, so that T can be processed in chunks
+ * when the full posterior history exceeds HBM.  Contiguous [B][K], [B][K][n], [B][K][n][n].
+ * *_out may alias *_in; NULL *_out = not written.  w_in == NULL means 1/K (inference.py:369). */
+typedef struct bf_carry {
+  const float* w_in;
+  const float* m_in; /* required: initial (predicted) means, inference.py:367 */
+  const float* P_in; /* required: initial (predicted) covariances, inference.py:368 */
+  float* w_out;
+  float* m_out;
+  float* P_out;
+} bf_carry;
+
+/* Linear-Gaussian SSM   f(x,q,u) = A x + G q,  h(x,r,u) = H x + D r   (the "Kalman" model:
+ * gaussian_sum_filter with num_components = 1 and linear f, h; e.g.
+ * docs/experiments/adaptive_experiment.py:59-64, BOT_Experiment_script.py:31-41).
+ * HOST pointers, row-major fp32.  G == NULL: identity (dq = n); D == NULL: identity (dr = m);
+ * q0 / r0 == NULL: zeros.  Q_steps / R_steps: 1 = time-invariant [d,d]; T = one matrix per
+ * step [T,d,d] (the `_get_params(x, 2, t)` rule of inference.py:21,337-340). */
+typedef struct bf_lgssm {
+  int32_t n, dq, m, dr;
+  const float *A, *G, *H, *D;
+  const float *q0, *r0;
+  const float *Q, *R;
+  int32_t Q_steps, R_steps;
+} bf_lgssm;
+
+int bf_version(void);
+const char* bf_last_error(void);
+/* Number of visible gfx950 devices (0 if none / HIP unavailable). */
+int bf_device_count(void);
+
+/* Tuning / test hook.  "kf_emit_mode": -1 = choose the store path from the layout (default),
+ * 0 = scalar strided stores, 1 = per-lane row stores, 2 = LDS time-transpose (reference layout). */
+int bf_set_option(const char* name, int value);
+
+/* Batched Kalman filter: B independent trajectories, one component each (K = 1), T steps.
+ * Replaces the lax.scan of gaussian_sum_filter (inference.py:333-371) with
+ * _condition_on (:72-105) and _predict (:51-70) specialised to linear f, h.
+ * y: observations, element (b, t, e) at y->ptr[b*sB + t*sT + e*sE], E = m. */
+int bf_kalman_filter_f32(const bf_lgssm* model, const bf_cstream* y, int64_t B, int64_t T,
+                         const bf_carry* carry, const bf_out_desc* out, void* stream);
+
+/* Bytes one (trajectory, timestep) moves for the streams enabled in `out`: the algorithmic
+ * traffic figure of SURVEY.md 8(d)  (4m + 4K(1 + 2n + 2n^2) for all five streams). */
+int64_t bf_bytes_per_step(int32_t n, int32_t m, int32_t K, const bf_out_desc* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BAYESFILT_H_ */

@@ -1,0 +1,419 @@
+"""Oracle (test infrastructure): NumPy fp32 restatement of the reference's JAX filters.
+
+Follows, line by line (paths relative to /root/reference):
+  _predict                  gaussfiltax/inference.py:51-70
+  _condition_on             gaussfiltax/inference.py:72-105
+  _kalman_step (unused)     gaussfiltax/inference.py:107-120
+  _MVN_log_prob             gaussfiltax/inference.py:24  (+ tfp MVNFullCovariance.log_prob)
+  _get_params/_process_input/swap_axes_on_values   gaussfiltax/inference.py:21-26
+  gaussian_sum_filter       gaussfiltax/inference.py:303-377
+  bootstrap_particle_filter gaussfiltax/inference.py:1302-1380
+  psd_solve, _resample, collapse   gaussfiltax/utils.py:256-259, 207-214, 10-18
+  ParamsNLSSM / ParamsBPF   gaussfiltax/models.py:26-84
+  NonlinearSSM.sample       gaussfiltax/models.py:240-289
+
+Quirks reproduced on purpose: update->reweight->predict order; psd_solve adds
+1e-6 to EVERY entry of S and uses LU (sgesv); posterior covariance P - K S K^T with the
+un-jittered S and no symmetrisation; log-likelihood from a Cholesky of the un-jittered S;
+linear-domain weights (0/0 -> NaN allowed); num_iter ignored; inputs=None -> zeros((T,1));
+time-varying parameters only through an extra leading axis on the (d,d) covariances.
+
+All arithmetic float32.  PARITY UNPINNED against the real reference (see oracle/__init__.py).
+"""
+from typing import NamedTuple, Optional, Callable
+import numpy as np
+
+from . import threefry as tf
+
+F32 = np.float32
+_LOG2PI = F32(np.log(2.0 * np.pi))
+
+
+# --------------------------------------------------------------------------- containers
+class ParamsNLSSM(NamedTuple):
+    """gaussfiltax/models.py:26-51 (field names and order identical)."""
+    initial_mean: np.ndarray
+    initial_covariance: np.ndarray
+    dynamics_function: Callable
+    dynamics_noise_bias: np.ndarray
+    dynamics_noise_covariance: np.ndarray
+    emission_function: Callable
+    emission_noise_bias: np.ndarray
+    emission_noise_covariance: np.ndarray
+
+
+class ParamsBPF(NamedTuple):
+    """gaussfiltax/models.py:55-84."""
+    initial_mean: np.ndarray
+    initial_covariance: np.ndarray
+    dynamics_function: Callable
+    dynamics_noise_bias: np.ndarray
+    dynamics_noise_covariance: np.ndarray
+    emission_function: Callable
+    emission_noise_bias: np.ndarray
+    emission_noise_covariance: np.ndarray
+    emission_distribution_log_prob: Callable
+
+
+class PosteriorGaussianSumFiltered(NamedTuple):
+    """gaussfiltax/inference.py:29-39."""
+    weights: Optional[np.ndarray] = None
+    means: Optional[np.ndarray] = None
+    covariances: Optional[np.ndarray] = None
+    predicted_means: Optional[np.ndarray] = None
+    predicted_covariances: Optional[np.ndarray] = None
+
+
+# --------------------------------------------------------------------------- helpers
+def _get_params(x, dim, t):
+    """inference.py:21."""
+    x = np.asarray(x)
+    return x[t] if x.ndim == dim + 1 else x
+
+
+def _process_input(inputs, T):
+    """inference.py:23."""
+    return np.zeros((T, 1), dtype=F32) if inputs is None else np.asarray(inputs, dtype=F32)
+
+
+def _mm(a, b):
+    return np.matmul(a, b, dtype=F32)
+
+
+def psd_solve(A, b):
+    """utils.py:256-259: solve(A + 1e-6 (every entry), b) by LU with partial pivoting."""
+    A = (np.asarray(A, dtype=F32) + F32(1e-6)).astype(F32)
+    return np.linalg.solve(A, np.asarray(b, dtype=F32)).astype(F32)
+
+
+def lu_solve_explicit(A, b):
+    """The same solve written out (sgetrf/sgetrs order); cross-check of psd_solve's LAPACK call."""
+    A = np.array(A, dtype=F32)
+    b = np.array(b, dtype=F32)
+    n = A.shape[0]
+    for k in range(n):
+        p = k + int(np.argmax(np.abs(A[k:, k])))
+        if p != k:
+            A[[k, p]] = A[[p, k]]
+            b[[k, p]] = b[[p, k]]
+        for i in range(k + 1, n):
+            l = F32(A[i, k] / A[k, k])
+            A[i, k] = l
+            A[i, k + 1:] = (A[i, k + 1:] - l * A[k, k + 1:]).astype(F32)
+            b[i] = (b[i] - l * b[k]).astype(F32)
+    for i in range(n - 1, -1, -1):
+        for j in range(i + 1, n):
+            b[i] = (b[i] - A[i, j] * b[j]).astype(F32)
+        b[i] = (b[i] / A[i, i]).astype(F32)
+    return b
+
+
+def mvn_log_prob(mean, cov, y):
+    """inference.py:24: MVN(mean, cov).log_prob(atleast_1d(y)) via Cholesky (tfp MVNTriL)."""
+    mean = np.atleast_1d(np.asarray(mean, dtype=F32))
+    y = np.atleast_1d(np.asarray(y, dtype=F32))
+    cov = np.asarray(cov, dtype=F32).reshape(mean.size, mean.size)
+    try:
+        L = np.linalg.cholesky(cov).astype(F32)
+    except np.linalg.LinAlgError:
+        return F32(np.nan)
+    d = (y - mean).astype(F32)
+    z = np.empty_like(d)
+    for i in range(d.size):                      # forward substitution, fp32
+        acc = d[i]
+        for j in range(i):
+            acc = F32(acc - L[i, j] * z[j])
+        z[i] = F32(acc / L[i, i])
+    quad = F32(0.0)
+    logdet = F32(0.0)
+    for i in range(d.size):
+        quad = F32(quad + z[i] * z[i])
+        logdet = F32(logdet + np.log(L[i, i]))
+    return F32(F32(-0.5) * quad - F32(0.5) * F32(d.size) * _LOG2PI - logdet)
+
+
+# --------------------------------------------------------------------------- step math
+def _predict(m, P, fn, Q, q0, u):
+    """inference.py:51-70.  fn supplies f and its analytic Jacobians (jacfwd in the reference)."""
+    F_x = fn.jac_x(m, q0, u)
+    F_q = fn.jac_noise(m, q0, u)
+    mu_pred = fn.value(m, q0, u)
+    Sigma_pred = (_mm(_mm(F_x, P), F_x.T) + _mm(_mm(F_q, Q), F_q.T)).astype(F32)
+    return mu_pred, Sigma_pred, F_x
+
+
+def _condition_on(m, P, hn, R, r0, u, y):
+    """inference.py:72-105."""
+    H_x = hn.jac_x(m, r0, u)
+    H_r = hn.jac_noise(m, r0, u)
+    S = (_mm(_mm(H_r, R), H_r.T) + _mm(_mm(H_x, P), H_x.T)).astype(F32)
+    K = psd_solve(S, _mm(H_x, P)).T
+    posterior_cov = (P - _mm(_mm(K, S), K.T)).astype(F32)
+    hm = hn.value(m, r0, u)
+    posterior_mean = (m + _mm(K, (y - hm).astype(F32))).astype(F32)
+    ll = mvn_log_prob(hm, S, y)
+    return ll, posterior_mean, posterior_cov, H_x, K
+
+
+def _kalman_step(m, P, fn, Q, q0, u, hn, R, r0, y):
+    """inference.py:107-120 (dead code in the reference: predict THEN update)."""
+    mu_pred, Sigma_pred, _ = _predict(m, P, fn, Q, q0, u)
+    ll, pm, pc, _, _ = _condition_on(mu_pred, Sigma_pred, hn, R, r0, u, y)
+    return ll, pm, pc
+
+
+def reweight(lls, weights):
+    """inference.py:347-350 (and :1350-1353): linear-domain weight update."""
+    lls = np.asarray(lls, dtype=F32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        lls = (lls - np.max(lls)).astype(F32)
+        w = (np.exp(lls).astype(F32) * weights).astype(F32)
+        return (w / sum_f32(w)).astype(F32)
+
+
+def sum_f32(x):
+    """jnp.sum in fp32.  Adjacent-pair tree over a zero-padded power-of-two array (the
+    up-sweep of threefry.cumsum_assoc, so sum == cumsum[-1]): the canonical order shared with
+    the HIP kernels (XLA's reduction order is unspecified)."""
+    x = np.asarray(x, dtype=F32).ravel()
+    n = 1
+    while n < x.size:
+        n *= 2
+    buf = np.zeros(n, dtype=F32)
+    buf[:x.size] = x
+    while n > 1:
+        buf = (buf[0::2] + buf[1::2]).astype(F32)
+        n //= 2
+    return F32(buf[0])
+
+
+# --------------------------------------------------------------------------- GSF / (E)KF
+def initial_component_means(params, num_components, key=None):
+    """inference.py:367: MVN(m0, P0).sample(K, PRNGKey(0)) = m0 + chol(P0) @ z_k, with
+    z = normal(PRNGKey(0), (K, n)) (row-major).  Best-effort restatement of tfp's sampler."""
+    key = tf.PRNGKey(0) if key is None else key
+    m0 = np.asarray(params.initial_mean, dtype=F32)
+    n = m0.size
+    L = np.linalg.cholesky(np.asarray(params.initial_covariance, dtype=F32)).astype(F32)
+    z = tf.normal(key, num_components * n).reshape(num_components, n)
+    return (m0[None, :] + _mm(z, L.T)).astype(F32)
+
+
+def gaussian_sum_filter(params, emissions, num_components=1, num_iter=1, inputs=None,
+                        initial_means=None, return_ll=False):
+    """inference.py:303-377.  ``initial_means`` (K,n) overrides the PRNGKey(0) draw of :367."""
+    emissions = np.asarray(emissions, dtype=F32)
+    T = len(emissions)
+    K = num_components
+    fn, hn = params.dynamics_function, params.emission_function
+    inputs = _process_input(inputs, T)
+    n = np.asarray(params.initial_mean).size
+
+    if initial_means is None:
+        initial_means = initial_component_means(params, K)
+    pred_means = np.array(initial_means, dtype=F32).reshape(K, n)
+    pred_covs = np.stack([np.asarray(params.initial_covariance, dtype=F32)] * K)
+    weights = (np.ones(K, dtype=F32) / F32(K)).astype(F32)
+
+    out_w = np.empty((T, K), F32)
+    out_m = np.empty((T, K, n), F32)
+    out_P = np.empty((T, K, n, n), F32)
+    out_pm = np.empty((T, K, n), F32)
+    out_pP = np.empty((T, K, n, n), F32)
+    out_ll = np.empty((T, K), F32)
+
+    for t in range(T):
+        Q = np.asarray(_get_params(params.dynamics_noise_covariance, 2, t), dtype=F32)
+        q0 = np.asarray(_get_params(params.dynamics_noise_bias, 2, t), dtype=F32)
+        R = np.asarray(_get_params(params.emission_noise_covariance, 2, t), dtype=F32)
+        r0 = np.asarray(_get_params(params.emission_noise_bias, 2, t), dtype=F32)
+        u = inputs[t]
+        y = emissions[t]
+        lls = np.empty(K, F32)
+        fm = np.empty((K, n), F32)
+        fP = np.empty((K, n, n), F32)
+        for k in range(K):
+            lls[k], fm[k], fP[k], _, _ = _condition_on(pred_means[k], pred_covs[k], hn, R, r0, u, y)
+        out_ll[t] = lls
+        weights = reweight(lls, weights)
+        for k in range(K):
+            pred_means[k], pred_covs[k], _ = _predict(fm[k], fP[k], fn, Q, q0, u)
+        out_w[t], out_m[t], out_P[t], out_pm[t], out_pP[t] = weights, fm, fP, pred_means, pred_covs
+
+    post = PosteriorGaussianSumFiltered(
+        weights=out_w.swapaxes(0, 1).copy(),
+        means=out_m.swapaxes(0, 1).copy(),
+        covariances=out_P.swapaxes(0, 1).copy(),
+        predicted_means=out_pm.swapaxes(0, 1).copy(),
+        predicted_covariances=out_pP.swapaxes(0, 1).copy(),
+    )
+    if return_ll:
+        return post, out_ll.swapaxes(0, 1).copy()
+    return post
+
+
+def collapse(mean_mat, covariance_tens, weight_vec):
+    """utils.py:10-18 (moment-matched single Gaussian; the reference runs this in NumPy fp64
+    on whatever dtype it is handed; here the inputs' dtype is kept)."""
+    M, dx = np.shape(mean_mat)
+    mean_out = np.matmul(weight_vec, mean_mat)
+    cov_out = np.zeros([dx, dx], dtype=mean_out.dtype)
+    for m in range(M):
+        diff = mean_mat[m] - mean_out
+        cov_out = cov_out + weight_vec[m] * (covariance_tens[m] + np.tensordot(diff, diff, axes=0))
+    return mean_out, cov_out
+
+
+def point_estimate(post):
+    """sum_k w_k m_k per t (docs/experiments/BOT_Experiment_script.py:101)."""
+    return np.sum(post.means * post.weights[..., None], axis=0).astype(F32)
+
+
+# --------------------------------------------------------------------------- BPF
+class GaussianEmissionLogProb:
+    """MVN(loc=h(x, r_eval, u), covariance_matrix=R).log_prob(y): the form of every
+    ``*lp`` function the reference's scripts define (e.g. nonlinearities.py:51-52 g96lp,
+    BOT_Experiment_script.py:45 gBOTlp)."""
+
+    def __init__(self, hn, R, r_eval=None):
+        self.hn = hn
+        self.R = np.asarray(R, dtype=F32)
+        self.r_eval = np.zeros(hn.noise_dim, dtype=F32) if r_eval is None else np.asarray(r_eval, dtype=F32)
+
+    def __call__(self, x, y, u):
+        return mvn_log_prob(self.hn.value(np.asarray(x, dtype=F32), self.r_eval, u), self.R, y)
+
+
+def sample_dynamics_distribution(params, key, x, u, cholQ=None):
+    """models.py:82-84: q = MVN(q0, Q).sample(seed=key); return f(x, q, u)."""
+    if cholQ is None:
+        cholQ = np.linalg.cholesky(np.asarray(params.dynamics_noise_covariance, dtype=F32)).astype(F32)
+    q = tf.mvn_sample(key, np.asarray(params.dynamics_noise_bias, dtype=F32), cholQ)
+    return params.dynamics_function.value(np.asarray(x, dtype=F32), q, u)
+
+
+def _resample(weights, particles, key):
+    """utils.py:207-214 (multinomial inverse-CDF; returns also the ancestor indices)."""
+    keys = tf.split(key, 2)
+    N = weights.shape[0]
+    idx = tf.choice(keys[0], weights)
+    idx = np.minimum(idx, N - 1)
+    return (np.ones(N, dtype=F32) / F32(N)).astype(F32), particles[idx], keys[1], idx
+
+
+def systematic_indices(weights, u0):
+    """Systematic resampling (north_star's alternative; NOT the reference's semantics):
+    positions (i + u0)/N against the canonical cumsum."""
+    N = weights.shape[0]
+    cdf = tf.cumsum_assoc(weights)
+    pos = ((np.arange(N, dtype=F32) + F32(u0)) / F32(N)).astype(F32) * cdf[-1]
+    return np.minimum(np.searchsorted(cdf, pos.astype(F32), side="left"), N - 1).astype(np.int32)
+
+
+def bootstrap_particle_filter(params, emissions, num_particles, key=None, inputs=None,
+                              ess_threshold=0.5, resampler="multinomial", debug=False):
+    """inference.py:1302-1380."""
+    key = tf.PRNGKey(0) if key is None else np.asarray(key, dtype=np.uint32)
+    emissions = np.asarray(emissions, dtype=F32)
+    T = len(emissions)
+    N = num_particles
+    inputs = _process_input(inputs, T)
+    m0 = np.asarray(params.initial_mean, dtype=F32)
+    n = m0.size
+    L0 = np.linalg.cholesky(np.asarray(params.initial_covariance, dtype=F32)).astype(F32)
+
+    keys = tf.split(key, N + 1)                                  # :1369
+    next_key = keys[0]
+    weights = (np.ones(N, dtype=F32) / F32(N)).astype(F32)
+    particles = np.stack([tf.mvn_sample(keys[1 + i], m0, L0) for i in range(N)])   # :1372-1373
+
+    out_w = np.empty((T, N), F32)
+    out_x = np.empty((T, N, n), F32)
+    dbg = {"resampled": np.zeros(T, bool), "ancestors": np.tile(np.arange(N, dtype=np.int32), (T, 1)),
+           "ess": np.zeros(T, F32), "pre_weights": np.empty((T, N), F32)}
+
+    for t in range(T):
+        Qt = np.asarray(_get_params(params.dynamics_noise_covariance, 2, t), dtype=F32)
+        cholQ = np.linalg.cholesky(Qt).astype(F32)
+        u = inputs[t]
+        y = emissions[t]
+        keys = tf.split(next_key, N + 1)                          # :1342
+        next_key = keys[0]
+        new_particles = np.stack([sample_dynamics_distribution(params, keys[1 + i], particles[i], u, cholQ)
+                                  for i in range(N)])            # :1344-1345
+        lls = np.array([params.emission_distribution_log_prob(new_particles[i], y, u) for i in range(N)],
+                       dtype=F32)                                 # :1348-1349
+        new_weights = reweight(lls, weights)                     # :1350-1353
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ess = F32(1.0) / sum_f32((new_weights * new_weights).astype(F32))
+        dbg["ess"][t] = ess
+        dbg["pre_weights"][t] = new_weights
+        if ess < F32(ess_threshold) * F32(N):                    # :1356
+            if resampler == "multinomial":
+                weights, new_particles, next_key, idx = _resample(new_weights, new_particles, next_key)
+            else:
+                ks = tf.split(next_key, 2)
+                idx = systematic_indices(new_weights, tf.uniform(ks[0], 1)[0])
+                new_particles = new_particles[idx]
+                weights = (np.ones(N, dtype=F32) / F32(N)).astype(F32)
+                next_key = ks[1]
+            dbg["resampled"][t] = True
+            dbg["ancestors"][t] = idx
+        else:
+            weights = new_weights
+        particles = new_particles
+        out_w[t] = weights
+        out_x[t] = particles
+
+    out = {"weights": out_w.swapaxes(0, 1).copy(), "particles": out_x.swapaxes(0, 1).copy()}
+    return (out, dbg) if debug else out
+
+
+# --------------------------------------------------------------------------- data generator
+def sample_ssm(params, key, num_timesteps, inputs=None):
+    """NonlinearSSM.sample, models.py:240-289 (tfp sampler restated as loc + chol @ normal)."""
+    inputs = _process_input(inputs, num_timesteps)
+    fn, hn = params.dynamics_function, params.emission_function
+    q0 = np.asarray(params.dynamics_noise_bias, dtype=F32)
+    r0 = np.asarray(params.emission_noise_bias, dtype=F32)
+    LQ = np.linalg.cholesky(np.asarray(params.dynamics_noise_covariance, dtype=F32)).astype(F32)
+    LR = np.linalg.cholesky(np.asarray(params.emission_noise_covariance, dtype=F32)).astype(F32)
+    L0 = np.linalg.cholesky(np.asarray(params.initial_covariance, dtype=F32)).astype(F32)
+    k = tf.split(np.asarray(key, dtype=np.uint32), 3)            # key1, key2, key  (:273)
+    state = tf.mvn_sample(k[0], np.asarray(params.initial_mean, dtype=F32), L0)
+    r = tf.mvn_sample(k[1], r0, LR)
+    states = [state]
+    emis = [hn.value(state, r, inputs[0])]
+    next_keys = tf.split(k[2], num_timesteps - 1)                # :280
+    for t in range(1, num_timesteps):
+        k1, k2 = tf.split(next_keys[t - 1], 2)                   # :262
+        q = tf.mvn_sample(k1, q0, LQ)
+        r = tf.mvn_sample(k2, r0, LR)
+        state = fn.value(state, q, inputs[t])
+        states.append(state)
+        emis.append(hn.value(state, r, inputs[t]))
+    return np.stack(states).astype(F32), np.stack(emis).astype(F32)
+
+
+# --------------------------------------------------------------------------- fp64 textbook KF
+def textbook_kalman_f64(A, GQGt, H, R, m0, P0, ys):
+    """Independent fp64 textbook Kalman filter (no jitter, Joseph-free), same step order as the
+    reference (update at t with the carried prior, then predict).  Used to PIN the oracle."""
+    A, GQGt, H, R = (np.asarray(v, dtype=np.float64) for v in (A, GQGt, H, R))
+    m = np.asarray(m0, dtype=np.float64).copy()
+    P = np.asarray(P0, dtype=np.float64).copy()
+    T = len(ys)
+    n = m.size
+    fm, fP, pm, pP, ll = (np.empty((T, n)), np.empty((T, n, n)), np.empty((T, n)), np.empty((T, n, n)), np.empty(T))
+    for t in range(T):
+        S = H @ P @ H.T + R
+        K = np.linalg.solve(S, H @ P).T
+        v = ys[t] - H @ m
+        ll[t] = -0.5 * (v @ np.linalg.solve(S, v) + np.log(np.linalg.det(S)) + len(v) * np.log(2 * np.pi))
+        m = m + K @ v
+        P = P - K @ S @ K.T
+        fm[t], fP[t] = m, P
+        m = A @ m
+        P = A @ P @ A.T + GQGt
+        pm[t], pP[t] = m, P
+    return fm, fP, pm, pP, ll

@@ -1,0 +1,78 @@
+"""Shared builders for tests: the same model on the oracle side and on the product side."""
+import numpy as np
+
+from oracle import gaussfilt_oracle as go, models as om, threefry as otf
+
+F32 = np.float32
+
+
+def cv_model_arrays(dt=0.5, q=1e-2, r=1e-1):
+    """constant-velocity model of BOT_Experiment_script.py:31-32,40."""
+    A = np.array([[1, dt, 0, 0], [0, 1, 0, 0], [0, 0, 1, dt], [0, 0, 0, 1]], F32)
+    G = np.array([[0.5, 0], [1, 0], [0, 0.5], [0, 1]], F32)
+    H = np.array([[1, 0, 0, 0], [0, 0, 1, 0]], F32)
+    return dict(A=A, G=G, H=H, D=np.eye(2, dtype=F32), Q=q * np.eye(2, dtype=F32), R=r * np.eye(2, dtype=F32),
+                m0=np.zeros(4, F32), P0=np.eye(4, dtype=F32), q0=np.zeros(2, F32), r0=np.zeros(2, F32))
+
+
+def random_stable_lgssm(n, m, seed, dq=None, dr=None, bias=False):
+    rng = np.random.default_rng(seed)
+    dq = n if dq is None else dq
+    dr = m if dr is None else dr
+    Aq, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    A = (0.95 * Aq).astype(F32)
+    G = (np.eye(n, dq) + 0.1 * rng.normal(size=(n, dq))).astype(F32)
+    H = (rng.normal(size=(m, n)) / np.sqrt(n)).astype(F32)
+    D = (np.eye(m, dr) + 0.1 * rng.normal(size=(m, dr))).astype(F32)
+    Lq = 0.1 * rng.normal(size=(dq, dq)); Lr = 0.3 * rng.normal(size=(dr, dr))
+    Q = (Lq @ Lq.T + 1e-2 * np.eye(dq)).astype(F32)
+    R = (Lr @ Lr.T + 1e-1 * np.eye(dr)).astype(F32)
+    L0 = 0.5 * rng.normal(size=(n, n))
+    P0 = (L0 @ L0.T + 0.5 * np.eye(n)).astype(F32)
+    q0 = (0.1 * rng.normal(size=dq)).astype(F32) if bias else np.zeros(dq, F32)
+    r0 = (0.1 * rng.normal(size=dr)).astype(F32) if bias else np.zeros(dr, F32)
+    return dict(A=A, G=G, H=H, D=D, Q=Q, R=R, m0=rng.normal(size=n).astype(F32), P0=P0, q0=q0, r0=r0)
+
+
+def oracle_params(a):
+    return go.ParamsNLSSM(a["m0"], a["P0"], om.Linear(a["A"], a["G"]), a["q0"], a["Q"],
+                          om.Linear(a["H"], a["D"]), a["r0"], a["R"])
+
+
+def product_params(a):
+    import bayesianfiltering_amd as bfa
+    nl = bfa.nonlinearities
+    return bfa.ParamsNLSSM(a["m0"], a["P0"], nl.linear_dynamics(a["A"], a["G"]), a["q0"], a["Q"],
+                           nl.linear_emission(a["H"], a["D"]), a["r0"], a["R"])
+
+
+def simulate_batch(a, B, T, seed):
+    """Independent trajectories with NumPy's generator (no JAX needed), fp32."""
+    rng = np.random.default_rng(seed)
+    n, m = a["A"].shape[0], a["H"].shape[0]
+    dq, dr = a["G"].shape[1], a["D"].shape[1]
+    LQ, LR, L0 = (np.linalg.cholesky(a[k].astype(np.float64)) for k in ("Q", "R", "P0"))
+    x = a["m0"] + rng.normal(size=(B, n)) @ L0.T
+    ys = np.empty((B, T, m), F32)
+    for t in range(T):
+        x = x @ a["A"].T.astype(np.float64) + (a["q0"] + rng.normal(size=(B, dq)) @ LQ.T) @ a["G"].T
+        ys[:, t] = x @ a["H"].T + (a["r0"] + rng.normal(size=(B, dr)) @ LR.T) @ a["D"].T
+    return ys
+
+
+def oracle_kalman_batch(a, ys, init_means):
+    """Run the oracle trajectory by trajectory; returns dict of (B,1,T,...) arrays + loglik."""
+    p = oracle_params(a)
+    outs = {k: [] for k in ("weights", "means", "covariances", "predicted_means", "predicted_covariances", "loglik")}
+    for b in range(ys.shape[0]):
+        post, ll = go.gaussian_sum_filter(p, ys[b], 1, initial_means=init_means[b].reshape(1, -1), return_ll=True)
+        for k in post._fields:
+            outs[k].append(getattr(post, k))
+        outs["loglik"].append(ll)
+    return {k: np.stack(v) for k, v in outs.items()}
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))

@@ -1,0 +1,103 @@
+"""GPU parity of the batched Kalman kernel (through the C-ABI) against the NumPy oracle.
+
+Tolerance: north_star asks filtered means/covariances within 1e-5 relative in fp32."""
+import numpy as np
+import pytest
+
+from tests import common as cm
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+FIELDS = ("weights", "means", "covariances", "predicted_means", "predicted_covariances")
+
+
+def _run(a, ys, init, layout, mode=-1, **kw):
+    import bayesianfiltering_amd as bfa
+    from bayesianfiltering_amd import _lib
+    lib = _lib.require_gpu()
+    _lib.check(lib.bf_set_option(b"kf_emit_mode", mode))
+    try:
+        return bfa.kalman_filter(cm.product_params(a), ys, initial_means=init, layout=layout, **kw)
+    finally:
+        lib.bf_set_option(b"kf_emit_mode", -1)
+
+
+@pytest.mark.parametrize("layout,mode", [("reference", 2), ("reference", 1), ("reference", 0), ("batch_inner", -1)])
+def test_cv_model_matches_oracle(layout, mode):
+    a = cm.cv_model_arrays()
+    B, T = 130, 64          # ragged last wave (130 = 2*64 + 2)
+    ys = cm.simulate_batch(a, B, T, seed=1)
+    init = np.tile(a["m0"], (B, 1)) + np.random.default_rng(2).normal(size=(B, 4)).astype(np.float32)
+    ref = cm.oracle_kalman_batch(a, ys, init)
+    post, ll = _run(a, ys, init, layout, mode, return_loglik=True)
+    for k in FIELDS:
+        got = getattr(post, k).cpu().numpy()
+        assert got.shape == ref[k].shape
+        assert cm.rel_err(got, ref[k]) < TOL, k
+    assert cm.rel_err(ll.cpu().numpy(), ref["loglik"]) < 2e-5
+
+
+@pytest.mark.parametrize("n,m,dq,dr", [(1, 1, 1, 1), (2, 1, 2, 1), (2, 2, 1, 2), (3, 1, 3, 1), (3, 3, 3, 3),
+                                       (4, 1, 2, 1), (4, 2, 4, 2), (4, 4, 3, 4), (8, 4, 8, 4)])
+def test_random_lgssm_dims(n, m, dq, dr):
+    a = cm.random_stable_lgssm(n, m, seed=10 * n + m, dq=dq, dr=dr, bias=True)
+    B, T = 70, 48
+    ys = cm.simulate_batch(a, B, T, seed=3)
+    init = np.tile(a["m0"], (B, 1))
+    ref = cm.oracle_kalman_batch(a, ys, init)
+    for layout in ("reference", "batch_inner"):
+        post = _run(a, ys, init, layout)
+        for k in FIELDS:
+            assert cm.rel_err(getattr(post, k).cpu().numpy(), ref[k]) < TOL, (layout, k)
+
+
+def test_single_trajectory_shapes_like_reference():
+    a = cm.cv_model_arrays()
+    ys = cm.simulate_batch(a, 1, 32, seed=5)[0]
+    post = _run(a, ys, a["m0"][None], "reference")
+    assert tuple(post.means.shape) == (1, 32, 4) and tuple(post.covariances.shape) == (1, 32, 4, 4)
+    assert tuple(post.weights.shape) == (1, 32)
+    ref = cm.oracle_kalman_batch(a, ys[None], a["m0"][None])
+    assert cm.rel_err(post.predicted_covariances.cpu().numpy(), ref["predicted_covariances"][0]) < TOL
+
+
+def test_chunked_carry_equals_one_shot():
+    import bayesianfiltering_amd as bfa
+    a = cm.cv_model_arrays()
+    B, T = 64, 96
+    ys = cm.simulate_batch(a, B, T, seed=7)
+    p = cm.product_params(a)
+    full = bfa.kalman_filter(p, ys)
+    first, carry = bfa.kalman_filter(p, ys[:, :32], return_carry=True)
+    second = bfa.kalman_filter(p, ys[:, 32:], carry=carry)
+    for k in FIELDS:
+        whole = getattr(full, k).cpu().numpy()
+        parts = np.concatenate([getattr(first, k).cpu().numpy(), getattr(second, k).cpu().numpy()], axis=2)
+        assert np.array_equal(whole, parts), k     # same arithmetic, chunking must be bit-exact
+
+
+def test_time_varying_covariances():
+    a = cm.cv_model_arrays()
+    B, T = 8, 32
+    ys = cm.simulate_batch(a, B, T, seed=9)
+    rng = np.random.default_rng(0)
+    a = dict(a)
+    a["Q"] = (a["Q"][None] * (1 + rng.random((T, 1, 1)))).astype(np.float32)
+    a["R"] = (a["R"][None] * (1 + rng.random((T, 1, 1)))).astype(np.float32)
+    init = np.tile(a["m0"], (B, 1))
+    ref = cm.oracle_kalman_batch(a, ys, init)
+    post = _run(a, ys, init, "reference")
+    for k in FIELDS:
+        assert cm.rel_err(getattr(post, k).cpu().numpy(), ref[k]) < TOL, k
+
+
+def test_errors_are_loud():
+    import bayesianfiltering_amd as bfa
+    from bayesianfiltering_amd import _lib
+    a = cm.random_stable_lgssm(5, 2, seed=1)
+    ys = cm.simulate_batch(a, 2, 8, seed=1)
+    with pytest.raises(_lib.BayesFiltError) as e:
+        bfa.kalman_filter(cm.product_params(a), ys)
+    assert e.value.code == _lib.BF_EUNSUPPORTED
+    with pytest.raises(TypeError):
+        bfa.kalman_filter(cm.product_params(a)._replace(dynamics_function=lambda x, q, u: x), ys)
