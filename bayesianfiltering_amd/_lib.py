@@ -69,6 +69,10 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `make -C bayesianfiltering_amd/csrc` "
             "(or __graft_entry__.build()).  There is no CPU fallback.")
+    # PyTorch-ROCm bundles its own HIP runtime (same SONAME as /opt/rocm's): it must be the one
+    # already loaded when this library binds libamdhip64, or the process ends up with a mixed
+    # runtime and torch reports "No HIP GPUs are available".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)

@@ -161,7 +161,7 @@ def main():
     if rank == 0:
         bytes_per_step = int(lib.bf_bytes_per_step(n, m, 1, None))      # 4m + 4(1 + 2n + 2n^2) = 172
         achieved = bytes_per_step * B * T / (kernel_ms * 1e-3) / 1e9
-        value = world * B * T / elapsed
+        value = world * B * T * args.steps / elapsed
         line = {
             "metric": "filter timesteps/sec (batch x T)", "value": value, "unit": "timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
