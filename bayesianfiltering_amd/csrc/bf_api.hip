@@ -21,7 +21,11 @@ int set_error(int code, const char* fmt, ...) {
 int launch_kf_small(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
                     const bf_out_desc* out, hipStream_t stream, int force_mode);
 
+int launch_kf_cols(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
+                   const bf_out_desc* out, hipStream_t stream, int force_mode);
+
 static int g_kf_emit_mode = -1;  // -1 = choose from the layout
+static int g_kf_kernel = 0;      // 0 = column-per-lane (default), 1 = lane-per-chain baseline
 
 }  // namespace bf
 
@@ -46,6 +50,11 @@ int bf_set_option(const char* name, int value) {
   if (name && std::strcmp(name, "kf_emit_mode") == 0) {
     if (value < -1 || value > 2) return bf::set_error(BF_EINVAL, "kf_emit_mode must be -1..2");
     bf::g_kf_emit_mode = value;
+    return BF_OK;
+  }
+  if (name && std::strcmp(name, "kf_kernel") == 0) {
+    if (value < 0 || value > 1) return bf::set_error(BF_EINVAL, "kf_kernel must be 0 or 1");
+    bf::g_kf_kernel = value;
     return BF_OK;
   }
   return bf::set_error(BF_EINVAL, "unknown option '%s'", name ? name : "(null)");
@@ -78,7 +87,9 @@ int bf_kalman_filter_f32(const bf_lgssm* model, const bf_cstream* y, int64_t B, 
   if (model->Q_steps < 1 || model->R_steps < 1) return bf::set_error(BF_EINVAL, "Q_steps / R_steps must be >= 1");
   if (!y->ptr) return bf::set_error(BF_EINVAL, "observations pointer is NULL");
   if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
-  return bf::launch_kf_small(model, y, B, T, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode);
+  if (bf::g_kf_kernel == 1)
+    return bf::launch_kf_small(model, y, B, T, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode);
+  return bf::launch_kf_cols(model, y, B, T, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode);
 }
 
 }  // extern "C"

@@ -8,6 +8,25 @@ namespace bf {
 
 #define BF_UNROLL _Pragma("unroll")
 
+// Single-instruction transcendental forms (v_rcp_f32 / v_sqrt_f32 / v_log_f32 / v_exp_f32, each
+// accurate to ~1 ulp).  The IEEE-exact library forms cost ~10 VALU instructions apiece and the
+// recursions here are instruction-issue bound; the parity budget (1e-5 relative, fp32) is two
+// orders of magnitude above what these cost.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
+// The reweight of gaussfiltax/inference.py:347-350 for ONE component: lls -= max(lls) gives 0
+// (NaN if ll is not finite), w <- exp(0) * w, w <- w / sum(w) = w / w: exactly 1.0 unless
+// something is non-finite or w == 0, in which case NaN -- evaluated without exp or division.
+__device__ __forceinline__ float reweight_single(float ll, float w) {
+  const float l0 = ll - ll;          // 0, or NaN for +-inf / NaN
+  const float wn = (l0 + 1.0f) * w;  // exp(0) * w
+  const bool ok = (wn == wn) && (wn != 0.0f) && (fabsf(wn) != __builtin_inff());
+  return ok ? 1.0f : __builtin_nanf("");
+}
+
 // c[R x C] = a[R x K] * b[K x C]
 template <int R, int K, int C>
 __device__ __forceinline__ void mm(const float* a, const float* b, float* c) {
@@ -44,6 +63,7 @@ __device__ __forceinline__ void mv(const float* a, const float* x, float* c) {
 template <int M, int C>
 __device__ __forceinline__ void psd_solve(const float* S, float* X /* in: Bm, out: X */) {
   float a[M * M];
+  float rdiag[M];
   BF_UNROLL for (int i = 0; i < M * M; ++i) a[i] = S[i] + 1e-6f;
   BF_UNROLL for (int k = 0; k < M; ++k) {
     // pivot search: first row of maximal |a[i][k]|, i >= k (isamax semantics)
@@ -68,15 +88,16 @@ __device__ __forceinline__ void psd_solve(const float* S, float* X /* in: Bm, ou
         X[i * C + j] = sw ? u : v;
       }
     }
-    float piv = a[k * M + k];
+    const float rpiv = fast_rcp(a[k * M + k]);
+    rdiag[k] = rpiv;
     BF_UNROLL for (int i = k + 1; i < M; ++i) {
-      float l = a[i * M + k] / piv;
+      float l = a[i * M + k] * rpiv;
       BF_UNROLL for (int j = k + 1; j < M; ++j) a[i * M + j] = fmaf(-l, a[k * M + j], a[i * M + j]);
       BF_UNROLL for (int j = 0; j < C; ++j) X[i * C + j] = fmaf(-l, X[k * C + j], X[i * C + j]);
     }
   }
   BF_UNROLL for (int i = M - 1; i >= 0; --i) {
-    float inv = 1.0f / a[i * M + i];
+    const float inv = rdiag[i];
     BF_UNROLL for (int j = 0; j < C; ++j) {
       float s = X[i * C + j];
       BF_UNROLL for (int q = i + 1; q < M; ++q) s = fmaf(-a[i * M + q], X[q * C + j], s);
@@ -90,29 +111,33 @@ __device__ __forceinline__ void psd_solve(const float* S, float* X /* in: Bm, ou
 template <int M>
 __device__ __forceinline__ float mvn_logpdf_chol(const float* S, const float* v) {
   float L[M * M];
+  float rd[M];
+  float dprod = 1.0f;
   BF_UNROLL for (int j = 0; j < M; ++j) {
     float d = S[j * M + j];
     BF_UNROLL for (int k = 0; k < j; ++k) d = fmaf(-L[j * M + k], L[j * M + k], d);
-    d = sqrtf(d);
+    d = fast_sqrt(d);  // NaN for a non-PD S, as the reference's Cholesky
     L[j * M + j] = d;
-    float inv = 1.0f / d;
+    dprod *= d;
+    const float inv = fast_rcp(d);
+    rd[j] = inv;
     BF_UNROLL for (int i = j + 1; i < M; ++i) {
       float s = S[i * M + j];
       BF_UNROLL for (int k = 0; k < j; ++k) s = fmaf(-L[i * M + k], L[j * M + k], s);
       L[i * M + j] = s * inv;
     }
   }
-  float quad = 0.f, logdet = 0.f;
+  float quad = 0.f;
   float z[M];
   BF_UNROLL for (int i = 0; i < M; ++i) {
     float s = v[i];
     BF_UNROLL for (int j = 0; j < i; ++j) s = fmaf(-L[i * M + j], z[j], s);
-    z[i] = s / L[i * M + i];
+    z[i] = s * rd[i];
     quad = fmaf(z[i], z[i], quad);
-    logdet += logf(L[i * M + i]);
   }
   constexpr float kLog2Pi = 1.8378770664093453f;
-  return -0.5f * quad - 0.5f * float(M) * kLog2Pi - logdet;
+  // sum_i log L_ii = log prod_i L_ii (one v_log_f32; M <= 8 keeps the product in range)
+  return -0.5f * quad - 0.5f * float(M) * kLog2Pi - fast_log(dprod);
 }
 
 // _condition_on (gaussfiltax/inference.py:72-105) given the linearisation at the prior mean:

@@ -1,0 +1,620 @@
+// kf_scan_cols: batched Kalman filter with one covariance COLUMN per lane.
+//
+// Replaces, for linear f/h and one component, the lax.scan body of gaussian_sum_filter
+// (gaussfiltax/inference.py:333-371): per step  _condition_on (:72-105)  ->  reweight
+// (:347-350)  ->  _predict (:51-70), emitting the five posterior streams of :357-363.
+//
+// Mapping (gfx950).  NL = next_pow2(n) consecutive lanes form a group that advances ONE
+// trajectory; lane j of the group owns column j of P and entry j of m.  A wave64 therefore
+// carries 64/NL trajectories and the batch of cfg2 (65,536 chains, n = 4) is 4,096 waves =
+// 4 waves per SIMD on 256 CUs -- enough to issue a VALU instruction every 2 cycles and to hide
+// LDS / HBM latency behind other waves (the earlier one-lane-per-chain kernel ran 1 wave per
+// SIMD and was issue/latency bound at 45 % of HBM peak even with no stores at all).
+//   * column-local products (H P, A P, K S, gains) need no communication;
+//   * products that contract over the lane index use DPP quad_perm / row_mirror modifiers or
+//     ds_swizzle (lane_group.hpp): P+ = P - (K S) K^T and P- = (A P) A^T broadcast one
+//     register of lane l to the group while every lane multiplies by its own A[j][l], K[j][b];
+//   * S = (H P) H^T and h(m) = H m are group all-reduces (xor butterflies);
+//   * the tiny m x m LU solve / Cholesky are done redundantly by every lane of the group.
+// Stores (the roofline: 172 B per chain-step at n=4, m=2): EMIT_STAGED transposes time through
+// per-wave LDS tiles so that each trajectory's stream leaves the CU as 64..128-byte contiguous
+// runs written by dwordx4 stores; EMIT_SCALAR handles arbitrary strides (with the batch-inner
+// layout its dword stores are contiguous across trajectories).  Observations are fetched a
+// block of steps ahead into registers and handed to the wave through an LDS tile, so no wave
+// ever waits on a load it issued in the same step.
+#include "bf_common.hpp"
+#include "kf_math.hpp"
+#include "lane_group.hpp"
+
+namespace bf {
+
+template <int N, int M>
+struct KFConst {
+  float A[N * N];    // F_x
+  float H[M * N];    // H_x
+  float GQG[N * N];  // F_q Q F_q^T
+  float DRD[M * M];  // H_r R H_r^T
+  float Gq0[N];      // F_q q0
+  float Dr0[M];      // H_r r0
+};
+
+enum { EMIT_SCALAR = 0, EMIT_STAGED = 2 };
+
+// compile-time-unrolled select of table[idx * STRIDE + OFF] for a lane-dependent idx < CNT
+template <int CNT, int STRIDE>
+__device__ __forceinline__ float pick(const float* table, int idx, int off) {
+  float r = table[off];
+  BF_UNROLL for (int q = 1; q < CNT; ++q) r = (idx == q) ? table[q * STRIDE + off] : r;
+  return r;
+}
+
+// Order LDS traffic between the lanes of ONE wave: the hardware executes a wave's DS
+// instructions in order, so only the compiler has to be kept from moving them.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+__device__ __forceinline__ unsigned lds_byte_addr(const float* p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+}
+
+// One LDS-DMA dword per lane: LDS[lds_base + 4*lane] <- *src.  No VGPR destination, so the
+// compiler neither tracks nor waits for it (cdna_hip_programming.md 5.7): completion is
+// awaited with wait_vm<N>() below.  M0 carries the wave-uniform LDS base.
+__device__ __forceinline__ void lds_dma_dword(const float* src, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dword %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_base)
+      : "memory");
+}
+
+// s_waitcnt vmcnt(n): wait until at most n of this wave's vector-memory operations (loads,
+// stores and LDS-DMA count together, in issue order) are outstanding.  n is wave-uniform.
+__device__ __forceinline__ void wait_vm(int n) {
+#define BF_VMCASE(K_) case K_: asm volatile("s_waitcnt vmcnt(" #K_ ")" ::: "memory"); break;
+  switch (n) {
+    BF_VMCASE(1) BF_VMCASE(2) BF_VMCASE(3) BF_VMCASE(4) BF_VMCASE(5) BF_VMCASE(6) BF_VMCASE(7) BF_VMCASE(8)
+    BF_VMCASE(9) BF_VMCASE(10) BF_VMCASE(11) BF_VMCASE(12) BF_VMCASE(13) BF_VMCASE(14) BF_VMCASE(15)
+    BF_VMCASE(16) BF_VMCASE(17) BF_VMCASE(18) BF_VMCASE(19) BF_VMCASE(20) BF_VMCASE(21) BF_VMCASE(22)
+    BF_VMCASE(23) BF_VMCASE(24) BF_VMCASE(25) BF_VMCASE(26) BF_VMCASE(27) BF_VMCASE(28) BF_VMCASE(29)
+    BF_VMCASE(30) BF_VMCASE(31) BF_VMCASE(32) BF_VMCASE(33) BF_VMCASE(34) BF_VMCASE(35) BF_VMCASE(36)
+    BF_VMCASE(37) BF_VMCASE(38) BF_VMCASE(39) BF_VMCASE(40)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef BF_VMCASE
+}
+
+// ---------------------------------------------------------------------------------------
+// Per-wave LDS tile that transposes time for one output stream.
+//   rows = the CPW trajectories of the wave; a row holds W = TS*E floats (TS consecutive steps)
+//   at a pitch of W + PAD floats.  PAD = 4 keeps the per-step dword writes of the 8 groups in
+//   a half-wave on 32 different banks while rows stay 16-byte aligned for the ds_read_b128 of
+//   the flush.  A flush writes every row's W*4 contiguous bytes with dwordx4 stores.
+template <int E, int W, int CPW, int PAD>
+struct Tile {
+  static constexpr int TS = W / E;
+  static constexpr int CH = W / 4;
+  static constexpr int PITCH = W + PAD;
+  static constexpr int FLOATS = CPW * PITCH;
+  static constexpr int ITER = (CPW * CH) / 64;  // dwordx4 store instructions per flush
+  static constexpr bool OK = (W % E == 0) && (W % 4 == 0) && (PAD % 4 == 0) && ((CH & (CH - 1)) == 0) &&
+                             (CPW * CH >= 64) && ((CPW * CH) % 64 == 0);
+
+  // lane-dependent byte offset of this lane's first chunk relative to the wave's base (the host
+  // guarantees that 16 rows of a stream span less than 4 GiB, so 32 bits are enough and the
+  // stores can use the SGPR-base + VGPR-offset form)
+  static __device__ __forceinline__ unsigned lane_off(int lane, long long sB) {
+    return (unsigned)((lane / CH) * sB * 4 + (lane % CH) * 16);
+  }
+
+  // read this lane's ITER chunks of the tile into registers
+  static __device__ __forceinline__ void read(const float* tile, int lane, float4* v) {
+    constexpr int RPI = 64 / CH;
+    const int c = lane % CH;
+    const int r0 = lane / CH;
+    BF_UNROLL for (int i = 0; i < ITER; ++i)
+        v[i] = *reinterpret_cast<const float4*>(tile + (r0 + i * RPI) * PITCH + c * 4);
+  }
+
+  // dst_wave (wave-uniform): address of element (first trajectory of the wave, first step of the
+  // row, e = 0).  Only chunks below chunk_limit are written (CH for a complete row).
+  static __device__ __forceinline__ void write(const float4* v, int lane, char* dst_wave, unsigned lane_byte_off,
+                                               long long sB, int chunk_limit) {
+    constexpr int RPI = 64 / CH;
+    BF_UNROLL for (int i = 0; i < ITER; ++i) {
+      char* base_i = dst_wave + (size_t)i * (size_t)RPI * (size_t)sB * 4;  // uniform
+      if (chunk_limit >= CH || (lane % CH) < chunk_limit) *reinterpret_cast<float4*>(base_i + lane_byte_off) = v[i];
+    }
+  }
+};
+
+template <int NS, int M>
+struct ColsCfg {
+  static constexpr int NL = next_pow2(NS);
+  static constexpr int CPW = 64 / NL;
+  static constexpr int EP = NS * NS;
+  // floats per staged row: 128-byte rows for the matrix streams, 64-byte rows for the rest
+  // (and never fewer than 64 float4 chunks per wave tile, so a flush is whole store instructions)
+  static constexpr int WMIN = 4 * NL;
+  static constexpr int WP = (EP >= 32 ? EP : 32) > WMIN ? (EP >= 32 ? EP : 32) : WMIN;
+  static constexpr int WM = (NS >= 16 ? NS : 16) > WMIN ? (NS >= 16 ? NS : 16) : WMIN;
+  static constexpr int WW = 16 > WMIN ? 16 : WMIN;
+  using TP = Tile<EP, WP, CPW, 4>;
+  using TM = Tile<NS, WM, CPW, 4>;
+  using TW = Tile<1, WW, CPW, 0>;
+  static constexpr int TSMAX = (TW::TS > TM::TS ? (TW::TS > TP::TS ? TW::TS : TP::TS) : (TM::TS > TP::TS ? TM::TS : TP::TS));
+  // observation blocks: YS steps (>= 8 floats per trajectory) fetched by LDS-DMA one block ahead
+  static constexpr int YS = (M >= 8) ? 1 : 8 / M;
+  static constexpr int YW = YS * M;                  // floats per trajectory per block
+  static constexpr int YTILE = CPW * YW;             // floats per block tile (DMA writes it in lane order)
+  static constexpr int YDMA = (YTILE + 63) / 64;     // LDS-DMA instructions per block
+  static constexpr int YBUF = YDMA * 64;             // floats reserved per buffer
+  static constexpr bool STAGED_OK = (NS == NL) && TP::OK && TM::OK && TW::OK;
+};
+
+template <int NS, int M, int MODE, bool TV>
+__global__ void __launch_bounds__(256, 4)
+kf_scan_cols_kernel(KFConst<NS, M> c, const float* __restrict__ gqg_t, const float* __restrict__ drd_t, CView y,
+                    CarryView carry, OutViews out, long long B, long long T, int lds_per_wave, int vm_younger) {
+  using Cfg = ColsCfg<NS, M>;
+  constexpr int NL = Cfg::NL, CPW = Cfg::CPW, EP = Cfg::EP, YS = Cfg::YS;
+  using TP = typename Cfg::TP;
+  using TM = typename Cfg::TM;
+  using TW = typename Cfg::TW;
+
+  const int lane = threadIdx.x & 63;
+  const int wave_in_blk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long gwave = (long long)blockIdx.x * 4 + wave_in_blk;
+  const long long b0w = gwave * CPW;  // first trajectory of this wave
+  if (b0w >= B) return;               // whole wave out of range (uniform)
+  const int g = lane / NL;
+  const int j = lane % NL;
+  const bool col_ok = j < NS;
+  const int jc = col_ok ? j : NS - 1;
+  const long long b_raw = b0w + g;
+  const bool chain_ok = (MODE == EMIT_STAGED) ? true : (b_raw < B);  // staged launches hold full waves only
+  const long long b = chain_ok ? b_raw : B - 1;
+
+  // ---- per-lane constants: row j of A, column j of H and of G Q G^T
+  float Arow[NS], Hcol[M], Gcol[NS], gq0j;
+  BF_UNROLL for (int l = 0; l < NS; ++l) Arow[l] = col_ok ? pick<NS, NS>(c.A, jc, l) : 0.f;
+  BF_UNROLL for (int a = 0; a < M; ++a) Hcol[a] = col_ok ? pick<NS, 1>(c.H, jc, a * NS) : 0.f;
+  BF_UNROLL for (int i = 0; i < NS; ++i) Gcol[i] = col_ok ? pick<NS, 1>(c.GQG, jc, i * NS) : 0.f;
+  gq0j = col_ok ? pick<NS, 1>(c.Gq0, jc, 0) : 0.f;
+
+  // ---- state
+  float Pc[NS], mj, w;
+  BF_UNROLL for (int i = 0; i < NS; ++i) Pc[i] = col_ok ? carry.P_in[b * EP + i * NS + jc] : 0.f;
+  mj = col_ok ? carry.m_in[b * NS + jc] : 0.f;
+  w = carry.w_in ? carry.w_in[b] : 1.0f;
+
+  // ---- LDS carve (dynamic; only enabled streams take space).  Tiles are addressed as
+  // lds + integer offset so that every access stays a DS instruction.
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int q = wave_in_blk * lds_per_wave;
+  const int oY = q;
+  q += 2 * Cfg::YBUF;
+  int oP = 0, opP = 0, oM = 0, opM = 0, oW = 0, oL = 0;
+  if constexpr (MODE == EMIT_STAGED) {
+    // a disabled stream aliases the observation tile (always large enough to be read from)
+    oP = out.P.p ? q : oY;   q += out.P.p ? TP::FLOATS : 0;
+    opP = out.pP.p ? q : oY; q += out.pP.p ? TP::FLOATS : 0;
+    oM = out.m.p ? q : oY;   q += out.m.p ? TM::FLOATS : 0;
+    opM = out.pm.p ? q : oY; q += out.pm.p ? TM::FLOATS : 0;
+    oW = out.w.p ? q : oY;   q += out.w.p ? TW::FLOATS : 0;
+    oL = out.ll.p ? q : oY;
+  }
+  const unsigned offP = TP::lane_off(lane, T * EP);
+  const unsigned offM = TM::lane_off(lane, T * NS);
+  const unsigned offW = TW::lane_off(lane, T);
+  // per-lane LDS positions for the per-step writes
+  const int putP = g * TP::PITCH + j;
+  const int putM = g * TM::PITCH + j;
+  const int putW = g * TW::PITCH;
+
+  // ---- observation stream: LDS-DMA, block k+1 lands while block k is consumed
+  const float* ysrc[Cfg::YDMA];
+  BF_UNROLL for (int i = 0; i < Cfg::YDMA; ++i) {
+    const int e = lane + 64 * i;
+    const int ch = (e / Cfg::YW) < CPW ? (e / Cfg::YW) : CPW - 1, f = e % Cfg::YW;
+    const long long bb = (b0w + ch < B) ? b0w + ch : B - 1;
+    // address of (trajectory, step f / M of block 0, entry f % M); advanced by YS*sT per block
+    ysrc[i] = y.p + bb * y.sB + (long long)(f / M) * y.sT + (long long)(f % M) * y.sE;
+  }
+  const unsigned ybase = lds_byte_addr(lds + oY);
+  auto y_fetch = [&](long long tb, int buf) {
+    BF_UNROLL for (int i = 0; i < Cfg::YDMA; ++i) {
+      const int e = lane + 64 * i;
+      const int f = e % Cfg::YW;
+      // steps past the end re-read the last valid step (value unused)
+      long long tt = tb + f / M;
+      tt = tt < T ? tt : T - 1;
+      const float* src = ysrc[i] + (tt - f / M) * y.sT;
+      if (Cfg::YTILE % 64 == 0 || e < Cfg::YTILE)
+        lds_dma_dword(src, ybase + (unsigned)(buf * Cfg::YBUF + 64 * i) * 4u);
+    }
+  };
+
+  // one filter step; STAGED selects the emit path at compile time
+  auto step = [&](long long t, auto staged_tag) {
+    constexpr bool STAGED = decltype(staged_tag)::value;
+    const int ys = (int)(t % YS);
+    const int ybuf = (int)((t / YS) & 1);
+    float yv[M];
+    BF_UNROLL for (int a = 0; a < M; ++a) yv[a] = lds[oY + ybuf * Cfg::YBUF + g * Cfg::YW + ys * M + a];
+
+    const float* GQGc = Gcol;
+    const float* DRD = c.DRD;
+    float gq[NS], dr[M * M];
+    if constexpr (TV) {
+      if (gqg_t) {
+        BF_UNROLL for (int i = 0; i < NS; ++i) gq[i] = col_ok ? gqg_t[t * EP + i * NS + jc] : 0.f;
+        GQGc = gq;
+      }
+      if (drd_t) {
+        BF_UNROLL for (int i = 0; i < M * M; ++i) dr[i] = drd_t[t * M * M + i];
+        DRD = dr;
+      }
+    }
+
+    // ================= _condition_on (inference.py:72-105) =================
+    // innovation v = y - (H m + H_r r0): group all-reduce over the state index
+    float v[M];
+    BF_UNROLL for (int a = 0; a < M; ++a) v[a] = yv[a] - (group_sum<NL>(Hcol[a] * mj) + c.Dr0[a]);
+    // column j of H_x P
+    float HPc[M];
+    BF_UNROLL for (int a = 0; a < M; ++a) {
+      float s = c.H[a * NS] * Pc[0];
+      BF_UNROLL for (int i = 1; i < NS; ++i) s = fmaf(c.H[a * NS + i], Pc[i], s);
+      HPc[a] = s;
+    }
+    // S = H_r R H_r^T + (H_x P) H_x^T
+    float S[M * M];
+    BF_UNROLL for (int a = 0; a < M; ++a) BF_UNROLL for (int bb = 0; bb < M; ++bb)
+        S[a * M + bb] = DRD[a * M + bb] + group_sum<NL>(HPc[a] * Hcol[bb]);
+    // K[j][:] = column j of solve(S + 1e-6, H_x P)
+    float X[M];
+    BF_UNROLL for (int a = 0; a < M; ++a) X[a] = HPc[a];
+    psd_solve<M, 1>(S, X);
+    // (K S)[j][:]
+    float KS[M];
+    BF_UNROLL for (int bb = 0; bb < M; ++bb) {
+      float s = X[0] * S[bb];
+      BF_UNROLL for (int a = 1; a < M; ++a) s = fmaf(X[a], S[a * M + bb], s);
+      KS[bb] = s;
+    }
+    // P+[i][j] = P[i][j] - sum_b (K S)[i][b] K[j][b]   ((K S)[i][:] lives in lane i)
+    static_for<0, NS>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      float s = group_bcast<NL, i>(KS[0]) * X[0];
+      BF_UNROLL for (int bb = 1; bb < M; ++bb) s = fmaf(group_bcast<NL, i>(KS[bb]), X[bb], s);
+      Pc[i] -= s;
+    });
+    // m+[j] = m[j] + K[j][:] . v
+    {
+      float s = X[0] * v[0];
+      BF_UNROLL for (int a = 1; a < M; ++a) s = fmaf(X[a], v[a], s);
+      mj += s;
+    }
+    const float ll = mvn_logpdf_chol<M>(S, v);
+
+    // ================= reweight, K = 1 (inference.py:347-350) =================
+    w = reweight_single(ll, w);
+
+    if constexpr (STAGED) {
+      if (out.m.p) lds[oM + putM + int(t % TM::TS) * NS] = mj;
+      if (out.P.p) {
+        const int o = oP + putP + int(t % TP::TS) * EP;
+        BF_UNROLL for (int i = 0; i < NS; ++i) lds[o + i * NS] = Pc[i];
+      }
+      if (j == 0) {
+        if (out.w.p) lds[oW + putW + int(t % TW::TS)] = w;
+        if (out.ll.p) lds[oL + putW + int(t % TW::TS)] = ll;
+      }
+    } else if (chain_ok && col_ok) {
+      if (out.m.p) out.m.p[b * out.m.sB + t * out.m.sT + j * out.m.sE] = mj;
+      if (out.P.p) BF_UNROLL for (int i = 0; i < NS; ++i)
+          out.P.p[b * out.P.sB + t * out.P.sT + (i * NS + j) * out.P.sE] = Pc[i];
+      if (j == 0) {
+        if (out.w.p) out.w.p[b * out.w.sB + t * out.w.sT] = w;
+        if (out.ll.p) out.ll.p[b * out.ll.sB + t * out.ll.sT] = ll;
+      }
+    }
+
+    // ================= _predict (inference.py:51-70) =================
+    // column j of F_x P+
+    float APc[NS];
+    BF_UNROLL for (int i = 0; i < NS; ++i) {
+      float s = c.A[i * NS] * Pc[0];
+      BF_UNROLL for (int k = 1; k < NS; ++k) s = fmaf(c.A[i * NS + k], Pc[k], s);
+      APc[i] = s;
+    }
+    // P-[i][j] = sum_l (F_x P+)[i][l] F_x[j][l] + (F_q Q F_q^T)[i][j]
+    BF_UNROLL for (int i = 0; i < NS; ++i) {
+      float s = 0.f;
+      static_for<0, NS>([&](auto L) {
+        constexpr int l = decltype(L)::value;
+        const float ap_l = group_bcast<NL, l>(APc[i]);
+        s = (l == 0) ? ap_l * Arow[0] : fmaf(ap_l, Arow[l], s);
+      });
+      Pc[i] = s + GQGc[i];
+    }
+    // m-[j] = sum_k F_x[j][k] m+[k] + (F_q q0)[j]
+    float mnew = 0.f;
+    static_for<0, NS>([&](auto Kk) {
+      constexpr int k = decltype(Kk)::value;
+      const float mk = group_bcast<NL, k>(mj);
+      mnew = (k == 0) ? Arow[0] * mk : fmaf(Arow[k], mk, mnew);
+    });
+    mj = mnew + gq0j;
+
+    if constexpr (STAGED) {
+      if (out.pm.p) lds[opM + putM + int(t % TM::TS) * NS] = mj;
+      if (out.pP.p) {
+        const int o = opP + putP + int(t % TP::TS) * EP;
+        BF_UNROLL for (int i = 0; i < NS; ++i) lds[o + i * NS] = Pc[i];
+      }
+    } else if (chain_ok && col_ok) {
+      if (out.pm.p) out.pm.p[b * out.pm.sB + t * out.pm.sT + j * out.pm.sE] = mj;
+      if (out.pP.p) BF_UNROLL for (int i = 0; i < NS; ++i)
+          out.pP.p[b * out.pP.sB + t * out.pP.sT + (i * NS + j) * out.pP.sE] = Pc[i];
+    }
+  };
+
+  // flush the tiles whose rows completed at step t (t1 = t + 1): all LDS reads of an event are
+  // issued before the first store so that one LDS round trip covers the whole event.  `last`
+  // (after the final step) also flushes the incomplete rows, chunk-limited.
+  auto flush_all = [&](long long t1, bool last) {
+    if constexpr (MODE == EMIT_STAGED) {
+      const int remP = (int)(t1 % TP::TS), remM = (int)(t1 % TM::TS), remW = (int)(t1 % TW::TS);
+      // (both tiles of a pair are read unconditionally -- a disabled stream's offset aliases a
+      // valid tile -- so the staging registers never become a conditionally-initialised array)
+      if (remP == 0 || last) {
+        wave_lds_sync();
+        const long long t0 = remP == 0 ? t1 - TP::TS : t1 - remP;
+        const int lim = remP == 0 ? TP::CH : (remP * EP) / 4;
+        float4 va[TP::ITER], vb[TP::ITER];
+        TP::read(lds + oP, lane, va);
+        TP::read(lds + opP, lane, vb);
+        if (out.P.p) TP::write(va, lane, reinterpret_cast<char*>(out.P.p + b0w * out.P.sB + t0 * EP), offP, out.P.sB, lim);
+        if (out.pP.p) TP::write(vb, lane, reinterpret_cast<char*>(out.pP.p + b0w * out.pP.sB + t0 * EP), offP, out.pP.sB, lim);
+      }
+      if (remM == 0 || last) {
+        wave_lds_sync();
+        const long long t0 = remM == 0 ? t1 - TM::TS : t1 - remM;
+        const int lim = remM == 0 ? TM::CH : (remM * NS) / 4;
+        float4 va[TM::ITER], vb[TM::ITER];
+        TM::read(lds + oM, lane, va);
+        TM::read(lds + opM, lane, vb);
+        if (out.m.p) TM::write(va, lane, reinterpret_cast<char*>(out.m.p + b0w * out.m.sB + t0 * NS), offM, out.m.sB, lim);
+        if (out.pm.p) TM::write(vb, lane, reinterpret_cast<char*>(out.pm.p + b0w * out.pm.sB + t0 * NS), offM, out.pm.sB, lim);
+      }
+      if (remW == 0 || last) {
+        wave_lds_sync();
+        const long long t0 = remW == 0 ? t1 - TW::TS : t1 - remW;
+        const int lim = remW == 0 ? TW::CH : remW / 4;
+        float4 va[TW::ITER], vb[TW::ITER];
+        TW::read(lds + oW, lane, va);
+        TW::read(lds + oL, lane, vb);
+        if (out.w.p) TW::write(va, lane, reinterpret_cast<char*>(out.w.p + b0w * out.w.sB + t0), offW, out.w.sB, lim);
+        if (out.ll.p) TW::write(vb, lane, reinterpret_cast<char*>(out.ll.p + b0w * out.ll.sB + t0), offW, out.ll.sB, lim);
+      }
+      wave_lds_sync();
+    }
+  };
+
+  // ---- time loop.  Block structure: at the top of block k the DMA of block k (issued one
+  // block earlier) is awaited with a counted vmcnt that leaves this wave's newer stores in
+  // flight, then the DMA of block k+1 is issued.
+  y_fetch(0, 0);
+  for (long long tb = 0; tb < T; tb += YS) {
+    // outstanding, youngest first: [stores of the previous block (>= vm_younger of them)] [DMA of this block]
+    wait_vm(tb == 0 ? 0 : vm_younger);
+    if (tb + YS < T) y_fetch(tb + YS, (int)(((tb / YS) + 1) & 1));
+    wave_lds_sync();
+    const long long te = (tb + YS < T) ? tb + YS : T;
+    for (long long t = tb; t < te; ++t) {
+      step(t, std::integral_constant<bool, MODE == EMIT_STAGED>{});
+      if (t + 1 < T) flush_all(t + 1, false);
+    }
+  }
+  flush_all(T, true);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  if (chain_ok && col_ok) {
+    if (carry.m_out) carry.m_out[b * NS + j] = mj;
+    if (carry.P_out) BF_UNROLL for (int i = 0; i < NS; ++i) carry.P_out[b * EP + i * NS + j] = Pc[i];
+    if (carry.w_out && j == 0) carry.w_out[b] = w;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+template <int N, int M>
+static void fill_const(const bf_lgssm* p, KFConst<N, M>& c, const float* Qt, const float* Rt) {
+  const int dq = p->dq, dr = p->dr;
+  auto Gat = [&](int i, int k) { return p->G ? p->G[i * dq + k] : (i == k ? 1.f : 0.f); };
+  auto Dat = [&](int i, int k) { return p->D ? p->D[i * dr + k] : (i == k ? 1.f : 0.f); };
+  for (int i = 0; i < N * N; ++i) c.A[i] = p->A[i];
+  for (int i = 0; i < M * N; ++i) c.H[i] = p->H[i];
+  // (G @ Q) @ G^T and (D @ R) @ D^T in fp32, association as written in inference.py:69,:100
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) {
+      float s = 0.f;
+      for (int l = 0; l < dq; ++l) {
+        float gq = 0.f;
+        for (int k = 0; k < dq; ++k) gq = fmaf(Gat(i, k), Qt[k * dq + l], gq);
+        s = fmaf(gq, Gat(j, l), s);
+      }
+      c.GQG[i * N + j] = s;
+    }
+  for (int i = 0; i < M; ++i)
+    for (int j = 0; j < M; ++j) {
+      float s = 0.f;
+      for (int l = 0; l < dr; ++l) {
+        float dq_ = 0.f;
+        for (int k = 0; k < dr; ++k) dq_ = fmaf(Dat(i, k), Rt[k * dr + l], dq_);
+        s = fmaf(dq_, Dat(j, l), s);
+      }
+      c.DRD[i * M + j] = s;
+    }
+  for (int i = 0; i < N; ++i) {
+    float s = 0.f;
+    for (int k = 0; k < dq; ++k) s = fmaf(Gat(i, k), p->q0 ? p->q0[k] : 0.f, s);
+    c.Gq0[i] = s;
+  }
+  for (int i = 0; i < M; ++i) {
+    float s = 0.f;
+    for (int k = 0; k < dr; ++k) s = fmaf(Dat(i, k), p->r0 ? p->r0[k] : 0.f, s);
+    c.Dr0[i] = s;
+  }
+}
+
+static bool stream_is_reference(const bf_stream& s, long long E, long long T) {
+  return s.ptr == nullptr ||
+         (s.sE == 1 && s.sT == E && s.sB == T * E && (reinterpret_cast<uintptr_t>(s.ptr) % 16 == 0));
+}
+
+template <int N, int M>
+static int launch_nm(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
+                     const bf_out_desc* out, hipStream_t stream, int force_mode) {
+  using Cfg = ColsCfg<N, M>;
+  KFConst<N, M> c;
+  fill_const<N, M>(p, c, p->Q, p->R);
+  CView yv{y->ptr, y->sB, y->sT, y->sE};
+  CarryView cv{carry->w_in, carry->m_in, carry->P_in, carry->w_out, carry->m_out, carry->P_out};
+  OutViews ov{make_sview(out->weights), make_sview(out->means), make_sview(out->covs),
+              make_sview(out->pred_means), make_sview(out->pred_covs), make_sview(out->loglik)};
+
+  const bool ref_layout = stream_is_reference(out->weights, 1, T) && stream_is_reference(out->loglik, 1, T) &&
+                          stream_is_reference(out->means, N, T) && stream_is_reference(out->pred_means, N, T) &&
+                          stream_is_reference(out->covs, N * N, T) && stream_is_reference(out->pred_covs, N * N, T);
+  // float4 stores need every enabled stream's rows (T*E floats apart) to stay 16-byte aligned
+  auto row_ok = [&](const bf_stream& st, long long E) { return st.ptr == nullptr || (T * E) % 4 == 0; };
+  const bool rows_aligned = row_ok(out->weights, 1) && row_ok(out->loglik, 1) && row_ok(out->means, N) &&
+                            row_ok(out->pred_means, N) && row_ok(out->covs, N * N) && row_ok(out->pred_covs, N * N);
+  // the flush addresses rows through 32-bit byte offsets from a wave-uniform base
+  const bool off32_ok = (double)T * N * N * 4.0 * 17.0 < 4.0e9;
+  const bool staged_ok = Cfg::STAGED_OK && ref_layout && rows_aligned && off32_ok;
+  int mode = staged_ok ? EMIT_STAGED : EMIT_SCALAR;
+  if (force_mode == EMIT_SCALAR || force_mode == 1) mode = EMIT_SCALAR;
+  if (force_mode == EMIT_STAGED && !staged_ok)
+    return set_error(BF_EINVAL, "staged emitter needs the contiguous reference layout, 16-byte aligned rows and n in {1,2,4,8}");
+
+  // time-varying covariances: per-step G Q_t G^T / D R_t D^T tables on the device
+  float* d_gqg = nullptr;
+  float* d_drd = nullptr;
+  const bool tv = (p->Q_steps > 1) || (p->R_steps > 1);
+  if (tv) {
+    if ((p->Q_steps > 1 && p->Q_steps != T) || (p->R_steps > 1 && p->R_steps != T))
+      return set_error(BF_EINVAL, "time-varying Q/R need exactly T=%lld matrices", T);
+    if (p->Q_steps > 1) {
+      float* h = new float[T * N * N];
+      for (long long t = 0; t < T; ++t) {
+        KFConst<N, M> ct;
+        fill_const<N, M>(p, ct, p->Q + t * p->dq * p->dq, p->R);
+        for (int i = 0; i < N * N; ++i) h[t * N * N + i] = ct.GQG[i];
+      }
+      hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&d_gqg), sizeof(float) * T * N * N, stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(d_gqg, h, sizeof(float) * T * N * N, hipMemcpyHostToDevice, stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);
+      delete[] h;
+      BF_HIP_CHECK(e);
+    }
+    if (p->R_steps > 1) {
+      float* h = new float[T * M * M];
+      for (long long t = 0; t < T; ++t) {
+        KFConst<N, M> ct;
+        fill_const<N, M>(p, ct, p->Q, p->R + t * p->dr * p->dr);
+        for (int i = 0; i < M * M; ++i) h[t * M * M + i] = ct.DRD[i];
+      }
+      hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&d_drd), sizeof(float) * T * M * M, stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(d_drd, h, sizeof(float) * T * M * M, hipMemcpyHostToDevice, stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);
+      delete[] h;
+      BF_HIP_CHECK(e);
+    }
+  }
+
+  // One launch over trajectories [b_begin, b_begin + b_count) with the given emit mode.
+  auto launch = [&](int mode_, long long b_begin, long long b_count) {
+    using Cfg = ColsCfg<N, M>;
+    const int nP = (out->covs.ptr ? 1 : 0) + (out->pred_covs.ptr ? 1 : 0);
+    const int nM = (out->means.ptr ? 1 : 0) + (out->pred_means.ptr ? 1 : 0);
+    const int nW = (out->weights.ptr ? 1 : 0) + (out->loglik.ptr ? 1 : 0);
+    int lds_per_wave = 2 * Cfg::YBUF;
+    // VMEM operations a wave issues per observation block besides the DMA itself: the lower
+    // bound the counted vmcnt of the kernel relies on
+    int vm_younger;
+    if (mode_ == EMIT_STAGED) {
+      lds_per_wave += nP * Cfg::TP::FLOATS + nM * Cfg::TM::FLOATS + nW * Cfg::TW::FLOATS;
+      vm_younger = (Cfg::YS / Cfg::TP::TS) * nP * Cfg::TP::ITER + (Cfg::YS / Cfg::TM::TS) * nM * Cfg::TM::ITER +
+                   (Cfg::YS / Cfg::TW::TS) * nW * Cfg::TW::ITER;
+    } else {
+      vm_younger = Cfg::YS * (nM + nP * N + nW);
+    }
+    if (vm_younger > 40) vm_younger = 40;
+    const size_t lds_bytes = sizeof(float) * (size_t)lds_per_wave * 4;
+    auto shift = [&](SView v) { if (v.p) v.p += b_begin * v.sB; return v; };
+    CView yv2{yv.p + b_begin * yv.sB, yv.sB, yv.sT, yv.sE};
+    CarryView cv2{cv.w_in ? cv.w_in + b_begin : nullptr, cv.m_in + b_begin * N, cv.P_in + b_begin * N * N,
+                  cv.w_out ? cv.w_out + b_begin : nullptr, cv.m_out ? cv.m_out + b_begin * N : nullptr,
+                  cv.P_out ? cv.P_out + b_begin * N * N : nullptr};
+    OutViews ov2{shift(ov.w), shift(ov.m), shift(ov.P), shift(ov.pm), shift(ov.pP), shift(ov.ll)};
+    const long long waves = (b_count + Cfg::CPW - 1) / Cfg::CPW;
+    dim3 block(256);
+    dim3 grid((unsigned)((waves + 3) / 4));
+#define BF_LAUNCH(MODE_, TV_)                                                                                  \
+  hipLaunchKernelGGL((kf_scan_cols_kernel<N, M, MODE_, TV_>), grid, block, lds_bytes, stream, c, d_gqg, d_drd, \
+                     yv2, cv2, ov2, b_count, T, lds_per_wave, vm_younger)
+    if (tv) {
+      if (mode_ == EMIT_SCALAR) BF_LAUNCH(EMIT_SCALAR, true);
+      else if constexpr (Cfg::STAGED_OK) BF_LAUNCH(EMIT_STAGED, true);
+    } else {
+      if (mode_ == EMIT_SCALAR) BF_LAUNCH(EMIT_SCALAR, false);
+      else if constexpr (Cfg::STAGED_OK) BF_LAUNCH(EMIT_STAGED, false);
+    }
+#undef BF_LAUNCH
+  };
+  if (mode == EMIT_STAGED) {
+    // the staged kernel takes whole waves only; a ragged remainder goes through the strided kernel
+    const long long b_main = (B / Cfg::CPW) * Cfg::CPW;
+    if (b_main > 0) launch(EMIT_STAGED, 0, b_main);
+    if (b_main < B) launch(EMIT_SCALAR, b_main, B - b_main);
+  } else {
+    launch(EMIT_SCALAR, 0, B);
+  }
+  BF_HIP_CHECK(hipGetLastError());
+  if (d_gqg) BF_HIP_CHECK(hipFreeAsync(d_gqg, stream));
+  if (d_drd) BF_HIP_CHECK(hipFreeAsync(d_drd, stream));
+  return BF_OK;
+}
+
+// (n, m) pairs compiled into the column-per-lane kernel
+int launch_kf_cols(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
+                   const bf_out_desc* out, hipStream_t stream, int force_mode) {
+#define BF_CASE(N_, M_) \
+  if (p->n == N_ && p->m == M_) return launch_nm<N_, M_>(p, y, B, T, carry, out, stream, force_mode)
+  BF_CASE(1, 1);
+  BF_CASE(2, 1);
+  BF_CASE(2, 2);
+  BF_CASE(3, 1);
+  BF_CASE(3, 3);
+  BF_CASE(4, 1);
+  BF_CASE(4, 2);
+  BF_CASE(4, 4);
+  BF_CASE(6, 3);
+  BF_CASE(8, 4);
+#undef BF_CASE
+  return set_error(BF_EUNSUPPORTED, "kalman filter: (n=%d, m=%d) is not compiled into the column-per-lane kernel",
+                   p->n, p->m);
+}
+
+}  // namespace bf

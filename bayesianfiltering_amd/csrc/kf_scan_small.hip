@@ -185,9 +185,7 @@ kf_scan_small_kernel(KFConst<N, M> c, const float* __restrict__ gqg_t, const flo
     float ll = condition_on<N, M>(c.H, DRD, v, m, P);
 
     // ---- reweight (K = 1): lls -= max; w = exp(lls) * w; w /= sum(w)
-    float l0 = ll - ll;
-    float wn = expf(l0) * w;
-    w = wn / wn;
+    w = reweight_single(ll, w);
 
     if constexpr (MODE == EMIT_SCALAR) {
       if (active) {

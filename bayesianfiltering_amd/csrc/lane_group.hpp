@@ -1,0 +1,77 @@
+// Cross-lane primitives for "lane groups": NL = 1,2,4,...,64 consecutive lanes of a wave64
+// cooperate on one filter chain (lane j of the group owns column j of the covariance).
+// Everything here is register-to-register on gfx950: DPP modifiers inside quads and rows of
+// 16, ds_swizzle (LDS crossbar, no memory) up to 32 lanes, v_readlane / ds_bpermute for 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <type_traits>
+
+namespace bf {
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(float, r);
+}
+
+template <int PATTERN>
+__device__ __forceinline__ float swizzle(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), PATTERN));
+}
+
+// value of lane K of the caller's NL-lane group
+template <int NL, int K>
+__device__ __forceinline__ float group_bcast(float v) {
+  static_assert(K >= 0 && K < NL, "lane index out of group");
+  if constexpr (NL == 1) {
+    return v;
+  } else if constexpr (NL == 2) {
+    return dpp_mov<(K) | (K << 2) | ((2 + K) << 4) | ((2 + K) << 6)>(v);
+  } else if constexpr (NL == 4) {
+    return dpp_mov<K * 0x55>(v);
+  } else if constexpr (NL == 8) {
+    return swizzle<0x18 | (K << 5)>(v);  // bitmode: and 0b11000, or K
+  } else if constexpr (NL == 16) {
+    return swizzle<0x10 | (K << 5)>(v);
+  } else if constexpr (NL == 32) {
+    return swizzle<0x00 | (K << 5)>(v);
+  } else {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), K));
+  }
+}
+
+// sum over the NL lanes of the group, result in every lane (xor butterfly: 1, 2, 4, ...)
+template <int NL>
+__device__ __forceinline__ float group_sum(float v) {
+  if constexpr (NL >= 2) v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  if constexpr (NL >= 4) v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  if constexpr (NL >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror: i <-> 7-i
+  if constexpr (NL >= 16) v += dpp_mov<0x140>(v);  // row_mirror: i <-> 15-i
+  if constexpr (NL >= 32) v += swizzle<0x401F>(v);  // xor 16 within 32
+  if constexpr (NL >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+template <int NL>
+__device__ __forceinline__ float group_max(float v) {
+  if constexpr (NL >= 2) v = fmaxf(v, dpp_mov<0xB1>(v));
+  if constexpr (NL >= 4) v = fmaxf(v, dpp_mov<0x4E>(v));
+  if constexpr (NL >= 8) v = fmaxf(v, dpp_mov<0x141>(v));
+  if constexpr (NL >= 16) v = fmaxf(v, dpp_mov<0x140>(v));
+  if constexpr (NL >= 32) v = fmaxf(v, swizzle<0x401F>(v));
+  if constexpr (NL >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, END)
+template <int I, int END, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < END) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, END>(f);
+  }
+}
+
+constexpr int next_pow2(int n) { return n <= 1 ? 1 : 2 * next_pow2((n + 1) / 2); }
+
+}  // namespace bf

@@ -1,0 +1,18 @@
+#!/bin/bash
+# usage: scripts/pmc.sh <tag> ; env PK PF etc. forwarded.  Collects SQ counters for the scan kernel.
+tag=$1
+cd /tmp && export TMPDIR=/tmp
+out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
+mkdir -p $out
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --output-format csv -d $out/p1 -- python3 $GRAFT_REPO_ROOT/scripts/kf_one.py > $out/p1.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT --output-format csv -d $out/p2 -- python3 $GRAFT_REPO_ROOT/scripts/kf_one.py > $out/p2.log 2>&1
+python3 - <<PY
+import csv,glob,collections
+for p in ("p1","p2"):
+    for f in glob.glob("$out/%s/**/*counter_collection.csv"%p, recursive=True):
+        acc=collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "kf_scan" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k,v in acc.items(): print("$tag",k, sum(v)/len(v), "n=%d"%len(v))
+PY

@@ -11,25 +11,30 @@ TOL = 1e-5
 FIELDS = ("weights", "means", "covariances", "predicted_means", "predicted_covariances")
 
 
-def _run(a, ys, init, layout, mode=-1, **kw):
+def _run(a, ys, init, layout, mode=-1, kernel=0, **kw):
     import bayesianfiltering_amd as bfa
     from bayesianfiltering_amd import _lib
     lib = _lib.require_gpu()
     _lib.check(lib.bf_set_option(b"kf_emit_mode", mode))
+    _lib.check(lib.bf_set_option(b"kf_kernel", kernel))
     try:
         return bfa.kalman_filter(cm.product_params(a), ys, initial_means=init, layout=layout, **kw)
     finally:
         lib.bf_set_option(b"kf_emit_mode", -1)
+        lib.bf_set_option(b"kf_kernel", 0)
 
 
-@pytest.mark.parametrize("layout,mode", [("reference", 2), ("reference", 1), ("reference", 0), ("batch_inner", -1)])
-def test_cv_model_matches_oracle(layout, mode):
+# kernel 0 = column-per-lane (shipping default), kernel 1 = lane-per-chain baseline
+@pytest.mark.parametrize("kernel,layout,mode", [(0, "reference", 2), (0, "reference", 0), (0, "batch_inner", -1),
+                                                (1, "reference", 2), (1, "reference", 1), (1, "batch_inner", -1)])
+def test_cv_model_matches_oracle(kernel, layout, mode):
     a = cm.cv_model_arrays()
-    B, T = 130, 64          # ragged last wave (130 = 2*64 + 2)
+    # ragged last wave (130 = 2*64 + 2); T not a multiple of the staging depth for the shipping kernel
+    B, T = 130, (72 if kernel == 0 else 64)
     ys = cm.simulate_batch(a, B, T, seed=1)
     init = np.tile(a["m0"], (B, 1)) + np.random.default_rng(2).normal(size=(B, 4)).astype(np.float32)
     ref = cm.oracle_kalman_batch(a, ys, init)
-    post, ll = _run(a, ys, init, layout, mode, return_loglik=True)
+    post, ll = _run(a, ys, init, layout, mode, kernel, return_loglik=True)
     for k in FIELDS:
         got = getattr(post, k).cpu().numpy()
         assert got.shape == ref[k].shape
@@ -38,7 +43,7 @@ def test_cv_model_matches_oracle(layout, mode):
 
 
 @pytest.mark.parametrize("n,m,dq,dr", [(1, 1, 1, 1), (2, 1, 2, 1), (2, 2, 1, 2), (3, 1, 3, 1), (3, 3, 3, 3),
-                                       (4, 1, 2, 1), (4, 2, 4, 2), (4, 4, 3, 4), (8, 4, 8, 4)])
+                                       (4, 1, 2, 1), (4, 2, 4, 2), (4, 4, 3, 4), (6, 3, 6, 3), (8, 4, 8, 4)])
 def test_random_lgssm_dims(n, m, dq, dr):
     a = cm.random_stable_lgssm(n, m, seed=10 * n + m, dq=dq, dr=dr, bias=True)
     B, T = 70, 48
