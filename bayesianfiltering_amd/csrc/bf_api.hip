@@ -18,14 +18,11 @@ int set_error(int code, const char* fmt, ...) {
   return code;
 }
 
-int launch_kf_small(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
-                    const bf_out_desc* out, hipStream_t stream, int force_mode);
-
-int launch_kf_cols(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
-                   const bf_out_desc* out, hipStream_t stream, int force_mode);
+int launch_kf_group(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
+                    const bf_out_desc* out, hipStream_t stream, int force_mode, int lanes);
 
 static int g_kf_emit_mode = -1;  // -1 = choose from the layout
-static int g_kf_kernel = 0;      // 0 = column-per-lane (default), 1 = lane-per-chain baseline
+static int g_kf_lanes = 0;       // 0 = default lanes per trajectory for the (n, m) pair
 
 }  // namespace bf
 
@@ -52,9 +49,9 @@ int bf_set_option(const char* name, int value) {
     bf::g_kf_emit_mode = value;
     return BF_OK;
   }
-  if (name && std::strcmp(name, "kf_kernel") == 0) {
-    if (value < 0 || value > 1) return bf::set_error(BF_EINVAL, "kf_kernel must be 0 or 1");
-    bf::g_kf_kernel = value;
+  if (name && std::strcmp(name, "kf_lanes") == 0) {
+    if (value < 0 || value > 64 || (value & (value - 1)) != 0) return bf::set_error(BF_EINVAL, "kf_lanes must be 0 or a power of two <= 64");
+    bf::g_kf_lanes = value;
     return BF_OK;
   }
   return bf::set_error(BF_EINVAL, "unknown option '%s'", name ? name : "(null)");
@@ -87,9 +84,8 @@ int bf_kalman_filter_f32(const bf_lgssm* model, const bf_cstream* y, int64_t B, 
   if (model->Q_steps < 1 || model->R_steps < 1) return bf::set_error(BF_EINVAL, "Q_steps / R_steps must be >= 1");
   if (!y->ptr) return bf::set_error(BF_EINVAL, "observations pointer is NULL");
   if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
-  if (bf::g_kf_kernel == 1)
-    return bf::launch_kf_small(model, y, B, T, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode);
-  return bf::launch_kf_cols(model, y, B, T, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode);
+  return bf::launch_kf_group(model, y, B, T, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode,
+                             bf::g_kf_lanes);
 }
 
 }  // extern "C"

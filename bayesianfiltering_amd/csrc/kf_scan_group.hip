@@ -1,27 +1,34 @@
-// kf_scan_cols: batched Kalman filter with one covariance COLUMN per lane.
+// kf_scan_group: batched Kalman filter, NL lanes per trajectory, CPL covariance COLUMNS per lane.
 //
 // Replaces, for linear f/h and one component, the lax.scan body of gaussian_sum_filter
 // (gaussfiltax/inference.py:333-371): per step  _condition_on (:72-105)  ->  reweight
 // (:347-350)  ->  _predict (:51-70), emitting the five posterior streams of :357-363.
 //
-// Mapping (gfx950).  NL = next_pow2(n) consecutive lanes form a group that advances ONE
-// trajectory; lane j of the group owns column j of P and entry j of m.  A wave64 therefore
-// carries 64/NL trajectories and the batch of cfg2 (65,536 chains, n = 4) is 4,096 waves =
-// 4 waves per SIMD on 256 CUs -- enough to issue a VALU instruction every 2 cycles and to hide
-// LDS / HBM latency behind other waves (the earlier one-lane-per-chain kernel ran 1 wave per
-// SIMD and was issue/latency bound at 45 % of HBM peak even with no stores at all).
-//   * column-local products (H P, A P, K S, gains) need no communication;
-//   * products that contract over the lane index use DPP quad_perm / row_mirror modifiers or
-//     ds_swizzle (lane_group.hpp): P+ = P - (K S) K^T and P- = (A P) A^T broadcast one
-//     register of lane l to the group while every lane multiplies by its own A[j][l], K[j][b];
+// Mapping (gfx950).  NL consecutive lanes (a power of two) form a group that advances ONE
+// trajectory; lane jl of the group owns the CPL = ceil(n / NL) columns jl*CPL .. jl*CPL+CPL-1
+// of P and the matching entries of m.  A wave64 carries CPW = 64 / NL trajectories.
+//   * column-local products (H P, A P, K S, the gain solve) need no communication;
+//   * products that contract over the column index (P+ = P - (K S) K^T, P- = (A P) A^T,
+//     m- = A m+) read the other lanes' registers through DPP quad_perm / ds_swizzle
+//     broadcasts (lane_group.hpp) while every lane multiplies by its own rows of A / K;
 //   * S = (H P) H^T and h(m) = H m are group all-reduces (xor butterflies);
-//   * the tiny m x m LU solve / Cholesky are done redundantly by every lane of the group.
-// Stores (the roofline: 172 B per chain-step at n=4, m=2): EMIT_STAGED transposes time through
-// per-wave LDS tiles so that each trajectory's stream leaves the CU as 64..128-byte contiguous
-// runs written by dwordx4 stores; EMIT_SCALAR handles arbitrary strides (with the batch-inner
-// layout its dword stores are contiguous across trajectories).  Observations are fetched a
-// block of steps ahead into registers and handed to the wave through an LDS tile, so no wave
-// ever waits on a load it issued in the same step.
+//   * the tiny m x m LU factorisation / Cholesky are done redundantly by every lane.
+// NL trades VALU work against occupancy: NL = 1 is one trajectory per lane (no redundancy,
+// 1 wave per SIMD at cfg2's 65,536 trajectories), NL = n is one column per lane (4 waves per
+// SIMD at n = 4, but the solve/Cholesky/log-likelihood are repeated in every lane).  The
+// kernel is instruction-issue bound, so the default is the NL with the fewest VALU
+// instructions per trajectory-step that still keeps >= 2 waves per SIMD.
+//
+// Stores (the roofline: 172 B per trajectory-step at n=4, m=2).  EMIT_STAGED (contiguous
+// reference layout [B][K][T][E]) transposes time through per-wave LDS tiles so that each
+// trajectory's stream leaves the CU as 64..128-byte contiguous runs written by dwordx4 stores;
+// EMIT_SCALAR handles arbitrary strides with one dword store per element (contiguous across
+// trajectories for the batch-inner layout).
+// Loads.  Observations are fetched one block of steps ahead by LDS-DMA (global_load_lds_dword):
+// no VGPR destination, so neither the compiler nor the wave ever waits on a load inside a
+// step; completion is awaited once per block with a counted s_waitcnt vmcnt(N) that leaves the
+// wave's newer stores in flight (gfx9 counts loads and stores on one in-order counter).
+#include <cstdlib>
 #include "bf_common.hpp"
 #include "kf_math.hpp"
 #include "lane_group.hpp"
@@ -40,11 +47,13 @@ struct KFConst {
 
 enum { EMIT_SCALAR = 0, EMIT_STAGED = 2 };
 
-// compile-time-unrolled select of table[idx * STRIDE + OFF] for a lane-dependent idx < CNT
-template <int CNT, int STRIDE>
-__device__ __forceinline__ float pick(const float* table, int idx, int off) {
-  float r = table[off];
-  BF_UNROLL for (int q = 1; q < CNT; ++q) r = (idx == q) ? table[q * STRIDE + off] : r;
+// table[idx * STRIDE + off] for a lane-dependent idx < CNT, as an unrolled select chain (the
+// table is a kernel argument: a runtime index would copy it to scratch)
+template <int CNT>
+__device__ __forceinline__ float pick(const float* table, int limit, int idx, int stride, int off) {
+  float r = (off < limit) ? table[off] : 0.f;
+  BF_UNROLL for (int q = 1; q < CNT; ++q)
+      if (q * stride + off < limit) r = (idx == q) ? table[q * stride + off] : r;
   return r;
 }
 
@@ -62,7 +71,7 @@ __device__ __forceinline__ unsigned lds_byte_addr(const float* p) {
 
 // One LDS-DMA dword per lane: LDS[lds_base + 4*lane] <- *src.  No VGPR destination, so the
 // compiler neither tracks nor waits for it (cdna_hip_programming.md 5.7): completion is
-// awaited with wait_vm<N>() below.  M0 carries the wave-uniform LDS base.
+// awaited with wait_vm(n) below.  M0 carries the wave-uniform LDS base.
 __device__ __forceinline__ void lds_dma_dword(const float* src, unsigned lds_base) {
   unsigned keep;
   asm volatile(
@@ -95,9 +104,9 @@ __device__ __forceinline__ void wait_vm(int n) {
 // ---------------------------------------------------------------------------------------
 // Per-wave LDS tile that transposes time for one output stream.
 //   rows = the CPW trajectories of the wave; a row holds W = TS*E floats (TS consecutive steps)
-//   at a pitch of W + PAD floats.  PAD = 4 keeps the per-step dword writes of the 8 groups in
-//   a half-wave on 32 different banks while rows stay 16-byte aligned for the ds_read_b128 of
-//   the flush.  A flush writes every row's W*4 contiguous bytes with dwordx4 stores.
+//   at a pitch of W + PAD floats.  PAD = 4 keeps the per-step writes of the lanes of a
+//   half-wave on different banks while rows stay 16-byte aligned for the ds_read_b128 of the
+//   flush.  A flush writes every row's W*4 contiguous bytes with dwordx4 stores.
 template <int E, int W, int CPW, int PAD>
 struct Tile {
   static constexpr int TS = W / E;
@@ -109,13 +118,11 @@ struct Tile {
                              (CPW * CH >= 64) && ((CPW * CH) % 64 == 0);
 
   // lane-dependent byte offset of this lane's first chunk relative to the wave's base (the host
-  // guarantees that 16 rows of a stream span less than 4 GiB, so 32 bits are enough and the
-  // stores can use the SGPR-base + VGPR-offset form)
+  // guarantees that the rows of one wave span less than 4 GiB, so 32 bits are enough)
   static __device__ __forceinline__ unsigned lane_off(int lane, long long sB) {
     return (unsigned)((lane / CH) * sB * 4 + (lane % CH) * 16);
   }
 
-  // read this lane's ITER chunks of the tile into registers
   static __device__ __forceinline__ void read(const float* tile, int lane, float4* v) {
     constexpr int RPI = 64 / CH;
     const int c = lane % CH;
@@ -136,10 +143,11 @@ struct Tile {
   }
 };
 
-template <int NS, int M>
-struct ColsCfg {
-  static constexpr int NL = next_pow2(NS);
-  static constexpr int CPW = 64 / NL;
+template <int NS, int M, int NL>
+struct GroupCfg {
+  static_assert((NL & (NL - 1)) == 0 && NL >= 1 && NL <= 64, "lanes per trajectory must be a power of two");
+  static constexpr int CPL = (NS + NL - 1) / NL;  // columns per lane
+  static constexpr int CPW = 64 / NL;             // trajectories per wave
   static constexpr int EP = NS * NS;
   // floats per staged row: 128-byte rows for the matrix streams, 64-byte rows for the rest
   // (and never fewer than 64 float4 chunks per wave tile, so a flush is whole store instructions)
@@ -150,22 +158,21 @@ struct ColsCfg {
   using TP = Tile<EP, WP, CPW, 4>;
   using TM = Tile<NS, WM, CPW, 4>;
   using TW = Tile<1, WW, CPW, 0>;
-  static constexpr int TSMAX = (TW::TS > TM::TS ? (TW::TS > TP::TS ? TW::TS : TP::TS) : (TM::TS > TP::TS ? TM::TS : TP::TS));
   // observation blocks: YS steps (>= 8 floats per trajectory) fetched by LDS-DMA one block ahead
   static constexpr int YS = (M >= 8) ? 1 : 8 / M;
-  static constexpr int YW = YS * M;                  // floats per trajectory per block
-  static constexpr int YTILE = CPW * YW;             // floats per block tile (DMA writes it in lane order)
-  static constexpr int YDMA = (YTILE + 63) / 64;     // LDS-DMA instructions per block
-  static constexpr int YBUF = YDMA * 64;             // floats reserved per buffer
-  static constexpr bool STAGED_OK = (NS == NL) && TP::OK && TM::OK && TW::OK;
+  static constexpr int YW = YS * M;               // floats per trajectory per block
+  static constexpr int YTILE = CPW * YW;          // floats per block tile (DMA writes it in lane order)
+  static constexpr int YDMA = (YTILE + 63) / 64;  // LDS-DMA instructions per block
+  static constexpr int YBUF = YDMA * 64;          // floats reserved per buffer
+  static constexpr bool STAGED_OK = (NS == NL * CPL) && TP::OK && TM::OK && TW::OK;
 };
 
-template <int NS, int M, int MODE, bool TV>
-__global__ void __launch_bounds__(256, 4)
-kf_scan_cols_kernel(KFConst<NS, M> c, const float* __restrict__ gqg_t, const float* __restrict__ drd_t, CView y,
-                    CarryView carry, OutViews out, long long B, long long T, int lds_per_wave, int vm_younger) {
-  using Cfg = ColsCfg<NS, M>;
-  constexpr int NL = Cfg::NL, CPW = Cfg::CPW, EP = Cfg::EP, YS = Cfg::YS;
+template <int NS, int M, int NL, int MODE, bool TV>
+__global__ void __launch_bounds__(256, (NL >= 4 ? 4 : NL))
+kf_scan_group_kernel(KFConst<NS, M> c, const float* __restrict__ gqg_t, const float* __restrict__ drd_t, CView y,
+                     CarryView carry, OutViews out, long long B, long long T, int lds_per_wave, int vm_younger) {
+  using Cfg = GroupCfg<NS, M, NL>;
+  constexpr int CPL = Cfg::CPL, CPW = Cfg::CPW, EP = Cfg::EP, YS = Cfg::YS;
   using TP = typename Cfg::TP;
   using TM = typename Cfg::TM;
   using TW = typename Cfg::TW;
@@ -176,48 +183,55 @@ kf_scan_cols_kernel(KFConst<NS, M> c, const float* __restrict__ gqg_t, const flo
   const long long b0w = gwave * CPW;  // first trajectory of this wave
   if (b0w >= B) return;               // whole wave out of range (uniform)
   const int g = lane / NL;
-  const int j = lane % NL;
-  const bool col_ok = j < NS;
-  const int jc = col_ok ? j : NS - 1;
+  const int jl = lane % NL;
   const long long b_raw = b0w + g;
   const bool chain_ok = (MODE == EMIT_STAGED) ? true : (b_raw < B);  // staged launches hold full waves only
   const long long b = chain_ok ? b_raw : B - 1;
 
-  // ---- per-lane constants: row j of A, column j of H and of G Q G^T
-  float Arow[NS], Hcol[M], Gcol[NS], gq0j;
-  BF_UNROLL for (int l = 0; l < NS; ++l) Arow[l] = col_ok ? pick<NS, NS>(c.A, jc, l) : 0.f;
-  BF_UNROLL for (int a = 0; a < M; ++a) Hcol[a] = col_ok ? pick<NS, 1>(c.H, jc, a * NS) : 0.f;
-  BF_UNROLL for (int i = 0; i < NS; ++i) Gcol[i] = col_ok ? pick<NS, 1>(c.GQG, jc, i * NS) : 0.f;
-  gq0j = col_ok ? pick<NS, 1>(c.Gq0, jc, 0) : 0.f;
+  // ---- per-lane constants for the CPL owned columns: rows of A, columns of H and of G Q G^T.
+  // Columns past n (padding lanes when NL*CPL > n) carry zeros and stay zero.
+  bool col_ok[CPL];
+  float Arow[CPL][NS], Hcol[CPL][M], Gcol[CPL][NS], gq0[CPL];
+  BF_UNROLL for (int cc = 0; cc < CPL; ++cc) {
+    col_ok[cc] = (jl * CPL + cc) < NS;
+    BF_UNROLL for (int l = 0; l < NS; ++l)
+        Arow[cc][l] = col_ok[cc] ? pick<NL>(c.A, NS * NS, jl, CPL * NS, cc * NS + l) : 0.f;
+    BF_UNROLL for (int a = 0; a < M; ++a) Hcol[cc][a] = col_ok[cc] ? pick<NL>(c.H, M * NS, jl, CPL, a * NS + cc) : 0.f;
+    BF_UNROLL for (int i = 0; i < NS; ++i) Gcol[cc][i] = col_ok[cc] ? pick<NL>(c.GQG, NS * NS, jl, CPL, i * NS + cc) : 0.f;
+    gq0[cc] = col_ok[cc] ? pick<NL>(c.Gq0, NS, jl, CPL, cc) : 0.f;
+  }
 
-  // ---- state
-  float Pc[NS], mj, w;
-  BF_UNROLL for (int i = 0; i < NS; ++i) Pc[i] = col_ok ? carry.P_in[b * EP + i * NS + jc] : 0.f;
-  mj = col_ok ? carry.m_in[b * NS + jc] : 0.f;
+  // ---- state: Pc[cc][i] = P[i][jl*CPL + cc], mj[cc] = m[jl*CPL + cc]
+  float Pc[CPL][NS], mj[CPL], w;
+  BF_UNROLL for (int cc = 0; cc < CPL; ++cc) {
+    const int col = col_ok[cc] ? jl * CPL + cc : 0;
+    BF_UNROLL for (int i = 0; i < NS; ++i) Pc[cc][i] = col_ok[cc] ? carry.P_in[b * EP + i * NS + col] : 0.f;
+    mj[cc] = col_ok[cc] ? carry.m_in[b * NS + col] : 0.f;
+  }
   w = carry.w_in ? carry.w_in[b] : 1.0f;
 
   // ---- LDS carve (dynamic; only enabled streams take space).  Tiles are addressed as
-  // lds + integer offset so that every access stays a DS instruction.
+  // lds + integer offset so that every access stays a DS instruction; a disabled stream
+  // aliases the observation tile (always large enough to be read from).
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int q = wave_in_blk * lds_per_wave;
   const int oY = q;
   q += 2 * Cfg::YBUF;
-  int oP = 0, opP = 0, oM = 0, opM = 0, oW = 0, oL = 0;
+  int oP = oY, opP = oY, oM = oY, opM = oY, oW = oY, oL = oY;
   if constexpr (MODE == EMIT_STAGED) {
-    // a disabled stream aliases the observation tile (always large enough to be read from)
-    oP = out.P.p ? q : oY;   q += out.P.p ? TP::FLOATS : 0;
-    opP = out.pP.p ? q : oY; q += out.pP.p ? TP::FLOATS : 0;
-    oM = out.m.p ? q : oY;   q += out.m.p ? TM::FLOATS : 0;
-    opM = out.pm.p ? q : oY; q += out.pm.p ? TM::FLOATS : 0;
-    oW = out.w.p ? q : oY;   q += out.w.p ? TW::FLOATS : 0;
-    oL = out.ll.p ? q : oY;
+    if (out.P.p) { oP = q; q += TP::FLOATS; }
+    if (out.pP.p) { opP = q; q += TP::FLOATS; }
+    if (out.m.p) { oM = q; q += TM::FLOATS; }
+    if (out.pm.p) { opM = q; q += TM::FLOATS; }
+    if (out.w.p) { oW = q; q += TW::FLOATS; }
+    if (out.ll.p) { oL = q; q += TW::FLOATS; }
   }
   const unsigned offP = TP::lane_off(lane, T * EP);
   const unsigned offM = TM::lane_off(lane, T * NS);
   const unsigned offW = TW::lane_off(lane, T);
   // per-lane LDS positions for the per-step writes
-  const int putP = g * TP::PITCH + j;
-  const int putM = g * TM::PITCH + j;
+  const int putP = g * TP::PITCH + jl * CPL;
+  const int putM = g * TM::PITCH + jl * CPL;
   const int putW = g * TW::PITCH;
 
   // ---- observation stream: LDS-DMA, block k+1 lands while block k is consumed
@@ -226,38 +240,36 @@ kf_scan_cols_kernel(KFConst<NS, M> c, const float* __restrict__ gqg_t, const flo
     const int e = lane + 64 * i;
     const int ch = (e / Cfg::YW) < CPW ? (e / Cfg::YW) : CPW - 1, f = e % Cfg::YW;
     const long long bb = (b0w + ch < B) ? b0w + ch : B - 1;
-    // address of (trajectory, step f / M of block 0, entry f % M); advanced by YS*sT per block
-    ysrc[i] = y.p + bb * y.sB + (long long)(f / M) * y.sT + (long long)(f % M) * y.sE;
+    // address of (trajectory, entry f % M) at step 0; the step is added per block
+    ysrc[i] = y.p + bb * y.sB + (long long)(f % M) * y.sE;
   }
   const unsigned ybase = lds_byte_addr(lds + oY);
   auto y_fetch = [&](long long tb, int buf) {
     BF_UNROLL for (int i = 0; i < Cfg::YDMA; ++i) {
       const int e = lane + 64 * i;
       const int f = e % Cfg::YW;
-      // steps past the end re-read the last valid step (value unused)
-      long long tt = tb + f / M;
+      long long tt = tb + f / M;  // steps past the end re-read the last valid step (value unused)
       tt = tt < T ? tt : T - 1;
-      const float* src = ysrc[i] + (tt - f / M) * y.sT;
       if (Cfg::YTILE % 64 == 0 || e < Cfg::YTILE)
-        lds_dma_dword(src, ybase + (unsigned)(buf * Cfg::YBUF + 64 * i) * 4u);
+        lds_dma_dword(ysrc[i] + tt * y.sT, ybase + (unsigned)(buf * Cfg::YBUF + 64 * i) * 4u);
     }
   };
 
-  // one filter step; STAGED selects the emit path at compile time
-  auto step = [&](long long t, auto staged_tag) {
-    constexpr bool STAGED = decltype(staged_tag)::value;
+  // ---- one filter step
+  auto step = [&](long long t) {
     const int ys = (int)(t % YS);
     const int ybuf = (int)((t / YS) & 1);
     float yv[M];
     BF_UNROLL for (int a = 0; a < M; ++a) yv[a] = lds[oY + ybuf * Cfg::YBUF + g * Cfg::YW + ys * M + a];
 
-    const float* GQGc = Gcol;
+    float gqv[CPL][NS], dr[M * M];
     const float* DRD = c.DRD;
-    float gq[NS], dr[M * M];
     if constexpr (TV) {
       if (gqg_t) {
-        BF_UNROLL for (int i = 0; i < NS; ++i) gq[i] = col_ok ? gqg_t[t * EP + i * NS + jc] : 0.f;
-        GQGc = gq;
+        BF_UNROLL for (int cc = 0; cc < CPL; ++cc) BF_UNROLL for (int i = 0; i < NS; ++i)
+            gqv[cc][i] = col_ok[cc] ? gqg_t[t * EP + i * NS + jl * CPL + cc] : 0.f;
+      } else {
+        BF_UNROLL for (int cc = 0; cc < CPL; ++cc) BF_UNROLL for (int i = 0; i < NS; ++i) gqv[cc][i] = Gcol[cc][i];
       }
       if (drd_t) {
         BF_UNROLL for (int i = 0; i < M * M; ++i) dr[i] = drd_t[t * M * M + i];
@@ -268,115 +280,135 @@ kf_scan_cols_kernel(KFConst<NS, M> c, const float* __restrict__ gqg_t, const flo
     // ================= _condition_on (inference.py:72-105) =================
     // innovation v = y - (H m + H_r r0): group all-reduce over the state index
     float v[M];
-    BF_UNROLL for (int a = 0; a < M; ++a) v[a] = yv[a] - (group_sum<NL>(Hcol[a] * mj) + c.Dr0[a]);
-    // column j of H_x P
-    float HPc[M];
     BF_UNROLL for (int a = 0; a < M; ++a) {
-      float s = c.H[a * NS] * Pc[0];
-      BF_UNROLL for (int i = 1; i < NS; ++i) s = fmaf(c.H[a * NS + i], Pc[i], s);
-      HPc[a] = s;
+      float s = Hcol[0][a] * mj[0];
+      BF_UNROLL for (int cc = 1; cc < CPL; ++cc) s = fmaf(Hcol[cc][a], mj[cc], s);
+      v[a] = yv[a] - (group_sum<NL>(s) + c.Dr0[a]);
+    }
+    // owned columns of H_x P, laid out [a][cc] (the right-hand sides of the gain solve)
+    float X[M * CPL];
+    BF_UNROLL for (int a = 0; a < M; ++a) BF_UNROLL for (int cc = 0; cc < CPL; ++cc) {
+      float s = c.H[a * NS] * Pc[cc][0];
+      BF_UNROLL for (int i = 1; i < NS; ++i) s = fmaf(c.H[a * NS + i], Pc[cc][i], s);
+      X[a * CPL + cc] = s;
     }
     // S = H_r R H_r^T + (H_x P) H_x^T
     float S[M * M];
-    BF_UNROLL for (int a = 0; a < M; ++a) BF_UNROLL for (int bb = 0; bb < M; ++bb)
-        S[a * M + bb] = DRD[a * M + bb] + group_sum<NL>(HPc[a] * Hcol[bb]);
-    // K[j][:] = column j of solve(S + 1e-6, H_x P)
-    float X[M];
-    BF_UNROLL for (int a = 0; a < M; ++a) X[a] = HPc[a];
-    psd_solve<M, 1>(S, X);
-    // (K S)[j][:]
-    float KS[M];
-    BF_UNROLL for (int bb = 0; bb < M; ++bb) {
-      float s = X[0] * S[bb];
-      BF_UNROLL for (int a = 1; a < M; ++a) s = fmaf(X[a], S[a * M + bb], s);
-      KS[bb] = s;
+    BF_UNROLL for (int a = 0; a < M; ++a) BF_UNROLL for (int bb = 0; bb < M; ++bb) {
+      float s = X[a * CPL] * Hcol[0][bb];
+      BF_UNROLL for (int cc = 1; cc < CPL; ++cc) s = fmaf(X[a * CPL + cc], Hcol[cc][bb], s);
+      S[a * M + bb] = DRD[a * M + bb] + group_sum<NL>(s);
     }
-    // P+[i][j] = P[i][j] - sum_b (K S)[i][b] K[j][b]   ((K S)[i][:] lives in lane i)
+    // K[col][:] = column col of solve(S + 1e-6, H_x P)       X[a][cc] = K[col(cc)][a]
+    psd_solve<M, CPL>(S, X);
+    // (K S)[col][:]
+    float KS[CPL][M];
+    BF_UNROLL for (int cc = 0; cc < CPL; ++cc) BF_UNROLL for (int bb = 0; bb < M; ++bb) {
+      float s = X[cc] * S[bb];
+      BF_UNROLL for (int a = 1; a < M; ++a) s = fmaf(X[a * CPL + cc], S[a * M + bb], s);
+      KS[cc][bb] = s;
+    }
+    // P+[i][col] = P[i][col] - sum_b (K S)[i][b] K[col][b]   ((K S)[i][:] lives in lane i / CPL)
     static_for<0, NS>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      float s = group_bcast<NL, i>(KS[0]) * X[0];
-      BF_UNROLL for (int bb = 1; bb < M; ++bb) s = fmaf(group_bcast<NL, i>(KS[bb]), X[bb], s);
-      Pc[i] -= s;
+      float ks_i[M];
+      BF_UNROLL for (int bb = 0; bb < M; ++bb) ks_i[bb] = group_bcast<NL, i / CPL>(KS[i % CPL][bb]);
+      BF_UNROLL for (int cc = 0; cc < CPL; ++cc) {
+        float s = ks_i[0] * X[cc];
+        BF_UNROLL for (int bb = 1; bb < M; ++bb) s = fmaf(ks_i[bb], X[bb * CPL + cc], s);
+        Pc[cc][i] -= s;
+      }
     });
-    // m+[j] = m[j] + K[j][:] . v
-    {
-      float s = X[0] * v[0];
-      BF_UNROLL for (int a = 1; a < M; ++a) s = fmaf(X[a], v[a], s);
-      mj += s;
+    // m+[col] = m[col] + K[col][:] . v
+    BF_UNROLL for (int cc = 0; cc < CPL; ++cc) {
+      float s = X[cc] * v[0];
+      BF_UNROLL for (int a = 1; a < M; ++a) s = fmaf(X[a * CPL + cc], v[a], s);
+      mj[cc] += s;
     }
     const float ll = mvn_logpdf_chol<M>(S, v);
 
     // ================= reweight, K = 1 (inference.py:347-350) =================
     w = reweight_single(ll, w);
 
-    if constexpr (STAGED) {
-      if (out.m.p) lds[oM + putM + int(t % TM::TS) * NS] = mj;
+    if constexpr (MODE == EMIT_STAGED) {
+      if (out.m.p) BF_UNROLL for (int cc = 0; cc < CPL; ++cc) lds[oM + putM + int(t % TM::TS) * NS + cc] = mj[cc];
       if (out.P.p) {
         const int o = oP + putP + int(t % TP::TS) * EP;
-        BF_UNROLL for (int i = 0; i < NS; ++i) lds[o + i * NS] = Pc[i];
+        BF_UNROLL for (int i = 0; i < NS; ++i) BF_UNROLL for (int cc = 0; cc < CPL; ++cc) lds[o + i * NS + cc] = Pc[cc][i];
       }
-      if (j == 0) {
+      if (jl == 0) {
         if (out.w.p) lds[oW + putW + int(t % TW::TS)] = w;
         if (out.ll.p) lds[oL + putW + int(t % TW::TS)] = ll;
       }
-    } else if (chain_ok && col_ok) {
-      if (out.m.p) out.m.p[b * out.m.sB + t * out.m.sT + j * out.m.sE] = mj;
-      if (out.P.p) BF_UNROLL for (int i = 0; i < NS; ++i)
-          out.P.p[b * out.P.sB + t * out.P.sT + (i * NS + j) * out.P.sE] = Pc[i];
-      if (j == 0) {
+    } else if (chain_ok) {
+      BF_UNROLL for (int cc = 0; cc < CPL; ++cc) if (col_ok[cc]) {
+        const int col = jl * CPL + cc;
+        if (out.m.p) out.m.p[b * out.m.sB + t * out.m.sT + col * out.m.sE] = mj[cc];
+        if (out.P.p) BF_UNROLL for (int i = 0; i < NS; ++i)
+            out.P.p[b * out.P.sB + t * out.P.sT + (i * NS + col) * out.P.sE] = Pc[cc][i];
+      }
+      if (jl == 0) {
         if (out.w.p) out.w.p[b * out.w.sB + t * out.w.sT] = w;
         if (out.ll.p) out.ll.p[b * out.ll.sB + t * out.ll.sT] = ll;
       }
     }
 
     // ================= _predict (inference.py:51-70) =================
-    // column j of F_x P+
-    float APc[NS];
-    BF_UNROLL for (int i = 0; i < NS; ++i) {
-      float s = c.A[i * NS] * Pc[0];
-      BF_UNROLL for (int k = 1; k < NS; ++k) s = fmaf(c.A[i * NS + k], Pc[k], s);
-      APc[i] = s;
+    // owned columns of F_x P+
+    float APc[CPL][NS];
+    BF_UNROLL for (int cc = 0; cc < CPL; ++cc) BF_UNROLL for (int i = 0; i < NS; ++i) {
+      float s = c.A[i * NS] * Pc[cc][0];
+      BF_UNROLL for (int k = 1; k < NS; ++k) s = fmaf(c.A[i * NS + k], Pc[cc][k], s);
+      APc[cc][i] = s;
     }
-    // P-[i][j] = sum_l (F_x P+)[i][l] F_x[j][l] + (F_q Q F_q^T)[i][j]
+    // P-[i][col] = sum_l (F_x P+)[i][l] F_x[col][l] + (F_q Q F_q^T)[i][col]
     BF_UNROLL for (int i = 0; i < NS; ++i) {
-      float s = 0.f;
+      float acc[CPL];
       static_for<0, NS>([&](auto L) {
         constexpr int l = decltype(L)::value;
-        const float ap_l = group_bcast<NL, l>(APc[i]);
-        s = (l == 0) ? ap_l * Arow[0] : fmaf(ap_l, Arow[l], s);
+        const float ap_l = group_bcast<NL, l / CPL>(APc[l % CPL][i]);
+        BF_UNROLL for (int cc = 0; cc < CPL; ++cc) acc[cc] = (l == 0) ? ap_l * Arow[cc][0] : fmaf(ap_l, Arow[cc][l], acc[cc]);
       });
-      Pc[i] = s + GQGc[i];
+      BF_UNROLL for (int cc = 0; cc < CPL; ++cc) {
+        if constexpr (TV) Pc[cc][i] = acc[cc] + gqv[cc][i];
+        else Pc[cc][i] = acc[cc] + Gcol[cc][i];
+      }
     }
-    // m-[j] = sum_k F_x[j][k] m+[k] + (F_q q0)[j]
-    float mnew = 0.f;
-    static_for<0, NS>([&](auto Kk) {
-      constexpr int k = decltype(Kk)::value;
-      const float mk = group_bcast<NL, k>(mj);
-      mnew = (k == 0) ? Arow[0] * mk : fmaf(Arow[k], mk, mnew);
-    });
-    mj = mnew + gq0j;
+    // m-[col] = sum_k F_x[col][k] m+[k] + (F_q q0)[col]
+    {
+      float acc[CPL];
+      static_for<0, NS>([&](auto Kk) {
+        constexpr int k = decltype(Kk)::value;
+        const float mk = group_bcast<NL, k / CPL>(mj[k % CPL]);
+        BF_UNROLL for (int cc = 0; cc < CPL; ++cc) acc[cc] = (k == 0) ? Arow[cc][0] * mk : fmaf(Arow[cc][k], mk, acc[cc]);
+      });
+      BF_UNROLL for (int cc = 0; cc < CPL; ++cc) mj[cc] = acc[cc] + gq0[cc];
+    }
 
-    if constexpr (STAGED) {
-      if (out.pm.p) lds[opM + putM + int(t % TM::TS) * NS] = mj;
+    if constexpr (MODE == EMIT_STAGED) {
+      if (out.pm.p) BF_UNROLL for (int cc = 0; cc < CPL; ++cc) lds[opM + putM + int(t % TM::TS) * NS + cc] = mj[cc];
       if (out.pP.p) {
         const int o = opP + putP + int(t % TP::TS) * EP;
-        BF_UNROLL for (int i = 0; i < NS; ++i) lds[o + i * NS] = Pc[i];
+        BF_UNROLL for (int i = 0; i < NS; ++i) BF_UNROLL for (int cc = 0; cc < CPL; ++cc) lds[o + i * NS + cc] = Pc[cc][i];
       }
-    } else if (chain_ok && col_ok) {
-      if (out.pm.p) out.pm.p[b * out.pm.sB + t * out.pm.sT + j * out.pm.sE] = mj;
-      if (out.pP.p) BF_UNROLL for (int i = 0; i < NS; ++i)
-          out.pP.p[b * out.pP.sB + t * out.pP.sT + (i * NS + j) * out.pP.sE] = Pc[i];
+    } else if (chain_ok) {
+      BF_UNROLL for (int cc = 0; cc < CPL; ++cc) if (col_ok[cc]) {
+        const int col = jl * CPL + cc;
+        if (out.pm.p) out.pm.p[b * out.pm.sB + t * out.pm.sT + col * out.pm.sE] = mj[cc];
+        if (out.pP.p) BF_UNROLL for (int i = 0; i < NS; ++i)
+            out.pP.p[b * out.pP.sB + t * out.pP.sT + (i * NS + col) * out.pP.sE] = Pc[cc][i];
+      }
     }
   };
 
-  // flush the tiles whose rows completed at step t (t1 = t + 1): all LDS reads of an event are
-  // issued before the first store so that one LDS round trip covers the whole event.  `last`
-  // (after the final step) also flushes the incomplete rows, chunk-limited.
+  // flush the tiles whose rows completed at step t1 - 1: all LDS reads of an event are issued
+  // before the first store so that one LDS round trip covers the whole event.  `last` (after the
+  // final step) also flushes the incomplete rows, chunk-limited.  Both tiles of a pair are
+  // read unconditionally so the staging registers never become a conditionally-initialised
+  // array (which the compiler would demote to scratch).
   auto flush_all = [&](long long t1, bool last) {
     if constexpr (MODE == EMIT_STAGED) {
       const int remP = (int)(t1 % TP::TS), remM = (int)(t1 % TM::TS), remW = (int)(t1 % TW::TS);
-      // (both tiles of a pair are read unconditionally -- a disabled stream's offset aliases a
-      // valid tile -- so the staging registers never become a conditionally-initialised array)
       if (remP == 0 || last) {
         wave_lds_sync();
         const long long t0 = remP == 0 ? t1 - TP::TS : t1 - remP;
@@ -422,17 +454,20 @@ kf_scan_cols_kernel(KFConst<NS, M> c, const float* __restrict__ gqg_t, const flo
     wave_lds_sync();
     const long long te = (tb + YS < T) ? tb + YS : T;
     for (long long t = tb; t < te; ++t) {
-      step(t, std::integral_constant<bool, MODE == EMIT_STAGED>{});
+      step(t);
       if (t + 1 < T) flush_all(t + 1, false);
     }
   }
   flush_all(T, true);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  if (chain_ok && col_ok) {
-    if (carry.m_out) carry.m_out[b * NS + j] = mj;
-    if (carry.P_out) BF_UNROLL for (int i = 0; i < NS; ++i) carry.P_out[b * EP + i * NS + j] = Pc[i];
-    if (carry.w_out && j == 0) carry.w_out[b] = w;
+  if (chain_ok) {
+    BF_UNROLL for (int cc = 0; cc < CPL; ++cc) if (col_ok[cc]) {
+      const int col = jl * CPL + cc;
+      if (carry.m_out) carry.m_out[b * NS + col] = mj[cc];
+      if (carry.P_out) BF_UNROLL for (int i = 0; i < NS; ++i) carry.P_out[b * EP + i * NS + col] = Pc[cc][i];
+    }
+    if (carry.w_out && jl == 0) carry.w_out[b] = w;
   }
 }
 
@@ -482,10 +517,10 @@ static bool stream_is_reference(const bf_stream& s, long long E, long long T) {
          (s.sE == 1 && s.sT == E && s.sB == T * E && (reinterpret_cast<uintptr_t>(s.ptr) % 16 == 0));
 }
 
-template <int N, int M>
-static int launch_nm(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
-                     const bf_out_desc* out, hipStream_t stream, int force_mode) {
-  using Cfg = ColsCfg<N, M>;
+template <int N, int M, int NL>
+static int launch_nml(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
+                      const bf_out_desc* out, hipStream_t stream, int force_mode) {
+  using Cfg = GroupCfg<N, M, NL>;
   KFConst<N, M> c;
   fill_const<N, M>(p, c, p->Q, p->R);
   CView yv{y->ptr, y->sB, y->sT, y->sE};
@@ -500,8 +535,8 @@ static int launch_nm(const bf_lgssm* p, const bf_cstream* y, long long B, long l
   auto row_ok = [&](const bf_stream& st, long long E) { return st.ptr == nullptr || (T * E) % 4 == 0; };
   const bool rows_aligned = row_ok(out->weights, 1) && row_ok(out->loglik, 1) && row_ok(out->means, N) &&
                             row_ok(out->pred_means, N) && row_ok(out->covs, N * N) && row_ok(out->pred_covs, N * N);
-  // the flush addresses rows through 32-bit byte offsets from a wave-uniform base
-  const bool off32_ok = (double)T * N * N * 4.0 * 17.0 < 4.0e9;
+  // the flush addresses the rows of one wave through 32-bit byte offsets from a uniform base
+  const bool off32_ok = (double)T * N * N * 4.0 * (Cfg::CPW + 1) < 4.0e9;
   const bool staged_ok = Cfg::STAGED_OK && ref_layout && rows_aligned && off32_ok;
   int mode = staged_ok ? EMIT_STAGED : EMIT_SCALAR;
   if (force_mode == EMIT_SCALAR || force_mode == 1) mode = EMIT_SCALAR;
@@ -545,7 +580,6 @@ static int launch_nm(const bf_lgssm* p, const bf_cstream* y, long long B, long l
 
   // One launch over trajectories [b_begin, b_begin + b_count) with the given emit mode.
   auto launch = [&](int mode_, long long b_begin, long long b_count) {
-    using Cfg = ColsCfg<N, M>;
     const int nP = (out->covs.ptr ? 1 : 0) + (out->pred_covs.ptr ? 1 : 0);
     const int nM = (out->means.ptr ? 1 : 0) + (out->pred_means.ptr ? 1 : 0);
     const int nW = (out->weights.ptr ? 1 : 0) + (out->loglik.ptr ? 1 : 0);
@@ -558,7 +592,7 @@ static int launch_nm(const bf_lgssm* p, const bf_cstream* y, long long B, long l
       vm_younger = (Cfg::YS / Cfg::TP::TS) * nP * Cfg::TP::ITER + (Cfg::YS / Cfg::TM::TS) * nM * Cfg::TM::ITER +
                    (Cfg::YS / Cfg::TW::TS) * nW * Cfg::TW::ITER;
     } else {
-      vm_younger = Cfg::YS * (nM + nP * N + nW);
+      vm_younger = Cfg::YS * (nM * Cfg::CPL + nP * N * Cfg::CPL + nW);
     }
     if (vm_younger > 40) vm_younger = 40;
     const size_t lds_bytes = sizeof(float) * (size_t)lds_per_wave * 4;
@@ -572,8 +606,8 @@ static int launch_nm(const bf_lgssm* p, const bf_cstream* y, long long B, long l
     dim3 block(256);
     dim3 grid((unsigned)((waves + 3) / 4));
 #define BF_LAUNCH(MODE_, TV_)                                                                                  \
-  hipLaunchKernelGGL((kf_scan_cols_kernel<N, M, MODE_, TV_>), grid, block, lds_bytes, stream, c, d_gqg, d_drd, \
-                     yv2, cv2, ov2, b_count, T, lds_per_wave, vm_younger)
+  hipLaunchKernelGGL((kf_scan_group_kernel<N, M, NL, MODE_, TV_>), grid, block, lds_bytes, stream, c, d_gqg,   \
+                     d_drd, yv2, cv2, ov2, b_count, T, lds_per_wave, vm_younger)
     if (tv) {
       if (mode_ == EMIT_SCALAR) BF_LAUNCH(EMIT_SCALAR, true);
       else if constexpr (Cfg::STAGED_OK) BF_LAUNCH(EMIT_STAGED, true);
@@ -597,24 +631,29 @@ static int launch_nm(const bf_lgssm* p, const bf_cstream* y, long long B, long l
   return BF_OK;
 }
 
-// (n, m) pairs compiled into the column-per-lane kernel
-int launch_kf_cols(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
-                   const bf_out_desc* out, hipStream_t stream, int force_mode) {
-#define BF_CASE(N_, M_) \
-  if (p->n == N_ && p->m == M_) return launch_nm<N_, M_>(p, y, B, T, carry, out, stream, force_mode)
-  BF_CASE(1, 1);
-  BF_CASE(2, 1);
-  BF_CASE(2, 2);
-  BF_CASE(3, 1);
-  BF_CASE(3, 3);
-  BF_CASE(4, 1);
-  BF_CASE(4, 2);
-  BF_CASE(4, 4);
-  BF_CASE(6, 3);
-  BF_CASE(8, 4);
+// (n, m, lanes-per-trajectory) triples compiled into the kernel.  `lanes` = 0 picks the default
+// (first entry listed for the (n, m) pair).
+int launch_kf_group(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
+                    const bf_out_desc* out, hipStream_t stream, int force_mode, int lanes) {
+#define BF_CASE(N_, M_, NL_)                                             \
+  if (p->n == N_ && p->m == M_ && (lanes == 0 || lanes == NL_))          \
+  return launch_nml<N_, M_, NL_>(p, y, B, T, carry, out, stream, force_mode)
+  BF_CASE(1, 1, 1);
+  BF_CASE(2, 1, 1);
+  BF_CASE(2, 2, 1);
+  BF_CASE(3, 1, 2);
+  BF_CASE(3, 3, 2);
+  BF_CASE(4, 1, 2);
+  BF_CASE(4, 2, 2);
+  BF_CASE(4, 2, 1);
+  BF_CASE(4, 2, 4);
+  BF_CASE(4, 4, 2);
+  BF_CASE(6, 3, 4);
+  BF_CASE(8, 4, 4);
 #undef BF_CASE
-  return set_error(BF_EUNSUPPORTED, "kalman filter: (n=%d, m=%d) is not compiled into the column-per-lane kernel",
-                   p->n, p->m);
+  return set_error(BF_EUNSUPPORTED,
+                   "kalman filter: (n=%d, m=%d, lanes=%d) is not compiled into the lane-group kernel", p->n, p->m,
+                   lanes);
 }
 
 }  // namespace bf

@@ -104,8 +104,11 @@ const char* bf_last_error(void);
 /* Number of visible gfx950 devices (0 if none / HIP unavailable). */
 int bf_device_count(void);
 
-/* Tuning / test hook.  "kf_emit_mode": -1 = choose the store path from the layout (default),
- * 0 = scalar strided stores, 1 = per-lane row stores, 2 = LDS time-transpose (reference layout). */
+/* Tuning / test hooks.
+ *   "kf_emit_mode": -1 = choose the store path from the layout (default), 0 = strided dword
+ *                   stores, 2 = LDS time-transpose (contiguous reference layout only).
+ *   "kf_lanes":     lanes that cooperate on one trajectory (0 = default for the dimensions;
+ *                   otherwise one of the compiled powers of two, e.g. 1, 2 or 4 at n = 4). */
 int bf_set_option(const char* name, int value);
 
 /* Batched Kalman filter: B independent trajectories, one component each (K = 1), T steps.

@@ -17,7 +17,7 @@ params = bfa.ParamsNLSSM(a["m0"], a["P0"], nl.linear_dynamics(a["A"], a["G"]), a
 dev = torch.device("cuda")
 y = torch.randn((B, T, 2), device=dev); init = torch.zeros((B, 4), device=dev)
 lib = _lib.require_gpu()
-lib.bf_set_option(b"kf_emit_mode", M); lib.bf_set_option(b"kf_kernel", K)
+lib.bf_set_option(b"kf_emit_mode", M); lib.bf_set_option(b"kf_lanes", K)
 post = bfa.kalman_filter(params, y, initial_means=init, layout=L, fields=F, return_carry=True)
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

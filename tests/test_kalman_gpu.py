@@ -11,30 +11,31 @@ TOL = 1e-5
 FIELDS = ("weights", "means", "covariances", "predicted_means", "predicted_covariances")
 
 
-def _run(a, ys, init, layout, mode=-1, kernel=0, **kw):
+def _run(a, ys, init, layout, mode=-1, lanes=0, **kw):
     import bayesianfiltering_amd as bfa
     from bayesianfiltering_amd import _lib
     lib = _lib.require_gpu()
     _lib.check(lib.bf_set_option(b"kf_emit_mode", mode))
-    _lib.check(lib.bf_set_option(b"kf_kernel", kernel))
+    _lib.check(lib.bf_set_option(b"kf_lanes", lanes))
     try:
         return bfa.kalman_filter(cm.product_params(a), ys, initial_means=init, layout=layout, **kw)
     finally:
         lib.bf_set_option(b"kf_emit_mode", -1)
-        lib.bf_set_option(b"kf_kernel", 0)
+        lib.bf_set_option(b"kf_lanes", 0)
 
 
-# kernel 0 = column-per-lane (shipping default), kernel 1 = lane-per-chain baseline
-@pytest.mark.parametrize("kernel,layout,mode", [(0, "reference", 2), (0, "reference", 0), (0, "batch_inner", -1),
-                                                (1, "reference", 2), (1, "reference", 1), (1, "batch_inner", -1)])
-def test_cv_model_matches_oracle(kernel, layout, mode):
+# lanes = lanes cooperating on one trajectory (0 = shipping default); mode 2 = LDS-staged stores,
+# mode 0 = strided stores
+@pytest.mark.parametrize("lanes", [0, 1, 2, 4])
+@pytest.mark.parametrize("layout,mode", [("reference", 2), ("reference", 0), ("batch_inner", -1)])
+def test_cv_model_matches_oracle(lanes, layout, mode):
     a = cm.cv_model_arrays()
-    # ragged last wave (130 = 2*64 + 2); T not a multiple of the staging depth for the shipping kernel
-    B, T = 130, (72 if kernel == 0 else 64)
+    # ragged last wave (130 = 2*64 + 2); T a multiple of 4 (aligned rows) but not of the staging depth
+    B, T = 130, 72
     ys = cm.simulate_batch(a, B, T, seed=1)
     init = np.tile(a["m0"], (B, 1)) + np.random.default_rng(2).normal(size=(B, 4)).astype(np.float32)
     ref = cm.oracle_kalman_batch(a, ys, init)
-    post, ll = _run(a, ys, init, layout, mode, kernel, return_loglik=True)
+    post, ll = _run(a, ys, init, layout, mode, lanes, return_loglik=True)
     for k in FIELDS:
         got = getattr(post, k).cpu().numpy()
         assert got.shape == ref[k].shape
