@@ -78,6 +78,22 @@ def cpu_baseline(a, T, target_s=12.0):
                       f"all five streams, {dt:.1f} s"}
 
 
+def pmc_traffic(B, T, layout):
+    """HBM bytes per launch of the scan kernel from the committed rocprofv3 PMC passes
+    (profiles/*_summary.json: WRITE_SIZE and FETCH_SIZE collected in separate runs of the same
+    launch, in KiB).  WRITE_SIZE is exact for 16-byte-per-lane stores; FETCH_SIZE is taken as
+    reported (the reads here are 4-byte LDS-DMA loads, for which the gfx950 half-count of wide
+    loads is not calibrated -- reads are 5 % of the traffic).  None if no matching profile."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_%s_summary.json" % layout)
+    if not (os.path.exists(path) and B == 65536 and T == 10000):
+        return None
+    try:
+        pmc = json.load(open(path)).get("pmc", {})
+        return (pmc["WRITE_SIZE"]["mean_per_dispatch"] + pmc["FETCH_SIZE"]["mean_per_dispatch"]) * 1024.0
+    except (KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,6 +177,7 @@ def main():
     if rank == 0:
         bytes_per_step = int(lib.bf_bytes_per_step(n, m, 1, None))      # 4m + 4(1 + 2n + 2n^2) = 172
         achieved = bytes_per_step * B * T / (kernel_ms * 1e-3) / 1e9
+        traffic = pmc_traffic(B, T, args.layout)
         value = world * B * T * args.steps / elapsed
         line = {
             "metric": "filter timesteps/sec (batch x T)", "value": value, "unit": "timesteps/s",
@@ -172,8 +189,8 @@ def main():
                        "batch_per_gpu": B, "T": T, "state_dim": n, "obs_dim": m,
                        "parallelism": f"batch-sharded x{world}" + (" + RCCL all-gather of summaries" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "kf_scan_small_kernel<4,2>", "kernel_ms": kernel_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "kf_scan_group_kernel<n=4,m=2>", "kernel_ms": kernel_ms,
                          "bytes_per_step": bytes_per_step},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,83 @@
+"""The C-ABI library loads, exports every symbol include/bayesfilt.h declares, and the product
+fails loudly (never falls back to a CPU path) when no MI355X is present."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "bayesfilt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_entry_points():
+    names = _declared_functions()
+    for required in ("bf_version", "bf_last_error", "bf_device_count", "bf_kalman_filter_f32", "bf_bytes_per_step"):
+        assert required in names
+
+
+def test_library_exports_every_declared_symbol():
+    from bayesianfiltering_amd import _lib
+    lib = _lib.load()
+    for name in _declared_functions():
+        assert hasattr(lib, name), f"{name} declared in include/bayesfilt.h but not exported"
+        assert name in _lib.SYMBOLS, f"{name} has no ctypes prototype in _lib.SYMBOLS"
+    assert lib.bf_version() >= 100
+
+
+def test_bytes_per_step_formula():
+    from bayesianfiltering_amd import _lib
+    lib = _lib.load()
+    assert lib.bf_bytes_per_step(4, 2, 1, None) == 172          # 4m + 4K(1 + 2n + 2n^2)
+    assert lib.bf_bytes_per_step(8, 4, 32, None) == 18576
+    assert lib.bf_bytes_per_step(64, 32, 1, None) == 33412
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    from bayesianfiltering_amd import _lib
+    assert C.sizeof(_lib.bf_stream) == 40 and C.sizeof(_lib.bf_cstream) == 40
+    assert C.sizeof(_lib.bf_out_desc) == 240 and C.sizeof(_lib.bf_carry) == 48
+    assert C.sizeof(_lib.bf_lgssm) == 16 + 8 * 8 + 8
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_no_gpu_means_loud_failure_not_fallback():
+    import bayesianfiltering_amd as bfa
+    from bayesianfiltering_amd import _lib
+    from tests import common as cm
+    a = cm.cv_model_arrays()
+    with pytest.raises(_lib.BayesFiltError) as e:
+        bfa.kalman_filter(cm.product_params(a), np.zeros((2, 8, 2), np.float32))
+    assert e.value.code == _lib.BF_ENOGPU
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "bayesianfiltering_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "oracle/" not in src or f.endswith(".md"), f
+
+
+def test_registry_functions_match_oracle_models():
+    """Host-callable registry functions (bayesianfiltering_amd.nonlinearities) agree with the oracle's models."""
+    from bayesianfiltering_amd import nonlinearities as nl
+    from oracle import models as om
+    rng = np.random.default_rng(0)
+    pairs = [(nl.lorenz96(8), om.Lorenz96(8), 8, 8, 0.0), (nl.lorenz96(8, mode="as_written"), om.Lorenz96(8, mode="as_written"), 8, 8, 0.0),
+             (nl.lorenz63(), om.Lorenz63(), 3, 3, 0.0), (nl.maneuver_bot(), om.ManeuverBOT(), 4, 2, 1.0),
+             (nl.maneuver_bot(), om.ManeuverBOT(), 4, 2, 2.0), (nl.bearing_range(), om.BearingRange(), 4, 2, 0.0),
+             (nl.sine(3), om.Sine(3), 3, 3, 0.0), (nl.quadratic(3, 0.5), om.Quadratic(3, 0.5), 3, 1, 0.0),
+             (nl.growth(), om.Growth(), 1, 1, 0.3), (nl.stoch_vol(3), om.StochVol(3), 3, 3, 1.0),
+             (nl.pick_even(8), om.PickEven(8), 8, 4, 0.0)]
+    for f, g, n, nw, u in pairs:
+        x = rng.normal(size=n).astype(np.float32); w = (0.1 * rng.normal(size=nw)).astype(np.float32)
+        assert np.allclose(f(x, w, np.float32([u])), g.value(x, w, np.float32([u])), rtol=1e-5, atol=1e-6), f.name
