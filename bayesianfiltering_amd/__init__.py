@@ -4,8 +4,9 @@ bootstrap particle filters) behind the call surface of the reference package ``g
 from .models import ParamsNLSSM, ParamsBPF
 from .containers import GaussianComponent, GaussianSum
 from .inference import (PosteriorGaussianSumFiltered, gaussian_sum_filter, kalman_filter, FilterCarry,
-                        FULL5, FILTERED)
+                        FULL5, FILTERED, PRNGKey, sample_initial_component_means)
 from . import nonlinearities, utils
 
 __all__ = ["ParamsNLSSM", "ParamsBPF", "GaussianComponent", "GaussianSum", "PosteriorGaussianSumFiltered",
-           "gaussian_sum_filter", "kalman_filter", "FilterCarry", "FULL5", "FILTERED", "nonlinearities", "utils"]
+           "gaussian_sum_filter", "kalman_filter", "FilterCarry", "FULL5", "FILTERED", "PRNGKey",
+           "sample_initial_component_means", "nonlinearities", "utils"]

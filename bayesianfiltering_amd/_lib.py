@@ -46,6 +46,12 @@ class bf_lgssm(C.Structure):
                 ("Q_steps", C.c_int32), ("R_steps", C.c_int32)]
 
 
+class bf_model(C.Structure):
+    _fields_ = [("dyn_id", C.c_int32), ("emi_id", C.c_int32), ("n", C.c_int32), ("dq", C.c_int32), ("m", C.c_int32),
+                ("dr", C.c_int32), ("dyn_theta", _FP), ("n_dyn_theta", C.c_int32), ("emi_theta", _FP),
+                ("n_emi_theta", C.c_int32), ("q0", _FP), ("r0", _FP), ("Q", _FP), ("R", _FP)]
+
+
 # every symbol include/bayesfilt.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "bf_version": (C.c_int, []),
@@ -53,6 +59,10 @@ SYMBOLS = {
     "bf_device_count": (C.c_int, []),
     "bf_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "bf_bytes_per_step": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(bf_out_desc)]),
+    "bf_gsf_ekf_f32": (C.c_int, [C.POINTER(bf_model), C.POINTER(bf_cstream), C.POINTER(bf_cstream), C.c_int64, C.c_int64,
+                                 C.c_int32, C.POINTER(bf_carry), C.POINTER(bf_out_desc), C.c_void_p]),
+    "bf_random_normal_f32": (C.c_int, [C.POINTER(C.c_uint32), C.c_int64, _FP]),
+    "bf_random_split": (C.c_int, [C.POINTER(C.c_uint32), C.c_int64, C.POINTER(C.c_uint32)]),
     "bf_kalman_filter_f32": (C.c_int, [C.POINTER(bf_lgssm), C.POINTER(bf_cstream), C.c_int64, C.c_int64,
                                        C.POINTER(bf_carry), C.POINTER(bf_out_desc), C.c_void_p]),
 }

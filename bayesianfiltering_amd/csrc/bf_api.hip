@@ -2,6 +2,7 @@
 // the kf_*/gsf_*/bpf_* translation units.
 #include <cstring>
 #include "bf_common.hpp"
+#include "bf_rng.hpp"
 
 namespace bf {
 
@@ -20,6 +21,9 @@ int set_error(int code, const char* fmt, ...) {
 
 int launch_kf_group(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
                     const bf_out_desc* out, hipStream_t stream, int force_mode, int lanes);
+
+int launch_gsf_ekf(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int K,
+                   const bf_carry* carry, const bf_out_desc* out, hipStream_t stream, int force_mode);
 
 static int g_kf_emit_mode = -1;  // -1 = choose from the layout
 static int g_kf_lanes = 0;       // 0 = default lanes per trajectory for the (n, m) pair
@@ -86,6 +90,35 @@ int bf_kalman_filter_f32(const bf_lgssm* model, const bf_cstream* y, int64_t B, 
   if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
   return bf::launch_kf_group(model, y, B, T, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode,
                              bf::g_kf_lanes);
+}
+
+int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream* u, int64_t B, int64_t T, int32_t K,
+                   const bf_carry* carry, const bf_out_desc* out, void* stream) {
+  if (!model || !y || !carry || !out) return bf::set_error(BF_EINVAL, "NULL argument");
+  if (B <= 0 || T <= 0 || K <= 0) return bf::set_error(BF_EINVAL, "B, T and K must be positive");
+  if (model->n <= 0 || model->m <= 0 || model->dq <= 0 || model->dr <= 0)
+    return bf::set_error(BF_EINVAL, "non-positive model dimension");
+  if (!model->Q || !model->R) return bf::set_error(BF_EINVAL, "Q and R are required");
+  if (!y->ptr) return bf::set_error(BF_EINVAL, "observations pointer is NULL");
+  if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
+  return bf::launch_gsf_ekf(model, y, u, B, T, K, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode);
+}
+
+int bf_random_normal_f32(const uint32_t key[2], int64_t count, float* host_out) {
+  if (!key || !host_out || count < 0 || count > 0x7fffffff) return bf::set_error(BF_EINVAL, "bad argument");
+  for (int64_t i = 0; i < count; ++i)
+    host_out[i] = bf::bits_to_normal(bf::threefry_bits(key[0], key[1], (uint32_t)i, (uint32_t)count));
+  return BF_OK;
+}
+
+int bf_random_split(const uint32_t key[2], int64_t num, uint32_t* host_out) {
+  if (!key || !host_out || num <= 0 || num > 0x3fffffff) return bf::set_error(BF_EINVAL, "bad argument");
+  for (int64_t i = 0; i < num; ++i) {
+    const bf::U32x2 k = bf::threefry_split(key[0], key[1], (uint32_t)i, (uint32_t)num);
+    host_out[2 * i] = k.x;
+    host_out[2 * i + 1] = k.y;
+  }
+  return BF_OK;
 }
 
 }  // extern "C"

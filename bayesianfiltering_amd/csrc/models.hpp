@@ -1,0 +1,184 @@
+// Device-side model registry: value and analytic Jacobians of the dynamics / emission functions
+// the reference's scripts pass as Python callables (gaussfiltax/models.py:46-49) and
+// differentiates with jacfwd (gaussfiltax/inference.py:328-329).  fn ids match
+// bayesianfiltering_amd/nonlinearities.py.  Sources of the formulas:
+//   linear                     docs/experiments/adaptive_experiment.py:59-64
+//   Lorenz-96 (f96 / g96)      gaussfiltax/nonlinearities.py:37-50 (mode 1 = matrix powers, 0 = as written)
+//   Lorenz-63                  docs/experiments/exp_lorentz63.py:37-41
+//   manoeuvring target + bearing/range   docs/experiments/BOT_Experiment_script.py:31-44
+//   sine / quadratic / growth  docs/notebooks/Experiment_TSP_2023.ipynb cell 2 (f1, g1, f3)
+//   stochastic volatility      docs/experiments/adaptive_experiment.py:51-54 (glmsv)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kf_math.hpp"
+
+namespace bf {
+
+enum { DYN_LINEAR = 0, DYN_LORENZ96 = 1, DYN_LORENZ63 = 2, DYN_MANEUVER_BOT = 3, DYN_SINE = 4, DYN_GROWTH = 5 };
+enum { EMI_LINEAR = 0, EMI_BEARING_RANGE = 1, EMI_QUADRATIC = 2, EMI_STOCH_VOL = 3 };
+
+// Everything the kernels need about one model; passed by value as a kernel argument.
+template <int N, int M>
+struct EkfModel {
+  int dyn_id, emi_id;
+  float dth[8];      // dynamics scalars (alpha, beta, gamma, dt, mode | sigma, rho, beta, dt | dt, acc | w0)
+  float eth[8];      // emission scalars (c | sigma, beta, c)
+  float A[N * N];    // linear dynamics matrix
+  float Hm[M * N];   // linear emission matrix
+  float GQG[N * N];  // F_q Q F_q^T (F_q is constant for every registry dynamics function)
+  float DRD[M * M];  // H_r R H_r^T when H_r is constant
+  float Gq0[N];      // F_q q0 (additive noise bias)
+  float Dr0[M];      // H_r r0 when H_r is constant
+  float R[M * M];    // emission noise covariance (state-dependent H_r: stochastic volatility)
+  float r0[M];
+};
+
+// f(x, q0, u) and F_x = df/dx at x (dense, row-major).  The noise bias enters additively for
+// every registry function: fx = g(x, u) + F_q q0.
+template <int N, int M>
+__device__ __forceinline__ void dyn_linearize(const EkfModel<N, M>& p, const float* x, float u0, float* F, float* fx) {
+  BF_UNROLL for (int i = 0; i < N * N; ++i) F[i] = 0.f;
+  switch (p.dyn_id) {
+    case DYN_LINEAR: {
+      BF_UNROLL for (int i = 0; i < N * N; ++i) F[i] = p.A[i];
+      mv<N, N>(p.A, x, fx);
+    } break;
+    case DYN_LORENZ96: {
+      const float alpha = p.dth[0], beta = p.dth[1], gamma = p.dth[2], dt = p.dth[3];
+      const bool mp = p.dth[4] != 0.f;
+      BF_UNROLL for (int i = 0; i < N; ++i) {
+        const int im1 = (i + N - 1) % N, ip1 = (i + 1) % N, im2 = (i + 2 * N - 2) % N;
+        const float ax = x[im1];
+        const float bx = mp ? (x[ip1] - x[im2]) : 0.f;
+        fx[i] = x[i] + dt * (alpha * (ax * bx) - beta * x[i] + gamma);
+        F[i * N + i] += 1.0f - dt * beta;
+        if (mp) {
+          F[i * N + im1] += dt * alpha * bx;
+          F[i * N + ip1] += dt * alpha * ax;
+          F[i * N + im2] += -dt * alpha * ax;
+        }
+      }
+    } break;
+    case DYN_LORENZ63: {
+      if constexpr (N == 3) {
+        const float s = p.dth[0], r = p.dth[1], b = p.dth[2], dt = p.dth[3];
+        fx[0] = dt * s * (x[1] - x[0]) + x[0];
+        fx[1] = dt * (x[0] * r - x[1] - x[0] * x[2]) + x[1];
+        fx[2] = dt * (x[0] * x[1] - b * x[2]) + x[2];
+        F[0] = 1.f - dt * s; F[1] = dt * s;     F[2] = 0.f;
+        F[3] = dt * (r - x[2]); F[4] = 1.f - dt; F[5] = -dt * x[0];
+        F[6] = dt * x[1];       F[7] = dt * x[0]; F[8] = 1.f - dt * b;
+      }
+    } break;
+    case DYN_MANEUVER_BOT: {
+      if constexpr (N == 4) {
+        const float dt = p.dth[0], acc = p.dth[1];
+        const float c0 = 0.5f * (u0 - 1.f) * (u0 - 2.f), c1 = -u0 * (u0 - 2.f), c2 = 0.5f * u0 * (u0 - 1.f);
+        // constant-velocity part
+        float Mx[16] = {c0, c0 * dt, 0, 0, 0, c0, 0, 0, 0, 0, c0, c0 * dt, 0, 0, 0, c0};
+        float J[16];
+        BF_UNROLL for (int i = 0; i < 16; ++i) J[i] = 0.f;
+        const float s2 = x[1] * x[1] + x[3] * x[3];
+        const float nrm = sqrtf(s2);
+        BF_UNROLL for (int sgn = 0; sgn < 2; ++sgn) {
+          const float cc = sgn == 0 ? c1 : c2;
+          const float a = sgn == 0 ? acc : -acc;
+          const float om = 0.1f * a / nrm;
+          const float sn = sinf(dt * om), cs = cosf(dt * om);
+          const float so = sn / om, co = (1.f - cs) / om;
+          const float Fm[16] = {1, so, 0, -co, 0, cs, 0, -sn, 0, co, 1, so, 0, sn, 0, cs};
+          const float dso = (dt * cs * om - sn) / (om * om);          // d(sn/om)/d om
+          const float dco = (dt * sn * om - (1.f - cs)) / (om * om);  // d((1-cs)/om)/d om
+          const float dF[16] = {0, dso, 0, -dco, 0, -dt * sn, 0, -dt * cs, 0, dco, 0, dso, 0, dt * cs, 0, -dt * sn};
+          const float dom1 = -om * x[1] / s2, dom3 = -om * x[3] / s2;
+          BF_UNROLL for (int i = 0; i < 4; ++i) {
+            float dfx = 0.f;
+            BF_UNROLL for (int k = 0; k < 4; ++k) {
+              Mx[i * 4 + k] += cc * Fm[i * 4 + k];
+              dfx = fmaf(dF[i * 4 + k], x[k], dfx);
+            }
+            J[i * 4 + 1] += cc * dfx * dom1;
+            J[i * 4 + 3] += cc * dfx * dom3;
+          }
+        }
+        BF_UNROLL for (int i = 0; i < 4; ++i) {
+          float s = 0.f;
+          BF_UNROLL for (int k = 0; k < 4; ++k) {
+            s = fmaf(Mx[i * 4 + k], x[k], s);
+            F[i * 4 + k] = Mx[i * 4 + k] + J[i * 4 + k];
+          }
+          fx[i] = s;
+        }
+      }
+    } break;
+    case DYN_SINE: {
+      const float w0 = p.dth[0];
+      BF_UNROLL for (int i = 0; i < N; ++i) {
+        fx[i] = sinf(w0 * x[i]);
+        F[i * N + i] = w0 * cosf(w0 * x[i]);
+      }
+    } break;
+    case DYN_GROWTH: {
+      if constexpr (N == 1) {
+        const float d = 1.f + x[0] * x[0];
+        fx[0] = x[0] / 2.0f + 25.0f * x[0] / d + u0;
+        F[0] = 0.5f + 25.0f * (1.f - x[0] * x[0]) / (d * d);
+      }
+    } break;
+    default: break;
+  }
+  BF_UNROLL for (int i = 0; i < N; ++i) fx[i] += p.Gq0[i];
+}
+
+// h(x, r0, u), H_x = dh/dx at x, and HrRHr = H_r R H_r^T.
+template <int N, int M>
+__device__ __forceinline__ void emi_linearize(const EkfModel<N, M>& p, const float* x, float u0, float* H, float* hx,
+                                              float* HrRHr) {
+  BF_UNROLL for (int i = 0; i < M * N; ++i) H[i] = 0.f;
+  BF_UNROLL for (int i = 0; i < M * M; ++i) HrRHr[i] = p.DRD[i];
+  switch (p.emi_id) {
+    case EMI_LINEAR: {
+      BF_UNROLL for (int i = 0; i < M * N; ++i) H[i] = p.Hm[i];
+      mv<M, N>(p.Hm, x, hx);
+      BF_UNROLL for (int a = 0; a < M; ++a) hx[a] += p.Dr0[a];
+    } break;
+    case EMI_BEARING_RANGE: {
+      if constexpr (N == 4 && M == 2) {
+        const float d2 = x[0] * x[0] + x[2] * x[2];
+        const float d = sqrtf(d2);
+        hx[0] = atan2f(x[2], x[0]) + p.Dr0[0];
+        hx[1] = d + p.Dr0[1];
+        H[0] = -x[2] / d2; H[2] = x[0] / d2;
+        H[4] = x[0] / d;   H[6] = x[2] / d;
+      }
+    } break;
+    case EMI_QUADRATIC: {
+      if constexpr (M == 1) {
+        const float c = p.eth[0];
+        float s = 0.f;
+        BF_UNROLL for (int i = 0; i < N; ++i) {
+          s = fmaf(x[i], x[i], s);
+          H[i] = 2.0f * c * x[i];
+        }
+        hx[0] = c * s + p.Dr0[0];
+      }
+    } break;
+    case EMI_STOCH_VOL: {
+      if constexpr (M == N) {
+        const float sigma = p.eth[0], beta = p.eth[1], c = p.eth[2];
+        float hr[M];
+        BF_UNROLL for (int i = 0; i < N; ++i) {
+          const float e = u0 * beta * expf(x[i] / sigma);
+          hx[i] = e * p.r0[i] + (1.f - u0) * (c * x[i] + p.r0[i]);
+          H[i * N + i] = e * p.r0[i] / sigma + (1.f - u0) * c;
+          hr[i] = e + (1.f - u0);
+        }
+        BF_UNROLL for (int a = 0; a < M; ++a) BF_UNROLL for (int b = 0; b < M; ++b)
+            HrRHr[a * M + b] = (hr[a] * p.R[a * M + b]) * hr[b];
+      }
+    } break;
+    default: break;
+  }
+}
+
+}  // namespace bf

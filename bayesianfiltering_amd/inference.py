@@ -227,17 +227,163 @@ def kalman_filter(params, emissions, *, initial_means=None, initial_covariances=
     return (post, *extras) if extras else post
 
 
+class _Model:
+    """Host-side build of bf_model from a ParamsNLSSM / ParamsBPF holding registry functions."""
+
+    def __init__(self, params):
+        f = require_device_function(params.dynamics_function, "dynamics", "params.dynamics_function")
+        h = require_device_function(params.emission_function, "emission", "params.emission_function")
+        self.n, self.dq, self.m, self.dr = f.out_dim, f.noise_dim, h.out_dim, h.noise_dim
+        if f.in_dim != self.n or h.in_dim != self.n:
+            raise ValueError("dynamics / emission functions do not match the state dimension")
+        self.dyn_theta = np.ascontiguousarray(f.theta if f.theta.size else np.zeros(1, F32))
+        self.emi_theta = np.ascontiguousarray(h.theta if h.theta.size else np.zeros(1, F32))
+        self.q0 = _host_f32(params.dynamics_noise_bias).reshape(self.dq)
+        self.r0 = _host_f32(params.emission_noise_bias).reshape(self.dr)
+        self.Q = _host_f32(params.dynamics_noise_covariance)
+        self.R = _host_f32(params.emission_noise_covariance)
+        if self.Q.shape != (self.dq, self.dq) or self.R.shape != (self.dr, self.dr):
+            raise _lib.BayesFiltError(_lib.BF_EUNSUPPORTED,
+                                      "time-varying Q/R are only supported on the linear Kalman path (kalman_filter)")
+        c = _lib.bf_model()
+        c.dyn_id, c.emi_id, c.n, c.dq, c.m, c.dr = f.fn_id, h.fn_id, self.n, self.dq, self.m, self.dr
+        c.dyn_theta, c.n_dyn_theta = _fp(self.dyn_theta), int(f.theta.size)
+        c.emi_theta, c.n_emi_theta = _fp(self.emi_theta), int(h.theta.size)
+        c.q0, c.r0, c.Q, c.R = _fp(self.q0), _fp(self.r0), _fp(self.Q), _fp(self.R)
+        self.c = c
+
+
+def PRNGKey(seed: int):
+    """jax.random.PRNGKey for the default threefry PRNG: uint32 [hi32(seed), lo32(seed)]."""
+    seed = int(seed)
+    return np.array([(seed >> 32) & 0xFFFFFFFF, seed & 0xFFFFFFFF], dtype=np.uint32)
+
+
+def _random_normal(key, count):
+    lib = _lib.load()
+    key = np.ascontiguousarray(np.asarray(key, dtype=np.uint32).reshape(2))
+    out = np.empty(count, dtype=F32)
+    _lib.check(lib.bf_random_normal_f32(key.ctypes.data_as(C.POINTER(C.c_uint32)), count, _fp(out)))
+    return out
+
+
+def sample_initial_component_means(params, num_components, key=None):
+    """The draw of gaussfiltax/inference.py:367: ``MVN(m0, P0).sample(K, PRNGKey(0))`` restated as
+    ``m0 + chol(P0) @ normal(key, (K, n))[k]`` (tfp's sampler is third-party; best-effort stream)."""
+    key = PRNGKey(0) if key is None else key
+    m0 = _host_f32(params.initial_mean).reshape(-1)
+    L = np.linalg.cholesky(_host_f32(params.initial_covariance).astype(np.float64)).astype(F32)
+    z = _random_normal(key, num_components * m0.size).reshape(num_components, m0.size)
+    return (m0[None, :] + z @ L.T).astype(F32)
+
+
+def _alloc_outputs(B, K, T, n, fields, layout, out, return_loglik, device):
+    ev = {"weights": (), "means": (n,), "covariances": (n, n), "predicted_means": (n,), "predicted_covariances": (n, n)}
+    bufs = {}
+    for name in FULL5:
+        if name in fields:
+            reuse = getattr(out, name, None) if out is not None else None
+            if reuse is not None:
+                if tuple(reuse.shape) != (B, K, T) + ev[name]:
+                    raise ValueError(f"out.{name} has shape {tuple(reuse.shape)}, expected {(B, K, T) + ev[name]}")
+                bufs[name] = reuse
+            else:
+                bufs[name] = _alloc_stream((B, K, T), ev[name], layout, device)
+        else:
+            bufs[name] = None
+    ll = _alloc_stream((B, K, T), (), layout, device) if return_loglik else None
+    od = _lib.bf_out_desc()
+    od.weights = _stream_desc(bufs["weights"], 0)
+    od.means = _stream_desc(bufs["means"], 1)
+    od.covs = _stream_desc(bufs["covariances"], 2)
+    od.pred_means = _stream_desc(bufs["predicted_means"], 1)
+    od.pred_covs = _stream_desc(bufs["predicted_covariances"], 2)
+    od.loglik = _stream_desc(ll, 0)
+    return bufs, ll, od
+
+
 def gaussian_sum_filter(params, emissions, num_components: int = 1, num_iter: int = 1, inputs=None, *,
-                        initial_means=None, **kw):
+                        initial_means=None, initial_covariances=None, carry=None,
+                        fields: Sequence[str] = FULL5, layout: str = "reference", out=None,
+                        return_loglik: bool = False, return_carry: bool = False, device="cuda"):
     """Gaussian-sum filter (bank of K extended Kalman filters + weight update),
-    gaussfiltax/inference.py:303-377.  ``num_iter`` is accepted and ignored exactly as in the
-    reference (:307, never read).  ``initial_means`` (K, n) / (B, K, n) overrides the
-    reference's fixed ``MVN(m0, P0).sample(K, PRNGKey(0))`` draw (:367).
+    gaussfiltax/inference.py:303-377, on the HIP engine.
+
+    Same positional signature as the reference.  ``num_iter`` is accepted and ignored exactly as
+    there (:307, never read).  ``emissions``: (T, m) -> arrays shaped (K, T, ...) like the
+    reference, or (B, T, m) -> (B, K, T, ...).  ``inputs``: None (zeros((T,1)), :23), (T,), (T, d)
+    or (B, T, d); the registry functions use ``u[0]``.  ``initial_means`` (K, n) / (B, K, n)
+    overrides the reference's fixed ``MVN(m0, P0).sample(K, PRNGKey(0))`` draw (:367).
+    ``carry`` / ``return_carry`` continue a scan in chunks (the carry of :334,356).
     """
-    f = require_device_function(params.dynamics_function, "dynamics", "params.dynamics_function")
-    h = require_device_function(params.emission_function, "emission", "params.emission_function")
-    if num_components == 1 and f.fn_id == DYN_LINEAR and h.fn_id == EMI_LINEAR and inputs is None \
-            and initial_means is not None:
-        return kalman_filter(params, emissions, initial_means=initial_means, **kw)
-    raise _lib.BayesFiltError(_lib.BF_EUNSUPPORTED,
-                              "gaussian_sum_filter: the nonlinear / multi-component HIP kernel is not built yet")
+    torch = _torch()
+    lib = _lib.require_gpu()
+    K = int(num_components)
+    if K < 1:
+        raise ValueError("num_components must be >= 1")
+    mdl = _Model(params)
+    n, m = mdl.n, mdl.m
+    y = _dev_f32(emissions, device)
+    squeeze = y.dim() == 2
+    if squeeze:
+        y = y.unsqueeze(0)
+    if y.dim() != 3 or y.shape[2] != m:
+        raise ValueError(f"emissions must be (T,{m}) or (B,T,{m}); got {tuple(y.shape)}")
+    B, T = int(y.shape[0]), int(y.shape[1])
+    if T == 0 or B == 0:
+        raise ValueError("empty emissions")
+
+    if carry is not None:
+        w_in, m_in, P_in = (_dev_f32(v, device).contiguous() for v in carry)
+    else:
+        w_in = None
+        im = sample_initial_component_means(params, K) if initial_means is None else initial_means
+        m_in = _dev_f32(im, device).reshape(-1, K, n)
+        m_in = m_in.expand(B, K, n).contiguous() if m_in.shape[0] == 1 else m_in.contiguous()
+        P0 = params.initial_covariance if initial_covariances is None else initial_covariances
+        P_in = _dev_f32(P0, device)
+        if P_in.dim() == 2:
+            P_in = P_in.reshape(1, 1, n, n).expand(B, K, n, n).contiguous()
+        else:
+            P_in = P_in.reshape(-1, K, n, n)
+            P_in = P_in.expand(B, K, n, n).contiguous() if P_in.shape[0] == 1 else P_in.contiguous()
+    if tuple(m_in.shape) != (B, K, n) or tuple(P_in.shape) != (B, K, n, n):
+        raise ValueError("initial means / covariances do not match (B, K, n) / (B, K, n, n)")
+
+    bufs, ll, od = _alloc_outputs(B, K, T, n, fields, layout, out, return_loglik, y.device)
+
+    yd = _lib.bf_cstream()
+    yd.ptr, yd.sB, yd.sK, yd.sT, yd.sE = y.data_ptr(), y.stride(0), 0, y.stride(1), y.stride(2)
+    ud = _lib.bf_cstream()
+    u_keep = None
+    if inputs is not None:
+        u_keep = _dev_f32(inputs, device)
+        if u_keep.dim() == 1:
+            u_keep = u_keep.reshape(1, T, 1)
+        elif u_keep.dim() == 2:
+            u_keep = u_keep.reshape(1, T, -1)
+        if u_keep.shape[1] != T or u_keep.shape[0] not in (1, B):
+            raise ValueError(f"inputs must be (T,), (T,d) or (B,T,d); got {tuple(u_keep.shape)}")
+        ud.ptr, ud.sB, ud.sT, ud.sE = u_keep.data_ptr(), (u_keep.stride(0) if u_keep.shape[0] == B else 0), u_keep.stride(1), 1
+
+    cr = _lib.bf_carry()
+    cr.w_in = w_in.data_ptr() if w_in is not None else None
+    cr.m_in, cr.P_in = m_in.data_ptr(), P_in.data_ptr()
+    c_out = None
+    if return_carry:
+        c_out = FilterCarry(torch.empty((B, K), dtype=torch.float32, device=y.device),
+                            torch.empty((B, K, n), dtype=torch.float32, device=y.device),
+                            torch.empty((B, K, n, n), dtype=torch.float32, device=y.device))
+        cr.w_out, cr.m_out, cr.P_out = (t.data_ptr() for t in c_out)
+
+    stream = torch.cuda.current_stream(y.device).cuda_stream
+    _lib.check(lib.bf_gsf_ekf_f32(C.byref(mdl.c), C.byref(yd), C.byref(ud), B, T, K, C.byref(cr), C.byref(od),
+                                  C.c_void_p(stream)))
+
+    post = PosteriorGaussianSumFiltered(**{k: (v[0] if (squeeze and v is not None) else v) for k, v in bufs.items()})
+    extras = []
+    if return_loglik:
+        extras.append(ll[0] if squeeze else ll)
+    if return_carry:
+        extras.append(c_out)
+    return (post, *extras) if extras else post

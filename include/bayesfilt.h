@@ -118,6 +118,37 @@ int bf_set_option(const char* name, int value);
 int bf_kalman_filter_f32(const bf_lgssm* model, const bf_cstream* y, int64_t B, int64_t T,
                          const bf_carry* carry, const bf_out_desc* out, void* stream);
 
+/* A state-space model built from the function registry (the device-side replacement of the
+ * Python callables f(x,q,u), h(x,r,u) of gaussfiltax/models.py:46-49; ids and theta layouts:
+ * bayesianfiltering_amd/nonlinearities.py, formulas: csrc/models.hpp).  HOST pointers. */
+typedef struct bf_model {
+  int32_t dyn_id, emi_id;
+  int32_t n, dq, m, dr;
+  const float* dyn_theta;
+  int32_t n_dyn_theta;
+  const float* emi_theta;
+  int32_t n_emi_theta;
+  const float *q0, *r0; /* noise biases, NULL = zeros                */
+  const float *Q, *R;   /* noise covariances [dq,dq], [dr,dr]        */
+} bf_model;
+
+/* Batched Gaussian-sum filter (bank of K extended Kalman filters + weight update): replaces the
+ * lax.scan of gaussian_sum_filter (inference.py:333-371) for K >= 1 and nonlinear f, h.
+ * u: optional inputs, element (b, t) at u->ptr[b*sB + t*sT] (only u[0] is used by the registry
+ * functions); NULL or u->ptr == NULL means zeros((T,1)) (inference.py:23).  The carry holds
+ * the K initial component means / covariances per trajectory ([B][K][n], [B][K][n][n]) and,
+ * optionally, weights [B][K] (NULL = 1/K, inference.py:369).  K rounded up to a power of two
+ * times the lanes per chain must not exceed 256. */
+int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream* u, int64_t B, int64_t T, int32_t K,
+                   const bf_carry* carry, const bf_out_desc* out, void* stream);
+
+/* jax.random.normal(key, (count,)) for the default threefry PRNG, written to a HOST buffer
+ * (used for the reference's fixed `MVN(m0, P0).sample(K, PRNGKey(0))` draw of the initial
+ * component means, inference.py:367: m0 + chol(P0) z).  key = {hi, lo} as jr.PRNGKey. */
+int bf_random_normal_f32(const uint32_t key[2], int64_t count, float* host_out);
+/* jax.random.split(key, num) -> num keys (2 words each) in a HOST buffer. */
+int bf_random_split(const uint32_t key[2], int64_t num, uint32_t* host_out);
+
 /* Bytes one (trajectory, timestep) moves for the streams enabled in `out`: the algorithmic
  * traffic figure of SURVEY.md 8(d)  (4m + 4K(1 + 2n + 2n^2) for all five streams). */
 int64_t bf_bytes_per_step(int32_t n, int32_t m, int32_t K, const bf_out_desc* out);

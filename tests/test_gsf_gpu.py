@@ -1,0 +1,194 @@
+"""GPU parity of the Gaussian-sum / EKF kernel (bf_gsf_ekf_f32) against the NumPy oracle and the
+golden fixtures.  Tolerance: 1e-5 relative (north_star) on means / covariances; weights are
+compared absolutely (they are in [0, 1])."""
+import numpy as np
+import pytest
+
+from oracle import gaussfilt_oracle as go, models as om, threefry as otf
+from tests import common as cm
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+TOL = 1e-5
+FIELDS = ("means", "covariances", "predicted_means", "predicted_covariances")
+
+
+def _nl():
+    import bayesianfiltering_amd as bfa
+    return bfa, bfa.nonlinearities
+
+
+def _check(post, ref, ll=None, ref_ll=None, tol=TOL, wtol=2e-5):
+    for k in FIELDS:
+        got = getattr(post, k).cpu().numpy()
+        exp = getattr(ref, k) if hasattr(ref, "_fields") else ref[k]
+        assert got.shape == exp.shape, k
+        assert cm.rel_err(got, exp) < tol, (k, cm.rel_err(got, exp))
+    w = post.weights.cpu().numpy()
+    we = ref.weights if hasattr(ref, "_fields") else ref["weights"]
+    assert np.max(np.abs(w - we)) < wtol
+    if ll is not None:
+        assert cm.rel_err(ll.cpu().numpy(), ref_ll) < 3e-5
+
+
+def _mode(mode):
+    from bayesianfiltering_amd import _lib
+    lib = _lib.require_gpu()
+    _lib.check(lib.bf_set_option(b"kf_emit_mode", mode))
+
+
+@pytest.mark.parametrize("mode", [-1, 0])
+def test_golden_lorenz96(golden_dir, mode):
+    bfa, nl = _nl()
+    for lmode in ("matrix_power", "as_written"):
+        d = np.load(f"{golden_dir}/gsf_lorenz96_{lmode}_n8_K4_T32.npz")
+        p = bfa.ParamsNLSSM(np.zeros(8, F32), np.eye(8, dtype=F32), nl.lorenz96(8, mode=lmode), np.zeros(8, F32),
+                            1e-2 * np.eye(8, dtype=F32), nl.pick_even(8), np.zeros(4, F32), 1e-1 * np.eye(4, dtype=F32))
+        _mode(mode)
+        try:
+            post, ll = bfa.gaussian_sum_filter(p, d["emissions"], 4, 1, initial_means=d["initial_means"], return_loglik=True)
+        finally:
+            _mode(-1)
+        assert tuple(post.means.shape) == (4, 32, 8) and tuple(post.covariances.shape) == (4, 32, 8, 8)
+        _check(post, d, ll, d["loglik"])
+
+
+def test_golden_lorenz63(golden_dir):
+    bfa, nl = _nl()
+    d = np.load(f"{golden_dir}/gsf_lorenz63_K4_T32.npz")
+    p = bfa.ParamsNLSSM(np.array([0.0, 1.0, 1.05], F32), np.eye(3, dtype=F32), nl.lorenz63(), np.zeros(3, F32),
+                        0.1 * np.eye(3, dtype=F32), nl.quadratic(3, 0.05), np.zeros(1, F32), np.eye(1, dtype=F32))
+    post, ll = bfa.gaussian_sum_filter(p, d["emissions"], 4, 1, initial_means=d["initial_means"], return_loglik=True)
+    _check(post, d, ll, d["loglik"])
+
+
+def _oracle_batch(p, ys, K, init, inputs=None):
+    outs = {k: [] for k in ("weights",) + FIELDS}
+    for b in range(ys.shape[0]):
+        post = go.gaussian_sum_filter(p, ys[b], K, initial_means=init[b], inputs=None if inputs is None else inputs)
+        for k in outs:
+            outs[k].append(getattr(post, k))
+    return {k: np.stack(v) for k, v in outs.items()}
+
+
+def test_bot_with_inputs_nonpow2_components():
+    """Manoeuvring target (u in {0,1,2}) with bearing+range emissions, K = 5 (padded to 8), B = 3."""
+    bfa, nl = _nl()
+    rng = np.random.default_rng(0)
+    T, K, B = 24, 5, 3
+    mu0 = np.array([2.0, 0.3, 3.0, -0.2], F32)
+    S0 = np.diag([0.1, 0.005, 0.1, 0.01]).astype(F32)
+    Q, R = 1e-3 * np.eye(2, dtype=F32), np.diag([1e-3, 1e-2]).astype(F32)
+    inputs = np.array([1] * 8 + [0] * 8 + [2] * 8, F32)
+    po = go.ParamsNLSSM(mu0, S0, om.ManeuverBOT(), np.zeros(2, F32), Q, om.BearingRange(), np.zeros(2, F32), R)
+    pp = bfa.ParamsNLSSM(mu0, S0, nl.maneuver_bot(), np.zeros(2, F32), Q, nl.bearing_range(), np.zeros(2, F32), R)
+    ys = np.stack([go.sample_ssm(po, otf.PRNGKey(10 + b), T, inputs.reshape(T, 1))[1] for b in range(B)])
+    init = (mu0 + 0.05 * rng.normal(size=(B, K, 4))).astype(F32)
+    ref = _oracle_batch(po, ys, K, init, inputs.reshape(T, 1))
+    post = bfa.gaussian_sum_filter(pp, ys, K, 1, inputs, initial_means=init)
+    assert tuple(post.means.shape) == (B, K, T, 4)
+    _check(post, ref, tol=3e-5)
+
+
+def test_single_linear_component_equals_kalman_kernel():
+    bfa, nl = _nl()
+    a = cm.cv_model_arrays()
+    ys = cm.simulate_batch(a, 5, 40, seed=4)
+    init = np.tile(a["m0"], (5, 1))
+    pk = bfa.kalman_filter(cm.product_params(a), ys, initial_means=init)
+    ref = cm.oracle_kalman_batch(a, ys, init)
+    pg = bfa.gaussian_sum_filter(cm.product_params(a), ys, 1, 1, initial_means=init.reshape(5, 1, 4))
+    for k in FIELDS + ("weights",):
+        assert cm.rel_err(getattr(pg, k).cpu().numpy(), ref[k]) < TOL, k
+        assert cm.rel_err(getattr(pg, k).cpu().numpy(), getattr(pk, k).cpu().numpy()) < TOL, k
+
+
+def test_default_initial_means_follow_prngkey0_draw():
+    bfa, nl = _nl()
+    a = cm.cv_model_arrays()
+    ys = cm.simulate_batch(a, 1, 16, seed=5)[0]
+    post = bfa.gaussian_sum_filter(cm.product_params(a), ys, 3)          # reference signature, no extras
+    ref = go.gaussian_sum_filter(cm.oracle_params(a), ys, 3)
+    _check(post, ref, tol=3e-5)
+
+
+@pytest.mark.parametrize("K,n", [(32, 8), (100, 4), (64, 4)])
+def test_many_components(K, n):
+    """cfg3-shaped (K=32, n=8: one wave per trajectory) and K=100, n=4 (two lanes per chain -> 256
+    lanes per trajectory, reweight continued through LDS); staged and strided stores agree bit for bit."""
+    bfa, nl = _nl()
+    rng = np.random.default_rng(K)
+    T, B = 16, 3
+    if n == 8:
+        po = go.ParamsNLSSM(np.zeros(8, F32), np.eye(8, dtype=F32), om.Lorenz96(8), np.zeros(8, F32),
+                            1e-2 * np.eye(8, dtype=F32), om.PickEven(8), np.zeros(4, F32), 1e-1 * np.eye(4, dtype=F32))
+        pp = bfa.ParamsNLSSM(np.zeros(8, F32), np.eye(8, dtype=F32), nl.lorenz96(8), np.zeros(8, F32),
+                             1e-2 * np.eye(8, dtype=F32), nl.pick_even(8), np.zeros(4, F32), 1e-1 * np.eye(4, dtype=F32))
+    else:
+        a = cm.cv_model_arrays()
+        po, pp = cm.oracle_params(a), cm.product_params(a)
+    ys = np.stack([go.sample_ssm(po, otf.PRNGKey(b), T)[1] for b in range(B)])
+    init = rng.normal(size=(B, K, n)).astype(F32)
+    ref = _oracle_batch(po, ys, K, init)
+    post = bfa.gaussian_sum_filter(pp, ys, K, 1, initial_means=init)
+    _check(post, ref, tol=3e-5)
+    _mode(0)
+    try:
+        post0 = bfa.gaussian_sum_filter(pp, ys, K, 1, initial_means=init)
+    finally:
+        _mode(-1)
+    for k in FIELDS + ("weights",):
+        assert np.array_equal(getattr(post, k).cpu().numpy(), getattr(post0, k).cpu().numpy()), k
+
+
+def test_stochastic_volatility_switching_emission():
+    bfa, nl = _nl()
+    T, K = 20, 4
+    Phi = 0.8 * np.eye(3, dtype=F32)
+    Q, R = 0.5 * np.eye(3, dtype=F32), 1e-1 * np.eye(3, dtype=F32)
+    inputs = np.array([0] * 10 + [1] * 10, F32)
+    r0 = np.array([0.1, -0.2, 0.05], F32)
+    po = go.ParamsNLSSM(np.zeros(3, F32), np.eye(3, dtype=F32), om.Linear(Phi), np.zeros(3, F32), Q, om.StochVol(3), r0, R)
+    pp = bfa.ParamsNLSSM(np.zeros(3, F32), np.eye(3, dtype=F32), nl.linear_dynamics(Phi), np.zeros(3, F32), Q,
+                         nl.stoch_vol(3), r0, R)
+    xs, ys = go.sample_ssm(po, otf.PRNGKey(3), T, inputs.reshape(T, 1))
+    init = np.random.default_rng(1).normal(size=(K, 3)).astype(F32)
+    ref = go.gaussian_sum_filter(po, ys, K, initial_means=init, inputs=inputs.reshape(T, 1))
+    post = bfa.gaussian_sum_filter(pp, ys, K, 1, inputs, initial_means=init)
+    _check(post, ref, tol=3e-5)
+
+
+def test_scalar_growth_and_sine_models():
+    bfa, nl = _nl()
+    T, K = 20, 3
+    # f3 / g3 of Experiment_TSP_2023.ipynb: growth dynamics with input, 0.8 x + r emission
+    po = go.ParamsNLSSM(np.zeros(1, F32), np.eye(1, dtype=F32), om.Growth(), np.zeros(1, F32), np.eye(1, dtype=F32),
+                        om.Linear(0.8 * np.eye(1, dtype=F32)), np.zeros(1, F32), 0.1 * np.eye(1, dtype=F32))
+    pp = bfa.ParamsNLSSM(np.zeros(1, F32), np.eye(1, dtype=F32), nl.growth(), np.zeros(1, F32), np.eye(1, dtype=F32),
+                         nl.linear_emission(0.8 * np.eye(1, dtype=F32)), np.zeros(1, F32), 0.1 * np.eye(1, dtype=F32))
+    u = np.cos(np.arange(T, dtype=F32))
+    xs, ys = go.sample_ssm(po, otf.PRNGKey(1), T, u.reshape(T, 1))
+    init = np.array([[0.5], [-0.5], [1.5]], F32)
+    # |f'(x)| reaches 25.5 for the growth model: ulp-level differences (v_rcp_f32 vs IEEE division)
+    # are amplified step after step, in the oracle as much as here
+    _check(bfa.gaussian_sum_filter(pp, ys, K, 1, u, initial_means=init),
+           go.gaussian_sum_filter(po, ys, K, initial_means=init, inputs=u.reshape(T, 1)), tol=2e-4)
+    # f1 / g1: sin(10 x) + q, c x.x + r
+    po = go.ParamsNLSSM(np.zeros(3, F32), np.eye(3, dtype=F32), om.Sine(3), np.zeros(3, F32), 0.1 * np.eye(3, dtype=F32),
+                        om.Quadratic(3, 0.5), np.zeros(1, F32), 0.5 * np.eye(1, dtype=F32))
+    pp = bfa.ParamsNLSSM(np.zeros(3, F32), np.eye(3, dtype=F32), nl.sine(3), np.zeros(3, F32), 0.1 * np.eye(3, dtype=F32),
+                         nl.quadratic(3, 0.5), np.zeros(1, F32), 0.5 * np.eye(1, dtype=F32))
+    xs, ys = go.sample_ssm(po, otf.PRNGKey(2), T)
+    init = 0.3 * np.random.default_rng(2).normal(size=(K, 3)).astype(F32)
+    _check(bfa.gaussian_sum_filter(pp, ys, K, 1, initial_means=init), go.gaussian_sum_filter(po, ys, K, initial_means=init),
+           tol=1e-4)   # sin(10 x): the Jacobian amplifies 1-ulp differences in sinf/cosf tenfold per step
+
+
+def test_gsf_errors():
+    bfa, nl = _nl()
+    from bayesianfiltering_amd import _lib
+    a = cm.cv_model_arrays()
+    ys = cm.simulate_batch(a, 1, 8, seed=1)[0]
+    with pytest.raises(_lib.BayesFiltError) as e:
+        bfa.gaussian_sum_filter(cm.product_params(a), ys, 300, initial_means=np.zeros((300, 4), F32))   # > 256 lanes
+    assert e.value.code == _lib.BF_EUNSUPPORTED
