@@ -4,9 +4,11 @@ bootstrap particle filters) behind the call surface of the reference package ``g
 from .models import ParamsNLSSM, ParamsBPF
 from .containers import GaussianComponent, GaussianSum
 from .inference import (PosteriorGaussianSumFiltered, gaussian_sum_filter, kalman_filter, FilterCarry,
-                        FULL5, FILTERED, PRNGKey, sample_initial_component_means)
+                        FULL5, FILTERED, PRNGKey, sample_initial_component_means,
+                        bootstrap_particle_filter, ParticleCarry, resample_indices)
 from . import nonlinearities, utils
 
 __all__ = ["ParamsNLSSM", "ParamsBPF", "GaussianComponent", "GaussianSum", "PosteriorGaussianSumFiltered",
            "gaussian_sum_filter", "kalman_filter", "FilterCarry", "FULL5", "FILTERED", "PRNGKey",
-           "sample_initial_component_means", "nonlinearities", "utils"]
+           "sample_initial_component_means", "bootstrap_particle_filter", "ParticleCarry", "resample_indices",
+           "nonlinearities", "utils"]

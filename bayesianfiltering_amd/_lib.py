@@ -52,6 +52,22 @@ class bf_model(C.Structure):
                 ("n_emi_theta", C.c_int32), ("q0", _FP), ("r0", _FP), ("Q", _FP), ("R", _FP)]
 
 
+class bf_bpf_model(C.Structure):
+    _fields_ = [("ssm", bf_model), ("m0", _FP), ("P0", _FP), ("lp_cov", _FP), ("r_eval", _FP)]
+
+
+class bf_bpf_carry(C.Structure):
+    _fields_ = [("x_in", C.c_void_p), ("w_in", C.c_void_p), ("key_in", C.c_void_p),
+                ("x_out", C.c_void_p), ("w_out", C.c_void_p), ("key_out", C.c_void_p)]
+
+
+class bf_bpf_out(C.Structure):
+    _fields_ = [("weights", C.c_void_p), ("w_sB", C.c_int64), ("w_sN", C.c_int64), ("w_sT", C.c_int64),
+                ("particles", C.c_void_p), ("x_sB", C.c_int64), ("x_sN", C.c_int64), ("x_sT", C.c_int64),
+                ("ancestors", C.c_void_p), ("mean", C.c_void_p), ("ess", C.c_void_p), ("logz", C.c_void_p),
+                ("resampled", C.c_void_p)]
+
+
 # every symbol include/bayesfilt.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "bf_version": (C.c_int, []),
@@ -61,6 +77,10 @@ SYMBOLS = {
     "bf_bytes_per_step": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(bf_out_desc)]),
     "bf_gsf_ekf_f32": (C.c_int, [C.POINTER(bf_model), C.POINTER(bf_cstream), C.POINTER(bf_cstream), C.c_int64, C.c_int64,
                                  C.c_int32, C.POINTER(bf_carry), C.POINTER(bf_out_desc), C.c_void_p]),
+    "bf_bpf_f32": (C.c_int, [C.POINTER(bf_bpf_model), C.POINTER(bf_cstream), C.POINTER(bf_cstream), C.c_int64, C.c_int64,
+                             C.c_int32, C.POINTER(C.c_uint32), C.c_float, C.c_int32, C.POINTER(bf_bpf_carry),
+                             C.POINTER(bf_bpf_out), C.c_void_p]),
+    "bf_resample_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "bf_random_normal_f32": (C.c_int, [C.POINTER(C.c_uint32), C.c_int64, _FP]),
     "bf_random_split": (C.c_int, [C.POINTER(C.c_uint32), C.c_int64, C.POINTER(C.c_uint32)]),
     "bf_kalman_filter_f32": (C.c_int, [C.POINTER(bf_lgssm), C.POINTER(bf_cstream), C.c_int64, C.c_int64,

@@ -25,6 +25,12 @@ int launch_kf_group(const bf_lgssm* p, const bf_cstream* y, long long B, long lo
 int launch_gsf_ekf(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int K,
                    const bf_carry* carry, const bf_out_desc* out, hipStream_t stream, int force_mode);
 
+int launch_bpf(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP,
+               float ess, int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o,
+               hipStream_t stream);
+int launch_resample(const float* d_w, const uint32_t* d_keys, long long B, int NP, int resampler, int* d_idx,
+                    hipStream_t stream);
+
 static int g_kf_emit_mode = -1;  // -1 = choose from the layout
 static int g_kf_lanes = 0;       // 0 = default lanes per trajectory for the (n, m) pair
 
@@ -102,6 +108,24 @@ int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream*
   if (!y->ptr) return bf::set_error(BF_EINVAL, "observations pointer is NULL");
   if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
   return bf::launch_gsf_ekf(model, y, u, B, T, K, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode);
+}
+
+int bf_bpf_f32(const bf_bpf_model* model, const bf_cstream* y, const bf_cstream* u, int64_t B, int64_t T, int32_t N,
+               const uint32_t key[2], float ess_threshold, int32_t resampler, const bf_bpf_carry* carry,
+               const bf_bpf_out* out, void* stream) {
+  if (!model || !y || !out || !key) return bf::set_error(BF_EINVAL, "NULL argument");
+  if (B <= 0 || T <= 0 || N <= 0) return bf::set_error(BF_EINVAL, "B, T and N must be positive");
+  if (!y->ptr) return bf::set_error(BF_EINVAL, "observations pointer is NULL");
+  if (!model->ssm.Q || !model->m0 || !model->P0 || !model->lp_cov) return bf::set_error(BF_EINVAL, "Q, m0, P0, lp_cov are required");
+  if (resampler != 0 && resampler != 1) return bf::set_error(BF_EINVAL, "resampler must be 0 (multinomial) or 1 (systematic)");
+  if (carry && carry->x_in && !carry->w_in) return bf::set_error(BF_EINVAL, "carry.x_in needs carry.w_in");
+  return bf::launch_bpf(model, y, u, B, T, N, ess_threshold, resampler, key, carry, out, static_cast<hipStream_t>(stream));
+}
+
+int bf_resample_f32(const float* d_w, const uint32_t* d_keys, int64_t B, int32_t N, int32_t resampler, int32_t* d_idx,
+                    void* stream) {
+  if (!d_w || !d_keys || !d_idx || B <= 0 || N <= 0) return bf::set_error(BF_EINVAL, "bad argument");
+  return bf::launch_resample(d_w, d_keys, B, N, resampler, d_idx, static_cast<hipStream_t>(stream));
 }
 
 int bf_random_normal_f32(const uint32_t key[2], int64_t count, float* host_out) {

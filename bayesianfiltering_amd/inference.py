@@ -387,3 +387,136 @@ def gaussian_sum_filter(params, emissions, num_components: int = 1, num_iter: in
     if return_carry:
         extras.append(c_out)
     return (post, *extras) if extras else post
+
+
+class ParticleCarry(NamedTuple):
+    """The scan carry (weights, particles, key) of inference.py:1364 at the end of a chunk."""
+    weights: Any
+    particles: Any
+    key: Any
+
+
+def bootstrap_particle_filter(params, emissions, num_particles: int, key=None, inputs=None,
+                              ess_threshold: float = 0.5, *, resampler: str = "multinomial", output: str = "full",
+                              carry=None, return_carry: bool = False, return_ancestors: bool = False, device="cuda"):
+    """Bootstrap particle filter, gaussfiltax/inference.py:1302-1380, on the HIP engine.
+
+    Same positional signature as the reference (``key`` defaults to ``PRNGKey(0)``).  Returns the
+    reference's dict ``{'weights': (N, T), 'particles': (N, T, n)}`` for ``emissions`` of shape
+    (T, m), or with a leading batch axis for (B, T, m).  ``output='summary'`` returns per-step
+    summaries instead (``mean`` (T, n), ``ess``, ``logz``, ``resampled`` (T,)) -- the full history of a
+    large run does not fit in HBM; ``output='both'`` returns everything.  ``resampler`` is
+    'multinomial' (the reference's ``jr.choice``, utils.py:207-214) or 'systematic'.
+    ``params.emission_distribution_log_prob`` must be a :class:`~.nonlinearities.GaussianLogProb`.
+    """
+    from .nonlinearities import GaussianLogProb
+    torch = _torch()
+    lib = _lib.require_gpu()
+    NP = int(num_particles)
+    if NP < 1:
+        raise ValueError("num_particles must be >= 1")
+    if resampler not in ("multinomial", "systematic"):
+        raise ValueError("resampler must be 'multinomial' or 'systematic'")
+    if output not in ("full", "summary", "both"):
+        raise ValueError("output must be 'full', 'summary' or 'both'")
+    lp = params.emission_distribution_log_prob
+    if not isinstance(lp, GaussianLogProb):
+        raise TypeError("params.emission_distribution_log_prob must be a nonlinearities.GaussianLogProb: Python "
+                        "callables cannot run inside the HIP kernels, and there is no CPU fallback.")
+    if lp.emission_function is not params.emission_function and \
+            (lp.emission_function.fn_id != params.emission_function.fn_id or
+             not np.array_equal(lp.emission_function.theta, params.emission_function.theta)):
+        raise ValueError("the log-prob's emission function must be params.emission_function")
+    mdl = _Model(params)
+    n, m = mdl.n, mdl.m
+    bm = _lib.bf_bpf_model()
+    bm.ssm = mdl.c
+    m0 = _host_f32(params.initial_mean).reshape(n)
+    P0 = _host_f32(params.initial_covariance).reshape(n, n)
+    lpc = np.ascontiguousarray(lp.covariance.reshape(m, m))
+    rev = np.ascontiguousarray(lp.r_eval.reshape(mdl.dr))
+    bm.m0, bm.P0, bm.lp_cov, bm.r_eval = _fp(m0), _fp(P0), _fp(lpc), _fp(rev)
+
+    y = _dev_f32(emissions, device)
+    squeeze = y.dim() == 2
+    if squeeze:
+        y = y.unsqueeze(0)
+    if y.dim() != 3 or y.shape[2] != m:
+        raise ValueError(f"emissions must be (T,{m}) or (B,T,{m}); got {tuple(y.shape)}")
+    B, T = int(y.shape[0]), int(y.shape[1])
+    dev = y.device
+    yd = _lib.bf_cstream()
+    yd.ptr, yd.sB, yd.sK, yd.sT, yd.sE = y.data_ptr(), y.stride(0), 0, y.stride(1), y.stride(2)
+    ud = _lib.bf_cstream()
+    u_keep = None
+    if inputs is not None:
+        u_keep = _dev_f32(inputs, device)
+        u_keep = u_keep.reshape(1, T, -1) if u_keep.dim() <= 2 else u_keep
+        if u_keep.shape[1] != T or u_keep.shape[0] not in (1, B):
+            raise ValueError(f"inputs must be (T,), (T,d) or (B,T,d); got {tuple(u_keep.shape)}")
+        ud.ptr, ud.sB, ud.sT, ud.sE = u_keep.data_ptr(), (u_keep.stride(0) if u_keep.shape[0] == B else 0), u_keep.stride(1), 1
+
+    key = PRNGKey(0) if key is None else np.asarray(key, dtype=np.uint32).reshape(2)
+    key_c = (C.c_uint32 * 2)(int(key[0]), int(key[1]))
+
+    od = _lib.bf_bpf_out()
+    res = {}
+    if output in ("full", "both"):
+        res["weights"] = torch.empty((B, NP, T), dtype=torch.float32, device=dev)
+        res["particles"] = torch.empty((B, NP, T, n), dtype=torch.float32, device=dev)
+        od.weights, (od.w_sB, od.w_sN, od.w_sT) = res["weights"].data_ptr(), res["weights"].stride()
+        od.particles, (od.x_sB, od.x_sN, od.x_sT) = res["particles"].data_ptr(), res["particles"].stride()[:3]
+    if return_ancestors:
+        if output == "summary":
+            raise ValueError("ancestors need output='full' or 'both'")
+        res["ancestors"] = torch.empty((B, NP, T), dtype=torch.int32, device=dev)
+        od.ancestors = res["ancestors"].data_ptr()
+    if output in ("summary", "both"):
+        res["mean"] = torch.empty((B, T, n), dtype=torch.float32, device=dev)
+        for k in ("ess", "logz", "resampled"):
+            res[k] = torch.empty((B, T), dtype=torch.float32, device=dev)
+        od.mean, od.ess, od.logz, od.resampled = (res[k].data_ptr() for k in ("mean", "ess", "logz", "resampled"))
+
+    cr = _lib.bf_bpf_carry()
+    keep = []
+    if carry is not None:
+        w_in = _dev_f32(carry.weights, device).reshape(B, NP).contiguous()
+        x_in = _dev_f32(carry.particles, device).reshape(B, NP, n).contiguous()
+        k_in = torch.as_tensor(np.asarray(carry.key.cpu() if hasattr(carry.key, "cpu") else carry.key, dtype=np.int64)
+                               .astype(np.uint32).view(np.int32).reshape(B, 2), device=dev)
+        keep += [w_in, x_in, k_in]
+        cr.x_in, cr.w_in, cr.key_in = x_in.data_ptr(), w_in.data_ptr(), k_in.data_ptr()
+    c_out = None
+    if return_carry:
+        c_out = ParticleCarry(torch.empty((B, NP), dtype=torch.float32, device=dev),
+                              torch.empty((B, NP, n), dtype=torch.float32, device=dev),
+                              torch.empty((B, 2), dtype=torch.int32, device=dev))
+        cr.w_out, cr.x_out, cr.key_out = c_out.weights.data_ptr(), c_out.particles.data_ptr(), c_out.key.data_ptr()
+
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(lib.bf_bpf_f32(C.byref(bm), C.byref(yd), C.byref(ud), B, T, NP, key_c, float(ess_threshold),
+                              1 if resampler == "systematic" else 0, C.byref(cr), C.byref(od), C.c_void_p(stream)))
+    if squeeze:
+        res = {k: v[0] for k, v in res.items()}
+    if return_carry:
+        c_out = ParticleCarry(c_out.weights, c_out.particles,
+                              torch.as_tensor(c_out.key.cpu().numpy().view(np.uint32).astype(np.int64)))
+        return res, c_out
+    return res
+
+
+def resample_indices(weights, keys, resampler: str = "multinomial"):
+    """The index draw of ``_resample`` (gaussfiltax/utils.py:210) alone:
+    ``jr.choice(key, N, (N,), p=weights)`` per row.  weights (B, N), keys (B, 2) uint32."""
+    torch = _torch()
+    lib = _lib.require_gpu()
+    w = _dev_f32(weights, "cuda").contiguous()
+    if w.dim() == 1:
+        w = w.unsqueeze(0)
+    B, NP = w.shape
+    k = torch.as_tensor(np.asarray(keys, dtype=np.uint32).reshape(B, 2).view(np.int32), device=w.device)
+    idx = torch.empty((B, NP), dtype=torch.int32, device=w.device)
+    stream = torch.cuda.current_stream(w.device).cuda_stream
+    _lib.check(lib.bf_resample_f32(w.data_ptr(), k.data_ptr(), B, NP, 1 if resampler == "systematic" else 0,
+                                   idx.data_ptr(), C.c_void_p(stream)))
+    return idx

@@ -142,6 +142,59 @@ typedef struct bf_model {
 int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream* u, int64_t B, int64_t T, int32_t K,
                    const bf_carry* carry, const bf_out_desc* out, void* stream);
 
+/* ---- bootstrap particle filter ------------------------------------------------------- */
+/* ParamsBPF (gaussfiltax/models.py:55-84): the state-space model plus the Gaussian emission
+ * log-density  MVN(h(x, r_eval, u), lp_cov).log_prob(y)  (the form of every `*lp` function of the
+ * reference's scripts, e.g. gaussfiltax/nonlinearities.py:51-52) and the initial law N(m0, P0).
+ * HOST pointers. */
+typedef struct bf_bpf_model {
+  bf_model ssm;
+  const float* m0;     /* [n]      */
+  const float* P0;     /* [n,n]    */
+  const float* lp_cov; /* [m,m] covariance of the emission log-density          */
+  const float* r_eval; /* [dr] noise value h is evaluated at (NULL = zeros)     */
+} bf_bpf_model;
+
+/* Scan carry (weights, particles, key) of inference.py:1364 for chunked runs; DEVICE pointers,
+ * contiguous [B][N][n], [B][N], [B][2].  x_in == NULL: draw the initial particles (:1369-1373). */
+typedef struct bf_bpf_carry {
+  const float* x_in;
+  const float* w_in;
+  const uint32_t* key_in;
+  float* x_out;
+  float* w_out;
+  uint32_t* key_out;
+} bf_bpf_carry;
+
+/* Outputs (DEVICE pointers, NULL = not emitted).  weights / particles are what the reference
+ * returns (inference.py:1359-1362): element (b,i,t) at weights[b*w_sB + i*w_sN + t*w_sT],
+ * (b,i,t,d) at particles[b*x_sB + i*x_sN + t*x_sT + d]; ancestors share the weights' strides.
+ * The per-step summaries are contiguous [B][T][n] / [B][T]. */
+typedef struct bf_bpf_out {
+  float* weights;
+  int64_t w_sB, w_sN, w_sT;
+  float* particles;
+  int64_t x_sB, x_sN, x_sT;
+  int32_t* ancestors;
+  float* mean;      /* sum_i w_i x_i of the emitted weights / particles */
+  float* ess;       /* 1 / sum w^2 before the resampling decision       */
+  float* logz;      /* log sum_i w_{t-1,i} p(y_t | x_i)                 */
+  float* resampled; /* 1.0 where the step resampled                     */
+} bf_bpf_out;
+
+/* Batched bootstrap particle filter: replaces the lax.scan of bootstrap_particle_filter
+ * (inference.py:1330-1377) with _resample (utils.py:207-214).  N <= 4096 particles per
+ * trajectory, one workgroup per trajectory.  key = {hi, lo} of jr.PRNGKey (used for every
+ * trajectory unless carry->key_in is given).  resampler: 0 = multinomial inverse-CDF (the
+ * reference's jr.choice), 1 = systematic. */
+int bf_bpf_f32(const bf_bpf_model* model, const bf_cstream* y, const bf_cstream* u, int64_t B, int64_t T, int32_t N,
+               const uint32_t key[2], float ess_threshold, int32_t resampler, const bf_bpf_carry* carry,
+               const bf_bpf_out* out, void* stream);
+
+/* Index draw of utils.py:210 alone: d_idx[b][i] = choice(d_keys[b], N, (N,), p = d_w[b]). */
+int bf_resample_f32(const float* d_w, const uint32_t* d_keys, int64_t B, int32_t N, int32_t resampler,
+                    int32_t* d_idx, void* stream);
+
 /* jax.random.normal(key, (count,)) for the default threefry PRNG, written to a HOST buffer
  * (used for the reference's fixed `MVN(m0, P0).sample(K, PRNGKey(0))` draw of the initial
  * component means, inference.py:367: m0 + chol(P0) z).  key = {hi, lo} as jr.PRNGKey. */

@@ -141,26 +141,33 @@ def normal(key, size):
     return bits_to_normal(random_bits(key, size))
 
 
-def cumsum_assoc(x):
-    """fp32 inclusive prefix sum in the rounding order of ``lax.associative_scan(add)``.
-
-    out[0] = x[0]; out[2i+1] = S[i]; out[2i] = S[i-1] + x[2i]  (i >= 1)
-    where S = cumsum_assoc(x[0::2][:len//2] + x[1::2]).
-    """
-    x = np.asarray(x, dtype=np.float32)
+def _scan_pow2(x):
+    """lax.associative_scan(add) on a power-of-two length: out[2i+1] = S[i], out[0] = x[0],
+    out[2i] = S[i-1] + x[2i] with S = scan(x[0::2] + x[1::2])  (== Brent-Kung up/down sweep)."""
     n = x.shape[0]
     if n < 2:
         return x.copy()
-    red = (x[0:n - 1:2][: n // 2] + x[1::2]).astype(np.float32)
-    odd = cumsum_assoc(red)
+    odd = _scan_pow2((x[0::2] + x[1::2]).astype(np.float32))
     out = np.empty(n, dtype=np.float32)
     out[1::2] = odd
     out[0] = x[0]
-    if n % 2 == 0:
-        out[2::2] = (odd[:-1] + x[2::2]).astype(np.float32)
-    else:
-        out[2::2] = (odd + x[2::2]).astype(np.float32)
+    out[2::2] = (odd[:-1] + x[2::2]).astype(np.float32)
     return out
+
+
+def cumsum_assoc(x):
+    """fp32 inclusive prefix sum in the rounding order of ``lax.associative_scan(add)``.  Lengths
+    that are not a power of two are zero-padded to the next one (zeros on the right change no
+    rounding of the kept prefix); this is the ONE canonical order of the oracle and of the HIP
+    resampler (a workgroup Brent-Kung scan reproduces it bit for bit)."""
+    x = np.asarray(x, dtype=np.float32)
+    n = x.shape[0]
+    p = 1
+    while p < n:
+        p *= 2
+    buf = np.zeros(p, dtype=np.float32)
+    buf[:n] = x
+    return _scan_pow2(buf)[:n].copy()
 
 
 def choice_indices(cdf, u):
