@@ -134,17 +134,20 @@ def main():
     init = torch.zeros((B, n), device=device)
 
     post = None
-    summary_local = torch.empty((B, n + n * n + 1), device=device)
-    summary_all = torch.empty((world * B, n + n * n + 1), device=device) if world > 1 else None
+    summary_local = torch.zeros((B, n + n * n), device=device)
+    summary_all = None
+
+    from bayesianfiltering_amd import distributed as bdist
 
     def step():
-        nonlocal post
+        # one pass of the hot path over this rank's batch + the path's one exchange step:
+        # RCCL all-gather of the per-trajectory posterior summaries (final mean, covariance)
+        nonlocal post, summary_all
         post = bfa.kalman_filter(params, y, initial_means=init, layout=args.layout, out=post)
         if world > 1:
             summary_local[:, :n] = post.means[:, 0, -1]
             summary_local[:, n:n + n * n] = post.covariances[:, 0, -1].reshape(B, n * n)
-            import torch.distributed as dist
-            dist.all_gather_into_tensor(summary_all, summary_local)
+            summary_all = bdist.all_gather_summaries(summary_local, world * B)
 
     for _ in range(args.warmup):
         step()
@@ -162,7 +165,7 @@ def main():
         if world > 1:
             summary_local[:, :n] = post.means[:, 0, -1]
             summary_local[:, n:n + n * n] = post.covariances[:, 0, -1].reshape(B, n * n)
-            dist.all_gather_into_tensor(summary_all, summary_local)
+            summary_all = bdist.all_gather_summaries(summary_local, world * B)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
