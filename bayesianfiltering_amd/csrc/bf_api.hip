@@ -22,6 +22,8 @@ int set_error(int code, const char* fmt, ...) {
 int launch_kf_group(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
                     const bf_out_desc* out, hipStream_t stream, int force_mode, int lanes);
 
+int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
+                   const bf_out_desc* out, hipStream_t stream);
 int launch_gsf_ekf(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int K,
                    const bf_carry* carry, const bf_out_desc* out, hipStream_t stream, int force_mode);
 
@@ -94,6 +96,8 @@ int bf_kalman_filter_f32(const bf_lgssm* model, const bf_cstream* y, int64_t B, 
   if (model->Q_steps < 1 || model->R_steps < 1) return bf::set_error(BF_EINVAL, "Q_steps / R_steps must be >= 1");
   if (!y->ptr) return bf::set_error(BF_EINVAL, "observations pointer is NULL");
   if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
+  if (model->n == 64 && model->m == 32)  // dense products large enough for the fp32 matrix cores
+    return bf::launch_kf_mfma(model, y, B, T, carry, out, static_cast<hipStream_t>(stream));
   return bf::launch_kf_group(model, y, B, T, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode,
                              bf::g_kf_lanes);
 }

@@ -1,0 +1,319 @@
+// kf_scan_mfma: batched Kalman filter for n = 64, m = 32 on the fp32 matrix cores.
+//
+// Same recursion as kf_scan_group.hip -- the lax.scan body of gaussian_sum_filter
+// (gaussfiltax/inference.py:333-371) for linear f/h and one component: _condition_on (:72-105),
+// reweight (:347-350), _predict (:51-70) -- but at state_dim 64 one step is ~2 MFLOP of dense
+// 64x64 / 32x64 products (60-120 flop per output byte, above the fp32 ridge),
+// so the covariance algebra runs on v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fmaf chain).
+//
+// Mapping (gfx950).  One workgroup of 4 waves per trajectory; wave w owns the 32x32 output tile
+// (ti, tj) = (w >> 1, w & 1) of every 64x64 product.  P lives in LDS (65-float pitch: both the
+// row-indexed and the column-indexed MFMA operand patterns are bank-conflict free) and, tile by
+// tile, in the accumulator registers of its owner wave across steps; the constant operands (the
+// wave's row blocks of A, H, and its tiles of G Q G^T, D R D^T) stay in VGPRs in MFMA operand
+// layout for the whole scan.  Per step:
+//   A  H P            (waves 0,1; K = 64)          hm = H m, v = y - hm                 (wave 2)
+//   B  S = (H P) H^T + D R D^T                     (wave 0; K = 64)
+//   C  chol(S + 1e-6) and its inverse L^-1         (wave 0, rows in registers, v_readlane broadcasts)
+//      chol(S), z = L^-1 v, log-likelihood         (wave 1)
+//   E  W = L^-1 (H P),  F  X = L^-T W = (S + 1e-6)^-1 H P   (waves 0,1; K = 32)     K = X^T
+//   G  K S = X^T S    (waves 0,1; K = 32)          m+ = m + X^T v                       (wave 2)
+//   H  P+ = P - (K S) X                            (all waves; K = 32)
+//   I  A P+           (all waves; K = 64)          m- = A m+ + G q0                 (waves 0,3)
+//   J  P- = (A P+) A^T + G Q G^T                   (all waves; K = 64)
+// The m x m system is solved through a Cholesky factor instead of the reference's LU with
+// partial pivoting (utils.py:256-259): S + 1e-6 is symmetric positive definite, the solution is
+// the same linear system's, and the two factorizations agree to ~1e-6 relative for the
+// conditioned S of a filter (the parity budget is 1e-5); the log-likelihood uses the Cholesky
+// factor of the un-jittered S exactly like the reference (inference.py:104, :24).
+#include "bf_common.hpp"
+#include "kf_math.hpp"
+#include "lane_group.hpp"
+
+namespace bf {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+template <int N, int M>
+struct MfmaConst {  // device-resident (too large for kernel arguments)
+  float A[N * N], H[M * N], GQG[N * N], DRD[M * M], Gq0[N], Dr0[M];
+};
+
+__device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// row of accumulator register r inside a 32x32 tile (C/D layout of the 32x32 MFMA shapes)
+__device__ __forceinline__ int c_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ float rdlane(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+// In-wave Cholesky of a 32x32 SPD matrix: lane (l & 31) holds row l of the matrix in a[0..31];
+// on return a[k] (k <= row) holds L[row][k].  Column j: every lane forms its s = A[i][j] -
+// sum_k L[i][k] L[j][k] with L[j][k] broadcast from lane j by v_readlane.
+__device__ __forceinline__ void chol32_rows(float* a, int li) {
+  static_for<0, 32>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    float s = a[j];
+    static_for<0, j>([&](auto Kk) {
+      constexpr int k = decltype(Kk)::value;
+      s = fmaf(-a[k], rdlane(a[k], j), s);
+    });
+    // IEEE sqrt / division here: the 32-step factorization and its explicit inverse compound
+    // rounding errors, and these 64 scalar ops per step are noise against the MFMA work
+    const float d = sqrtf(rdlane(s, j));  // NaN if not positive definite
+    const float rinv = 1.0f / d;
+    a[j] = (li == j) ? d : s * rinv;
+  });
+}
+
+template <int N, int M>
+__global__ void __launch_bounds__(256, 2)
+kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView carry, OutViews out, long long B, long long T) {
+  static_assert(N == 64 && M == 32, "tile assignment is written for n = 64, m = 32");
+  constexpr int PP = N + 1;  // LDS pitch of 64-wide matrices
+  constexpr int PS = M + 1;  // LDS pitch of 32-wide matrices
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ti = wave >> 1, tj = wave & 1;
+  const int lr = lane & 31, lk = lane >> 5;
+  const long long b = blockIdx.x;
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sP = lds;                 // [64][65]  current covariance
+  float* sT = sP + N * PP;         // [64][65]  H P / W / X, then A P+
+  float* sKS = sT + N * PP;        // [64][33]  -(K S)
+  float* sS = sKS + N * PS;        // [32][33]  S
+  float* sLi = sS + M * PS;        // [32][33]  inverse Cholesky factor of S + 1e-6
+  float* sm = sLi + M * PS;        // [64] mean
+  float* sm2 = sm + N;             // [64] mean (ping-pong)
+  float* sv = sm2 + N;             // [32] innovation
+  float* sy = sv + M;              // [32] observation
+
+  // ---- constant operands in MFMA layout: lane holds X[32*blk + (l & 31)][2 s + (l >> 5)]
+  float Ati[32], Atj[32], Hr[32];
+  BF_UNROLL for (int s = 0; s < 32; ++s) {
+    Ati[s] = cst->A[(32 * ti + lr) * N + 2 * s + lk];
+    Atj[s] = cst->A[(32 * tj + lr) * N + 2 * s + lk];
+    Hr[s] = cst->H[lr * N + 2 * s + lk];
+  }
+  f32x16 gqg, drd, Pacc;
+  BF_UNROLL for (int r = 0; r < 16; ++r) {
+    gqg[r] = cst->GQG[(32 * ti + c_row(r, lane)) * N + 32 * tj + lr];
+    drd[r] = cst->DRD[c_row(r, lane) * M + lr];
+    Pacc[r] = carry.P_in[b * N * N + (32 * ti + c_row(r, lane)) * N + 32 * tj + lr];
+    sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = Pacc[r];
+  }
+  if (tid < N) sm[tid] = carry.m_in[b * N + tid];
+  float w = carry.w_in ? carry.w_in[b] : 1.0f;
+  float ynext = (wave == 2 && lane < M) ? y.p[b * y.sB + lane * y.sE] : 0.f;
+  __syncthreads();
+
+  float* mcur = sm;
+  float* mnxt = sm2;
+  for (long long t = 0; t < T; ++t) {
+    // ================= phase A: H P (waves 0,1); innovation (wave 2)
+    if (wave < 2) {
+      f32x16 acc = {0};
+      BF_UNROLL for (int s = 0; s < 32; ++s) acc = mfma2(Hr[s], sP[(2 * s + lk) * PP + 32 * tj + lr], acc);
+      BF_UNROLL for (int r = 0; r < 16; ++r) sT[c_row(r, lane) * PP + 32 * tj + lr] = acc[r];
+    } else if (wave == 2) {
+      if (lane < M) sy[lane] = ynext;
+      const long long tn = t + 1 < T ? t + 1 : t;
+      if (lane < M) ynext = y.p[b * y.sB + tn * y.sT + lane * y.sE];  // prefetch
+      float s = 0.f;
+      BF_UNROLL for (int q = 0; q < 32; ++q) s = fmaf(Hr[q], mcur[2 * q + lk], s);
+      s += __shfl_xor(s, 32, 64);
+      if (lane < M) sv[lane] = sy[lane] - (s + cst->Dr0[lane]);
+    }
+    __syncthreads();
+    // ================= phase B: S = (H P) H^T + D R D^T (wave 0)
+    if (wave == 0) {
+      f32x16 acc = drd;
+      BF_UNROLL for (int s = 0; s < 32; ++s) acc = mfma2(sT[lr * PP + 2 * s + lk], Hr[s], acc);
+      BF_UNROLL for (int r = 0; r < 16; ++r) sS[c_row(r, lane) * PS + lr] = acc[r];
+    }
+    __syncthreads();
+    // ================= phase C: factorizations (waves 0 and 1)
+    float ll = 0.f;
+    if (wave == 0) {
+      float a[32], x[32];
+      BF_UNROLL for (int k = 0; k < 32; ++k) a[k] = sS[lr * PS + k] + 1e-6f;  // psd_solve's jitter on every entry
+      chol32_rows(a, lr);
+      // column (l & 31) of L^-1: x[i] = (delta_ic - sum_{k<i} L[i][k] x[k]) / L[i][i]
+      static_for<0, 32>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        float s = (lr == i) ? 1.f : 0.f;
+        static_for<0, i>([&](auto Kk) {
+          constexpr int k = decltype(Kk)::value;
+          s = fmaf(-rdlane(a[k], i), x[k], s);
+        });
+        x[i] = s / rdlane(a[i], i);
+      });
+      if (lane < 32) BF_UNROLL for (int i = 0; i < 32; ++i) sLi[i * PS + lr] = x[i];
+    } else if (wave == 1) {
+      float a[32];
+      BF_UNROLL for (int k = 0; k < 32; ++k) a[k] = sS[lr * PS + k];
+      chol32_rows(a, lr);
+      // z = L^-1 v by forward substitution across lanes; lane i carries the running residual of row i
+      float acc = sv[lr], quad = 0.f, dprod = 1.f;
+      static_for<0, 32>([&](auto Kk) {
+        constexpr int k = decltype(Kk)::value;
+        const float lkk = rdlane(a[k], k);
+        const float zk = rdlane(acc, k) / lkk;
+        quad = fmaf(zk, zk, quad);
+        dprod *= lkk;
+        acc = fmaf(-a[k], zk, acc);
+      });
+      // sum of 32 log-diagonals as log of the product, split in two to stay in range
+      ll = -0.5f * quad - 0.5f * float(M) * 1.8378770664093453f - fast_log(dprod);
+    }
+    __syncthreads();
+    // ================= phase E: W = L^-1 (H P) -> sT rows 32..63 (waves 0,1; K = 32)
+    if (wave < 2) {
+      f32x16 acc = {0};
+      BF_UNROLL for (int s = 0; s < 16; ++s)
+          acc = mfma2(sLi[lr * PS + 2 * s + lk], sT[(2 * s + lk) * PP + 32 * tj + lr], acc);
+      BF_UNROLL for (int r = 0; r < 16; ++r) sT[(32 + c_row(r, lane)) * PP + 32 * tj + lr] = acc[r];
+    }
+    __syncthreads();
+    // ================= phase F: X = L^-T W -> sT rows 0..31
+    if (wave < 2) {
+      f32x16 acc = {0};
+      BF_UNROLL for (int s = 0; s < 16; ++s)
+          acc = mfma2(sLi[(2 * s + lk) * PS + lr], sT[(32 + 2 * s + lk) * PP + 32 * tj + lr], acc);
+      BF_UNROLL for (int r = 0; r < 16; ++r) sT[c_row(r, lane) * PP + 32 * tj + lr] = acc[r];
+    }
+    __syncthreads();
+    // ================= phase G: -(K S) = -(X^T S), row block `wave` (waves 0,1); m+ (wave 2)
+    if (wave < 2) {
+      f32x16 acc = {0};
+      BF_UNROLL for (int s = 0; s < 16; ++s)
+          acc = mfma2(sT[(2 * s + lk) * PP + 32 * wave + lr], sS[(2 * s + lk) * PS + lr], acc);
+      BF_UNROLL for (int r = 0; r < 16; ++r) sKS[(32 * wave + c_row(r, lane)) * PS + lr] = -acc[r];
+    } else if (wave == 2) {
+      float s = mcur[lane];
+      BF_UNROLL for (int a = 0; a < M; ++a) s = fmaf(sT[a * PP + lane], sv[a], s);
+      mnxt[lane] = s;  // filtered mean
+    }
+    __syncthreads();
+    // ================= phase H: P+ = P - (K S) X (all waves; K = 32); emit filtered streams
+    BF_UNROLL for (int s = 0; s < 16; ++s)
+        Pacc = mfma2(sKS[(32 * ti + lr) * PS + 2 * s + lk], sT[(2 * s + lk) * PP + 32 * tj + lr], Pacc);
+    BF_UNROLL for (int r = 0; r < 16; ++r) sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = Pacc[r];
+    if (out.P.p) BF_UNROLL for (int r = 0; r < 16; ++r)
+        out.P.p[b * out.P.sB + t * out.P.sT + ((32 * ti + c_row(r, lane)) * N + 32 * tj + lr) * out.P.sE] = Pacc[r];
+    if (wave == 2 && out.m.p) out.m.p[b * out.m.sB + t * out.m.sT + lane * out.m.sE] = mnxt[lane];
+    if (wave == 1 && lane == 0) {
+      w = reweight_single(ll, w);
+      if (out.w.p) out.w.p[b * out.w.sB + t * out.w.sT] = w;
+      if (out.ll.p) out.ll.p[b * out.ll.sB + t * out.ll.sT] = ll;
+    }
+    __syncthreads();
+    // ================= phase I: A P+ -> sT (all waves; K = 64); m- = A m+ + G q0 (waves 0, 3)
+    {
+      f32x16 acc = {0};
+      BF_UNROLL for (int s = 0; s < 32; ++s) acc = mfma2(Ati[s], sP[(2 * s + lk) * PP + 32 * tj + lr], acc);
+      BF_UNROLL for (int r = 0; r < 16; ++r) sT[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = acc[r];
+    }
+    if (wave == 0 || wave == 3) {
+      float s = 0.f;
+      BF_UNROLL for (int q = 0; q < 32; ++q) s = fmaf(Ati[q], mnxt[2 * q + lk], s);
+      s += __shfl_xor(s, 32, 64);
+      if (lane < 32) mcur[32 * ti + lane] = s + cst->Gq0[32 * ti + lane];  // predicted mean
+    }
+    __syncthreads();
+    // ================= phase J: P- = (A P+) A^T + G Q G^T (all waves; K = 64); emit predicted streams
+    Pacc = gqg;
+    BF_UNROLL for (int s = 0; s < 32; ++s) Pacc = mfma2(sT[(32 * ti + lr) * PP + 2 * s + lk], Atj[s], Pacc);
+    BF_UNROLL for (int r = 0; r < 16; ++r) sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = Pacc[r];
+    if (out.pP.p) BF_UNROLL for (int r = 0; r < 16; ++r)
+        out.pP.p[b * out.pP.sB + t * out.pP.sT + ((32 * ti + c_row(r, lane)) * N + 32 * tj + lr) * out.pP.sE] = Pacc[r];
+    if (wave == 2 && out.pm.p) out.pm.p[b * out.pm.sB + t * out.pm.sT + lane * out.pm.sE] = mcur[lane];
+    __syncthreads();
+  }
+
+  if (carry.P_out) BF_UNROLL for (int r = 0; r < 16; ++r)
+      carry.P_out[b * N * N + (32 * ti + c_row(r, lane)) * N + 32 * tj + lr] = Pacc[r];
+  if (carry.m_out && tid < N) carry.m_out[b * N + tid] = mcur[tid];
+  if (carry.w_out && wave == 1 && lane == 0) carry.w_out[b] = w;
+}
+
+// ---------------------------------------------------------------------------------------
+int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
+                   const bf_out_desc* out, hipStream_t stream) {
+  constexpr int N = 64, M = 32;
+  if (p->n != N || p->m != M) return set_error(BF_EUNSUPPORTED, "MFMA Kalman kernel is compiled for n = 64, m = 32");
+  if (p->Q_steps > 1 || p->R_steps > 1)
+    return set_error(BF_EUNSUPPORTED, "time-varying Q/R are not supported on the MFMA Kalman kernel");
+  const int dq = p->dq, dr = p->dr;
+  MfmaConst<N, M>* h = new MfmaConst<N, M>;
+  auto Gat = [&](int i, int k) { return p->G ? p->G[i * dq + k] : (i == k ? 1.f : 0.f); };
+  auto Dat = [&](int i, int k) { return p->D ? p->D[i * dr + k] : (i == k ? 1.f : 0.f); };
+  for (int i = 0; i < N * N; ++i) h->A[i] = p->A[i];
+  for (int i = 0; i < M * N; ++i) h->H[i] = p->H[i];
+  {  // (G Q) G^T and (D R) D^T, association of inference.py:69,:100
+    float* GQ = new float[(size_t)N * dq];
+    for (int i = 0; i < N; ++i)
+      for (int l = 0; l < dq; ++l) {
+        float s = 0.f;
+        for (int k = 0; k < dq; ++k) s = fmaf(Gat(i, k), p->Q[k * dq + l], s);
+        GQ[i * dq + l] = s;
+      }
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < N; ++j) {
+        float s = 0.f;
+        for (int l = 0; l < dq; ++l) s = fmaf(GQ[i * dq + l], Gat(j, l), s);
+        h->GQG[i * N + j] = s;
+      }
+    delete[] GQ;
+    float* DRm = new float[(size_t)M * dr];
+    for (int i = 0; i < M; ++i)
+      for (int l = 0; l < dr; ++l) {
+        float s = 0.f;
+        for (int k = 0; k < dr; ++k) s = fmaf(Dat(i, k), p->R[k * dr + l], s);
+        DRm[i * dr + l] = s;
+      }
+    for (int i = 0; i < M; ++i)
+      for (int j = 0; j < M; ++j) {
+        float s = 0.f;
+        for (int l = 0; l < dr; ++l) s = fmaf(DRm[i * dr + l], Dat(j, l), s);
+        h->DRD[i * M + j] = s;
+      }
+    delete[] DRm;
+  }
+  for (int i = 0; i < N; ++i) {
+    float s = 0.f;
+    for (int k = 0; k < dq; ++k) s = fmaf(Gat(i, k), p->q0 ? p->q0[k] : 0.f, s);
+    h->Gq0[i] = s;
+  }
+  for (int i = 0; i < M; ++i) {
+    float s = 0.f;
+    for (int k = 0; k < dr; ++k) s = fmaf(Dat(i, k), p->r0 ? p->r0[k] : 0.f, s);
+    h->Dr0[i] = s;
+  }
+  MfmaConst<N, M>* d = nullptr;
+  hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&d), sizeof(*h), stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d, h, sizeof(*h), hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  delete h;
+  BF_HIP_CHECK(e);
+
+  CView yv{y->ptr, y->sB, y->sT, y->sE};
+  CarryView cv{carry->w_in, carry->m_in, carry->P_in, carry->w_out, carry->m_out, carry->P_out};
+  OutViews ov{make_sview(out->weights), make_sview(out->means), make_sview(out->covs),
+              make_sview(out->pred_means), make_sview(out->pred_covs), make_sview(out->loglik)};
+  const size_t lds_bytes = sizeof(float) * (size_t)(2 * N * (N + 1) + N * (M + 1) + 2 * M * (M + 1) + 2 * N + 2 * M);
+  auto kern = kf_scan_mfma_kernel<N, M>;
+  if (lds_bytes > 64 * 1024)
+    BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(256), lds_bytes, stream, d, yv, cv, ov, B, T);
+  hipError_t le = hipGetLastError();
+  hipError_t fe = hipFreeAsync(d, stream);
+  BF_HIP_CHECK(le);
+  BF_HIP_CHECK(fe);
+  return BF_OK;
+}
+
+}  // namespace bf

@@ -107,3 +107,32 @@ def test_errors_are_loud():
     assert e.value.code == _lib.BF_EUNSUPPORTED
     with pytest.raises(TypeError):
         bfa.kalman_filter(cm.product_params(a)._replace(dynamics_function=lambda x, q, u: x), ys)
+
+
+def test_mfma_path_n64_m32():
+    """cfg5 shape: dense random-stable LGSSM n = 64, m = 32 on the fp32 matrix-core kernel.  The
+    C port of the oracle (validated against the NumPy oracle in tests/test_oracle_filters.py) is the
+    checker; a few trajectories also run through the NumPy oracle itself."""
+    import bayesianfiltering_amd as bfa
+    from oracle import c_oracle
+    a = cm.random_stable_lgssm(64, 32, seed=64, bias=True)
+    a["Q"] = (1e-2 * np.eye(64)).astype(np.float32)
+    a["R"] = (1e-1 * np.eye(32)).astype(np.float32)
+    B, T = 6, 24
+    ys = cm.simulate_batch(a, B, T, seed=9)
+    init = np.tile(a["m0"], (B, 1))
+    ref = c_oracle.kalman_filter(a, ys, init)
+    post, ll, carry = bfa.kalman_filter(cm.product_params(a), ys, initial_means=init, return_loglik=True, return_carry=True)
+    for k in FIELDS:
+        got = getattr(post, k).cpu().numpy()
+        assert got.shape == ref[k].shape
+        assert cm.rel_err(got, ref[k]) < TOL, (k, cm.rel_err(got, ref[k]))
+    assert cm.rel_err(ll.cpu().numpy(), ref["loglik"]) < 2e-5
+    ref_np = cm.oracle_kalman_batch(a, ys[:1], init[:1])
+    assert cm.rel_err(post.covariances[:1].cpu().numpy(), ref_np["covariances"]) < TOL
+    # the carry continues the scan bit for bit
+    p1, c1 = bfa.kalman_filter(cm.product_params(a), ys[:, :10], initial_means=init, return_carry=True)
+    p2 = bfa.kalman_filter(cm.product_params(a), ys[:, 10:], carry=c1)
+    whole = post.predicted_covariances.cpu().numpy()
+    parts = np.concatenate([p1.predicted_covariances.cpu().numpy(), p2.predicted_covariances.cpu().numpy()], axis=2)
+    assert np.array_equal(whole, parts)
