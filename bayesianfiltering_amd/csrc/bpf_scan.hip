@@ -16,7 +16,7 @@
 //   * max / sum over particles: thread-local adjacent-pair tree, xor-butterfly across lanes
 //     (adjacent lanes first), then across waves through LDS -- the adjacent-pair tree of the
 //     oracle's sum, so the normalised weights feed the CDF with identical rounding;
-//   * CDF: workgroup Brent-Kung scan == lax.associative_scan(add) order (oracle/threefry.py
+//   * CDF: workgroup Brent-Kung scan == lax.associative_scan(add) order (the cumsum_assoc of the test oracle
 //     cumsum_assoc), kept in LDS; inverse-CDF draw r_i = c[N-1] * (1 - u_i) and a binary search
 //     per slot (searchsorted side='left');
 //   * gather x <- x[idx]: through an LDS tile, DCH state dimensions per pass.
@@ -150,7 +150,7 @@ __device__ __forceinline__ void emi_value(const BpfModel<N, DQ, M>& p, const flo
 
 // Ancestor indices of utils.py:210: idx = choice(key, N, (N,), p = w) = searchsorted(cumsum(w), c[N-1] * (1 - u)),
 // with the CDF in lax.associative_scan order (== Brent-Kung: thread tree, wave up-sweep,
-// cross-wave scan, down-sweeps) so that it matches oracle/threefry.py:cumsum_assoc bit for bit.
+// cross-wave scan, down-sweeps) so that it matches the test oracle (cumsum_assoc) bit for bit.
 // resampler 1 = systematic positions (i + u0) / N instead of N independent uniforms.
 template <int PPT, int NW>
 __device__ __forceinline__ void resample_indices(const float* wn, const bool* valid, int NP, U32x2 kc, int resampler,
