@@ -24,6 +24,8 @@ int launch_kf_group(const bf_lgssm* p, const bf_cstream* y, long long B, long lo
 
 int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
                    const bf_out_desc* out, hipStream_t stream);
+int launch_collapse(const bf_stream* w, const bf_stream* m, const bf_stream* P, long long B, long long T, int K, int n,
+                    float* mean_out, float* cov_out, hipStream_t stream);
 int launch_gsf_ekf(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int K,
                    const bf_carry* carry, const bf_out_desc* out, hipStream_t stream, int force_mode);
 
@@ -112,6 +114,15 @@ int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream*
   if (!y->ptr) return bf::set_error(BF_EINVAL, "observations pointer is NULL");
   if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
   return bf::launch_gsf_ekf(model, y, u, B, T, K, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode);
+}
+
+int bf_collapse_f32(const bf_stream* weights, const bf_stream* means, const bf_stream* covs, int64_t B, int64_t T,
+                    int32_t K, int32_t n, float* mean_out, float* cov_out, void* stream) {
+  if (!weights || !means || !weights->ptr || !means->ptr) return bf::set_error(BF_EINVAL, "weights and means are required");
+  if (cov_out && (!covs || !covs->ptr)) return bf::set_error(BF_EINVAL, "cov_out needs the covariance stream");
+  if (B <= 0 || T <= 0 || K <= 0 || n <= 0) return bf::set_error(BF_EINVAL, "non-positive size");
+  if (!mean_out && !cov_out) return bf::set_error(BF_EINVAL, "nothing to compute");
+  return bf::launch_collapse(weights, means, covs, B, T, K, n, mean_out, cov_out, static_cast<hipStream_t>(stream));
 }
 
 int bf_bpf_f32(const bf_bpf_model* model, const bf_cstream* y, const bf_cstream* u, int64_t B, int64_t T, int32_t N,

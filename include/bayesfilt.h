@@ -142,6 +142,13 @@ typedef struct bf_model {
 int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream* u, int64_t B, int64_t T, int32_t K,
                    const bf_carry* carry, const bf_out_desc* out, void* stream);
 
+/* Moment-matching collapse of the mixture posterior per (trajectory, step): gaussfiltax/utils.py:10-18
+ * and the point estimate sum_k w_k m_k (docs/experiments/BOT_Experiment_script.py:101).  weights /
+ * means / covs are the strided streams a filter emitted (covs may be NULL when cov_out is NULL);
+ * mean_out [B][T][n], cov_out [B][T][n][n] contiguous DEVICE buffers (either may be NULL). */
+int bf_collapse_f32(const bf_stream* weights, const bf_stream* means, const bf_stream* covs, int64_t B, int64_t T,
+                    int32_t K, int32_t n, float* mean_out, float* cov_out, void* stream);
+
 /* ---- bootstrap particle filter ------------------------------------------------------- */
 /* ParamsBPF (gaussfiltax/models.py:55-84): the state-space model plus the Gaussian emission
  * log-density  MVN(h(x, r_eval, u), lp_cov).log_prob(y)  (the form of every `*lp` function of the

@@ -194,3 +194,26 @@ def test_gsf_errors():
     with pytest.raises(_lib.BayesFiltError) as e:
         bfa.gaussian_sum_filter(cm.product_params(a), ys, 300, initial_means=np.zeros((300, 4), F32))   # > 256 lanes
     assert e.value.code == _lib.BF_EUNSUPPORTED
+
+
+def test_collapse_matches_reference_formula():
+    """utils.collapse (gaussfiltax/utils.py:10-18) and the per-step collapse of a GSF posterior."""
+    bfa, nl = _nl()
+    rng = np.random.default_rng(0)
+    K, n = 5, 3
+    means = rng.normal(size=(K, n)).astype(F32)
+    L = rng.normal(size=(K, n, n)); covs = (L @ L.transpose(0, 2, 1) + np.eye(n)).astype(F32)
+    w = rng.random(K).astype(F32); w /= w.sum()
+    mu, cov = bfa.utils.collapse(means, covs, w)
+    mu_ref, cov_ref = go.collapse(means.astype(np.float64), covs.astype(np.float64), w.astype(np.float64))
+    assert cm.rel_err(mu.cpu().numpy(), mu_ref) < 1e-6 and cm.rel_err(cov.cpu().numpy(), cov_ref) < 1e-6
+    d = np.load(f"{cm.__file__.rsplit('/', 1)[0]}/golden/gsf_lorenz63_K4_T32.npz")
+    p = bfa.ParamsNLSSM(np.array([0.0, 1.0, 1.05], F32), np.eye(3, dtype=F32), nl.lorenz63(), np.zeros(3, F32),
+                        0.1 * np.eye(3, dtype=F32), nl.quadratic(3, 0.05), np.zeros(1, F32), np.eye(1, dtype=F32))
+    post = bfa.gaussian_sum_filter(p, d["emissions"], 4, 1, initial_means=d["initial_means"])
+    mean_t, cov_t = bfa.utils.collapse_posterior(post)
+    pe = np.sum(d["means"] * d["weights"][..., None], axis=0)          # BOT_Experiment_script.py:101
+    assert cm.rel_err(mean_t.cpu().numpy(), pe) < 1e-5
+    t = 17
+    _, c_ref = go.collapse(d["means"][:, t].astype(np.float64), d["covariances"][:, t].astype(np.float64), d["weights"][:, t].astype(np.float64))
+    assert cm.rel_err(cov_t[t].cpu().numpy(), c_ref) < 1e-5
