@@ -1,14 +1,14 @@
 """bayesianfiltering_amd: MI355X-native batched Bayesian filtering (Kalman / Gaussian-sum /
 bootstrap particle filters) behind the call surface of the reference package ``gaussfiltax``
 (kostastsa/BayesianFiltering).  See DESIGN.md for the hot path and its boundary."""
-from .models import ParamsNLSSM, ParamsBPF
+from .models import ParamsNLSSM, ParamsBPF, NonlinearSSM
 from .containers import GaussianComponent, GaussianSum
 from .inference import (PosteriorGaussianSumFiltered, gaussian_sum_filter, kalman_filter, FilterCarry,
                         FULL5, FILTERED, PRNGKey, sample_initial_component_means,
                         bootstrap_particle_filter, ParticleCarry, resample_indices)
 from . import nonlinearities, utils
 
-__all__ = ["ParamsNLSSM", "ParamsBPF", "GaussianComponent", "GaussianSum", "PosteriorGaussianSumFiltered",
+__all__ = ["ParamsNLSSM", "ParamsBPF", "NonlinearSSM", "GaussianComponent", "GaussianSum", "PosteriorGaussianSumFiltered",
            "gaussian_sum_filter", "kalman_filter", "FilterCarry", "FULL5", "FILTERED", "PRNGKey",
            "sample_initial_component_means", "bootstrap_particle_filter", "ParticleCarry", "resample_indices",
            "nonlinearities", "utils"]

@@ -32,6 +32,8 @@ int launch_gsf_ekf(const bf_model* p, const bf_cstream* y, const bf_cstream* u, 
 int launch_bpf(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP,
                float ess, int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o,
                hipStream_t stream);
+int launch_sample_ssm(const bf_bpf_model* bp, const uint32_t* d_keys, const bf_cstream* u, long long B, long long T,
+                      float* d_states, float* d_emis, hipStream_t stream);
 int launch_resample(const float* d_w, const uint32_t* d_keys, long long B, int NP, int resampler, int* d_idx,
                     hipStream_t stream);
 
@@ -135,6 +137,14 @@ int bf_bpf_f32(const bf_bpf_model* model, const bf_cstream* y, const bf_cstream*
   if (resampler != 0 && resampler != 1) return bf::set_error(BF_EINVAL, "resampler must be 0 (multinomial) or 1 (systematic)");
   if (carry && carry->x_in && !carry->w_in) return bf::set_error(BF_EINVAL, "carry.x_in needs carry.w_in");
   return bf::launch_bpf(model, y, u, B, T, N, ess_threshold, resampler, key, carry, out, static_cast<hipStream_t>(stream));
+}
+
+int bf_sample_ssm_f32(const bf_bpf_model* model, const uint32_t* d_keys, const bf_cstream* u, int64_t B, int64_t T,
+                      float* d_states, float* d_emissions, void* stream) {
+  if (!model || !d_keys || (!d_states && !d_emissions)) return bf::set_error(BF_EINVAL, "NULL argument");
+  if (B <= 0 || T <= 0) return bf::set_error(BF_EINVAL, "B and T must be positive");
+  if (!model->ssm.Q || !model->ssm.R || !model->m0 || !model->P0) return bf::set_error(BF_EINVAL, "Q, R, m0, P0 are required");
+  return bf::launch_sample_ssm(model, d_keys, u, B, T, d_states, d_emissions, static_cast<hipStream_t>(stream));
 }
 
 int bf_resample_f32(const float* d_w, const uint32_t* d_keys, int64_t B, int32_t N, int32_t resampler, int32_t* d_idx,

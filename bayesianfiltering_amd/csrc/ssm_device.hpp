@@ -1,0 +1,206 @@
+// Device-side state-space model for the sampling kernels (particle filter, data generator):
+// the registry functions' VALUES (no Jacobians), the Cholesky factors the Gaussian draws and the
+// emission log-density need, and the host code that fills them from the C-ABI structs.
+#pragma once
+#include <cstring>
+#include "bf_common.hpp"
+#include "kf_math.hpp"
+#include "models.hpp"
+
+namespace bf {
+
+template <int N, int DQ, int M>
+struct BpfModel {
+  int dyn_id, emi_id, g_identity, pad_;
+  float dth[8], eth[8];
+  float A[N * N];     // linear dynamics
+  float Gm[N * DQ];   // F_q (noise input matrix); identity when g_identity
+  float Hm[M * N];    // linear emission
+  float q0[DQ];
+  float LQ[DQ * DQ];  // chol(Q), lower
+  float hb[M];        // emission bias term evaluated at r_eval (H_r r_eval)
+  float LR[M * M];    // chol(R_lp), lower, of the log-prob covariance
+  float rdLR[M];      // 1 / diag(LR)
+  float lp_const;     // -0.5 m log(2 pi) - sum log diag(LR)
+  float m0[N];
+  float L0[N * N];    // chol(P0), lower
+};
+
+// value of f(x, q, u) for the registry dynamics (additive noise through F_q)
+template <int N, int DQ, int M>
+__device__ __forceinline__ void dyn_value(const BpfModel<N, DQ, M>& p, const float* x, const float* q, float u0, float* out) {
+  switch (p.dyn_id) {
+    case DYN_LINEAR: mv<N, N>(p.A, x, out); break;
+    case DYN_LORENZ96: {
+      const float alpha = p.dth[0], beta = p.dth[1], gamma = p.dth[2], dt = p.dth[3];
+      const bool mp = p.dth[4] != 0.f;
+      BF_UNROLL for (int i = 0; i < N; ++i) {
+        const float ax = x[(i + N - 1) % N];
+        const float bx = mp ? (x[(i + 1) % N] - x[(i + 2 * N - 2) % N]) : 0.f;
+        out[i] = x[i] + dt * (alpha * (ax * bx) - beta * x[i] + gamma);
+      }
+    } break;
+    case DYN_LORENZ63:
+      if constexpr (N == 3) {
+        const float s = p.dth[0], r = p.dth[1], b = p.dth[2], dt = p.dth[3];
+        out[0] = dt * s * (x[1] - x[0]) + x[0];
+        out[1] = dt * (x[0] * r - x[1] - x[0] * x[2]) + x[1];
+        out[2] = dt * (x[0] * x[1] - b * x[2]) + x[2];
+      }
+      break;
+    case DYN_MANEUVER_BOT:
+      if constexpr (N == 4) {
+        const float dt = p.dth[0], acc = p.dth[1];
+        const float c0 = 0.5f * (u0 - 1.f) * (u0 - 2.f), c1 = -u0 * (u0 - 2.f), c2 = 0.5f * u0 * (u0 - 1.f);
+        float Mx[16] = {c0, c0 * dt, 0, 0, 0, c0, 0, 0, 0, 0, c0, c0 * dt, 0, 0, 0, c0};
+        const float nrm = sqrtf(x[1] * x[1] + x[3] * x[3]);
+        BF_UNROLL for (int sgn = 0; sgn < 2; ++sgn) {
+          const float cc = sgn == 0 ? c1 : c2;
+          const float om = 0.1f * (sgn == 0 ? acc : -acc) / nrm;
+          const float sn = sinf(dt * om), cs = cosf(dt * om);
+          const float so = sn / om, co = (1.f - cs) / om;
+          const float Fm[16] = {1, so, 0, -co, 0, cs, 0, -sn, 0, co, 1, so, 0, sn, 0, cs};
+          BF_UNROLL for (int i = 0; i < 16; ++i) Mx[i] += cc * Fm[i];
+        }
+        mv<4, 4>(Mx, x, out);
+      }
+      break;
+    case DYN_SINE: BF_UNROLL for (int i = 0; i < N; ++i) out[i] = sinf(p.dth[0] * x[i]); break;
+    case DYN_GROWTH:
+      if constexpr (N == 1) out[0] = x[0] / 2.0f + 25.0f * x[0] / (1.f + x[0] * x[0]) + u0;
+      break;
+    default: BF_UNROLL for (int i = 0; i < N; ++i) out[i] = x[i]; break;
+  }
+  if (p.g_identity) {
+    if constexpr (DQ == N) BF_UNROLL for (int i = 0; i < N; ++i) out[i] += q[i];
+  } else {
+    BF_UNROLL for (int i = 0; i < N; ++i) {
+      float s = 0.f;
+      BF_UNROLL for (int k = 0; k < DQ; ++k) s = fmaf(p.Gm[i * DQ + k], q[k], s);
+      out[i] += s;
+    }
+  }
+}
+
+// mean of the emission density: h(x, r_eval, u) for the registry emissions with constant H_r
+template <int N, int DQ, int M>
+__device__ __forceinline__ void emi_value(const BpfModel<N, DQ, M>& p, const float* x, float u0, float* hx) {
+  switch (p.emi_id) {
+    case EMI_LINEAR: mv<M, N>(p.Hm, x, hx); break;
+    case EMI_BEARING_RANGE:
+      if constexpr (N == 4 && M == 2) {
+        hx[0] = atan2f(x[2], x[0]);
+        hx[1] = sqrtf(x[0] * x[0] + x[2] * x[2]);
+      }
+      break;
+    case EMI_QUADRATIC:
+      if constexpr (M == 1) {
+        float s = 0.f;
+        BF_UNROLL for (int i = 0; i < N; ++i) s = fmaf(x[i], x[i], s);
+        hx[0] = p.eth[0] * s;
+      }
+      break;
+    default: BF_UNROLL for (int a = 0; a < M; ++a) hx[a] = 0.f; break;
+  }
+  BF_UNROLL for (int a = 0; a < M; ++a) hx[a] += p.hb[a];
+}
+
+static inline int cholesky_lower(const float* A, int n, float* L) {  // fp32, row-major; returns 0 or -1 (not PD)
+  for (int i = 0; i < n * n; ++i) L[i] = 0.f;
+  for (int j = 0; j < n; ++j) {
+    float d = A[j * n + j];
+    for (int k = 0; k < j; ++k) d -= L[j * n + k] * L[j * n + k];
+    if (!(d > 0.f)) return -1;
+    d = sqrtf(d);
+    L[j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      float s = A[i * n + j];
+      for (int k = 0; k < j; ++k) s -= L[i * n + k] * L[j * n + k];
+      L[i * n + j] = s / d;
+    }
+  }
+  return 0;
+}
+
+template <int N, int DQ, int M>
+static inline int fill_bpf_model(const bf_bpf_model* bp, BpfModel<N, DQ, M>& e) {
+  const bf_model* p = &bp->ssm;
+  std::memset(&e, 0, sizeof(e));
+  e.dyn_id = p->dyn_id;
+  e.emi_id = p->emi_id;
+  e.g_identity = 1;
+  const float* th = p->dyn_theta;
+  switch (p->dyn_id) {
+    case DYN_LINEAR:
+      if (p->n_dyn_theta != N * N + N * DQ) return set_error(BF_EINVAL, "linear dynamics: theta must hold A and G");
+      for (int i = 0; i < N * N; ++i) e.A[i] = th[i];
+      for (int i = 0; i < N * DQ; ++i) e.Gm[i] = th[N * N + i];
+      e.g_identity = 0;
+      break;
+    case DYN_LORENZ96:
+      if (p->n_dyn_theta != 5 || DQ != N) return set_error(BF_EINVAL, "lorenz96: theta = (alpha, beta, gamma, dt, mode), dq = n");
+      for (int i = 0; i < 5; ++i) e.dth[i] = th[i];
+      break;
+    case DYN_LORENZ63:
+      if (N != 3 || p->n_dyn_theta != 4 || DQ != 3) return set_error(BF_EINVAL, "lorenz63: n = dq = 3");
+      for (int i = 0; i < 4; ++i) e.dth[i] = th[i];
+      break;
+    case DYN_MANEUVER_BOT: {
+      if (N != 4 || p->n_dyn_theta != 2 || DQ != 2) return set_error(BF_EINVAL, "maneuver_bot: n = 4, dq = 2");
+      e.dth[0] = th[0];
+      e.dth[1] = th[1];
+      const float Gb[8] = {0.5f, 0, 1, 0, 0, 0.5f, 0, 1};
+      for (int i = 0; i < 8 && i < N * DQ; ++i) e.Gm[i] = Gb[i];
+      e.g_identity = 0;
+    } break;
+    case DYN_SINE:
+      if (p->n_dyn_theta != 1 || DQ != N) return set_error(BF_EINVAL, "sine: theta = (w0), dq = n");
+      e.dth[0] = th[0];
+      break;
+    case DYN_GROWTH:
+      if (N != 1 || DQ != 1) return set_error(BF_EINVAL, "growth: n = dq = 1");
+      break;
+    default: return set_error(BF_EUNSUPPORTED, "unknown dynamics function id %d", p->dyn_id);
+  }
+  th = p->emi_theta;
+  const int dr = p->dr;
+  float D[M * 64] = {0};
+  if (dr > 64) return set_error(BF_EUNSUPPORTED, "emission noise dimension > 64");
+  for (int i = 0; i < M; ++i)
+    for (int k = 0; k < dr; ++k) D[i * dr + k] = (i == k) ? 1.f : 0.f;
+  switch (p->emi_id) {
+    case EMI_LINEAR:
+      if (p->n_emi_theta != M * N + M * dr) return set_error(BF_EINVAL, "linear emission: theta must hold H and D");
+      for (int i = 0; i < M * N; ++i) e.Hm[i] = th[i];
+      for (int i = 0; i < M * dr; ++i) D[i] = th[M * N + i];
+      break;
+    case EMI_BEARING_RANGE:
+      if (N != 4 || M != 2 || dr != 2) return set_error(BF_EINVAL, "bearing_range: n = 4, m = dr = 2");
+      break;
+    case EMI_QUADRATIC:
+      if (M != 1 || dr != 1 || p->n_emi_theta != 1) return set_error(BF_EINVAL, "quadratic: m = dr = 1");
+      e.eth[0] = th[0];
+      break;
+    default:
+      return set_error(BF_EUNSUPPORTED, "emission function id %d has no Gaussian log-density with constant covariance", p->emi_id);
+  }
+  for (int i = 0; i < M; ++i) {
+    float s = 0.f;
+    for (int k = 0; k < dr; ++k) s = fmaf(D[i * dr + k], bp->r_eval ? bp->r_eval[k] : 0.f, s);
+    e.hb[i] = s;
+  }
+  for (int i = 0; i < DQ; ++i) e.q0[i] = p->q0 ? p->q0[i] : 0.f;
+  if (cholesky_lower(p->Q, DQ, e.LQ) != 0) return set_error(BF_EINVAL, "dynamics noise covariance is not positive definite");
+  if (cholesky_lower(bp->lp_cov, M, e.LR) != 0) return set_error(BF_EINVAL, "log-prob covariance is not positive definite");
+  float logdet = 0.f;
+  for (int i = 0; i < M; ++i) {
+    e.rdLR[i] = 1.0f / e.LR[i * M + i];
+    logdet += logf(e.LR[i * M + i]);
+  }
+  e.lp_const = -0.5f * (float)M * 1.8378770664093453f - logdet;
+  for (int i = 0; i < N; ++i) e.m0[i] = bp->m0[i];
+  if (cholesky_lower(bp->P0, N, e.L0) != 0) return set_error(BF_EINVAL, "initial covariance is not positive definite");
+  return BF_OK;
+}
+
+}  // namespace bf

@@ -198,6 +198,13 @@ int bf_bpf_f32(const bf_bpf_model* model, const bf_cstream* y, const bf_cstream*
                const uint32_t key[2], float ess_threshold, int32_t resampler, const bf_bpf_carry* carry,
                const bf_bpf_out* out, void* stream);
 
+/* Synthetic data: NonlinearSSM.sample (gaussfiltax/models.py:240-289) for B trajectories, one key
+ * per trajectory (d_keys [B][2], DEVICE).  model->ssm carries f, h, q0, Q, r0, R; model->m0 / P0 the
+ * initial law (lp_cov / r_eval unused).  d_states [B][T][n], d_emissions [B][T][m] contiguous
+ * DEVICE buffers (either may be NULL). */
+int bf_sample_ssm_f32(const bf_bpf_model* model, const uint32_t* d_keys, const bf_cstream* u, int64_t B, int64_t T,
+                      float* d_states, float* d_emissions, void* stream);
+
 /* Index draw of utils.py:210 alone: d_idx[b][i] = choice(d_keys[b], N, (N,), p = d_w[b]). */
 int bf_resample_f32(const float* d_w, const uint32_t* d_keys, int64_t B, int32_t N, int32_t resampler,
                     int32_t* d_idx, void* stream);
