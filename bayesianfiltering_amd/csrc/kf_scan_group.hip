@@ -60,7 +60,7 @@ struct GroupCfg {
   static constexpr int WW = 16 > WMIN ? 16 : WMIN;
   using TP = Tile<EP, WP, CPW, 4>;
   using TM = Tile<NS, WM, CPW, 4>;
-  using TW = Tile<1, WW, CPW, 0>;
+  using TW = Tile<1, WW, CPW, (NL == 1 ? 0 : 4)>;  // NL = 1 fills the 160 KiB exactly without the pad
   // observation blocks: YS steps (>= 8 floats per trajectory) fetched by LDS-DMA one block ahead
   static constexpr int YS = (M >= 8) ? 1 : 8 / M;
   static constexpr int YW = YS * M;               // floats per trajectory per block
@@ -147,7 +147,7 @@ kf_scan_group_kernel(KFConst<NS, M> c, const float* __restrict__ gqg_t, const fl
     ysrc[i] = y.p + bb * y.sB + (long long)(f % M) * y.sE;
   }
   const unsigned ybase = lds_byte_addr(lds + oY);
-  auto y_fetch = [&](long long tb, int buf) {
+  auto y_fetch = [&](long long tb, int buf) __attribute__((always_inline)) {
     BF_UNROLL for (int i = 0; i < Cfg::YDMA; ++i) {
       const int e = lane + 64 * i;
       const int f = e % Cfg::YW;
@@ -159,14 +159,16 @@ kf_scan_group_kernel(KFConst<NS, M> c, const float* __restrict__ gqg_t, const fl
   };
 
   // ---- one filter step
-  auto step = [&](long long t) {
+  auto step = [&](long long t) __attribute__((always_inline)) {
     const int ys = (int)(t % YS);
     const int ybuf = (int)((t / YS) & 1);
     float yv[M];
     BF_UNROLL for (int a = 0; a < M; ++a) yv[a] = lds[oY + ybuf * Cfg::YBUF + g * Cfg::YW + ys * M + a];
 
-    float gqv[CPL][NS], dr[M * M];
-    const float* DRD = c.DRD;
+    // (values are copied, never selected through a pointer: a pointer that may address either a
+    // kernel argument or a private array becomes a flat pointer and defeats register promotion)
+    float gqv[CPL][NS], DRD[M * M];
+    BF_UNROLL for (int i = 0; i < M * M; ++i) DRD[i] = c.DRD[i];
     if constexpr (TV) {
       if (gqg_t) {
         BF_UNROLL for (int cc = 0; cc < CPL; ++cc) BF_UNROLL for (int i = 0; i < NS; ++i)
@@ -174,10 +176,7 @@ kf_scan_group_kernel(KFConst<NS, M> c, const float* __restrict__ gqg_t, const fl
       } else {
         BF_UNROLL for (int cc = 0; cc < CPL; ++cc) BF_UNROLL for (int i = 0; i < NS; ++i) gqv[cc][i] = Gcol[cc][i];
       }
-      if (drd_t) {
-        BF_UNROLL for (int i = 0; i < M * M; ++i) dr[i] = drd_t[t * M * M + i];
-        DRD = dr;
-      }
+      if (drd_t) BF_UNROLL for (int i = 0; i < M * M; ++i) DRD[i] = drd_t[t * M * M + i];
     }
 
     // ================= _condition_on (inference.py:72-105) =================
@@ -309,7 +308,7 @@ kf_scan_group_kernel(KFConst<NS, M> c, const float* __restrict__ gqg_t, const fl
   // final step) also flushes the incomplete rows, chunk-limited.  Both tiles of a pair are
   // read unconditionally so the staging registers never become a conditionally-initialised
   // array (which the compiler would demote to scratch).
-  auto flush_all = [&](long long t1, bool last) {
+  auto flush_all = [&](long long t1, bool last) __attribute__((always_inline)) {
     if constexpr (MODE == EMIT_STAGED) {
       const int remP = (int)(t1 % TP::TS), remM = (int)(t1 % TM::TS), remW = (int)(t1 % TW::TS);
       if (remP == 0 || last) {
@@ -350,15 +349,26 @@ kf_scan_group_kernel(KFConst<NS, M> c, const float* __restrict__ gqg_t, const fl
   // block earlier) is awaited with a counted vmcnt that leaves this wave's newer stores in
   // flight, then the DMA of block k+1 is issued.
   y_fetch(0, 0);
-  for (long long tb = 0; tb < T; tb += YS) {
+  const long long nblk = (T + YS - 1) / YS;
+  for (long long kb = 0; kb < nblk; ++kb) {
+    const long long tb = kb * YS;
     // outstanding, youngest first: [stores of the previous block (>= vm_younger of them)] [DMA of this block]
-    wait_vm(tb == 0 ? 0 : vm_younger);
-    if (tb + YS < T) y_fetch(tb + YS, (int)(((tb / YS) + 1) & 1));
+    wait_vm(kb == 0 ? 0 : vm_younger);
+    if (tb + YS < T) y_fetch(tb + YS, (int)((kb + 1) & 1));
     wave_lds_sync();
-    const long long te = (tb + YS < T) ? tb + YS : T;
-    for (long long t = tb; t < te; ++t) {
-      step(t);
-      if (t + 1 < T) flush_all(t + 1, false);
+    if (tb + YS <= T) {
+      // whole block, unrolled: with t = kb * YS + I the tile slots (t % TS) fold to constants and
+      // the compiler can overlap the tail of one step with the head of the next
+      static_for<0, YS>([&](auto I) __attribute__((always_inline)) {
+        const long long t = kb * YS + decltype(I)::value;
+        step(t);
+        if (t + 1 < T) flush_all(t + 1, false);
+      });
+    } else {
+      for (long long t = tb; t < T; ++t) {
+        step(t);
+        if (t + 1 < T) flush_all(t + 1, false);
+      }
     }
   }
   flush_all(T, true);
@@ -441,8 +451,19 @@ static int launch_nml(const bf_lgssm* p, const bf_cstream* y, long long B, long 
   // the flush addresses the rows of one wave through 32-bit byte offsets from a uniform base
   const bool off32_ok = (double)T * N * N * 4.0 * (Cfg::CPW + 1) < 4.0e9;
   const bool staged_ok = Cfg::STAGED_OK && ref_layout && rows_aligned && off32_ok;
-  int mode = staged_ok ? EMIT_STAGED : EMIT_SCALAR;
+  // the staging tiles of one workgroup (4 waves) must fit the 160 KiB LDS
+  bool lds_ok = true;
+  if constexpr (Cfg::STAGED_OK) {
+    const int nP = (out->covs.ptr ? 1 : 0) + (out->pred_covs.ptr ? 1 : 0);
+    const int nM = (out->means.ptr ? 1 : 0) + (out->pred_means.ptr ? 1 : 0);
+    const int nW = (out->weights.ptr ? 1 : 0) + (out->loglik.ptr ? 1 : 0);
+    const size_t per_wave = 2 * Cfg::YBUF + nP * Cfg::TP::FLOATS + nM * Cfg::TM::FLOATS + nW * Cfg::TW::FLOATS;
+    lds_ok = per_wave * 4 * sizeof(float) <= 160 * 1024;
+  }
+  int mode = (staged_ok && lds_ok) ? EMIT_STAGED : EMIT_SCALAR;
   if (force_mode == EMIT_SCALAR || force_mode == 1) mode = EMIT_SCALAR;
+  if (force_mode == EMIT_STAGED && staged_ok && !lds_ok)
+    return set_error(BF_EINVAL, "staged emitter: the enabled streams need more than 160 KiB of LDS at %d lanes per trajectory", NL);
   if (force_mode == EMIT_STAGED && !staged_ok)
     return set_error(BF_EINVAL, "staged emitter needs the contiguous reference layout, 16-byte aligned rows and n in {1,2,4,8}");
 

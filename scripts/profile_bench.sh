@@ -8,8 +8,7 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" > $out/trace.log 2>&1
-# PMC passes: the same launch (B=65536, T=10000, FULL5) through scripts/kf_one.py -- bench.py's
-# on-device data generator issues ~60k tiny torch kernels, which the counter collector does not survive
+# PMC passes: the same launch (B=65536, T=10000, FULL5) through scripts/kf_one.py
 export PB=65536 PT=10000 PF=full5 PR=2
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $root/scripts/kf_one.py > $out/pmc_write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $root/scripts/kf_one.py > $out/pmc_fetch.log 2>&1
