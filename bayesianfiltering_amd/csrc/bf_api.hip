@@ -37,6 +37,7 @@ int launch_sample_ssm(const bf_bpf_model* bp, const uint32_t* d_keys, const bf_c
 int launch_resample(const float* d_w, const uint32_t* d_keys, long long B, int NP, int resampler, int* d_idx,
                     hipStream_t stream);
 
+extern int g_bpf_variant;
 static int g_kf_emit_mode = -1;  // -1 = choose from the layout
 static int g_kf_lanes = 0;       // 0 = default lanes per trajectory for the (n, m) pair
 
@@ -68,6 +69,11 @@ int bf_set_option(const char* name, int value) {
   if (name && std::strcmp(name, "kf_lanes") == 0) {
     if (value < 0 || value > 64 || (value & (value - 1)) != 0) return bf::set_error(BF_EINVAL, "kf_lanes must be 0 or a power of two <= 64");
     bf::g_kf_lanes = value;
+    return BF_OK;
+  }
+  if (name && std::strcmp(name, "bpf_variant") == 0) {
+    if (value < 0 || value > 1) return bf::set_error(BF_EINVAL, "bpf_variant must be 0 or 1");
+    bf::g_bpf_variant = value;
     return BF_OK;
   }
   return bf::set_error(BF_EINVAL, "unknown option '%s'", name ? name : "(null)");

@@ -347,6 +347,8 @@ static int launch_bpf_cfg(const BpfModel<N, DQ, M>* d_mdl, const bf_cstream* y, 
   return BF_OK;
 }
 
+int g_bpf_variant = 0;  // tuning hook (bf_set_option "bpf_variant")
+
 template <int N, int DQ, int M>
 static int launch_bpf_dims(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
                            int NP, float ess, int resampler, const uint32_t key[2], const BpfCarry& cr, const BpfOut& out,
@@ -366,7 +368,13 @@ static int launch_bpf_dims(const bf_bpf_model* bp, const bf_cstream* y, const bf
   if (NP <= 64) rc = launch_bpf_cfg<N, DQ, M, 1, 1>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
   else if (NP <= 256) rc = launch_bpf_cfg<N, DQ, M, 1, 4>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
   else if (NP <= 1024) rc = launch_bpf_cfg<N, DQ, M, 1, 16>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
-  else if (NP <= 4096) rc = launch_bpf_cfg<N, DQ, M, 4, 16>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
+  else if (NP <= 4096) {
+    // two geometries for the largest capacity: 1024 threads x 4 particles (128-VGPR budget) or
+    // 512 threads x 8 particles (256-VGPR budget); variant 0 = 1024 x 4 is the default
+    // (measured at cfg4's shape: 1024 x 4 = 28.0 ms per 50 steps, 512 x 8 = 33.8 ms)
+    if (g_bpf_variant == 1) rc = launch_bpf_cfg<N, DQ, M, 8, 8>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
+    else rc = launch_bpf_cfg<N, DQ, M, 4, 16>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
+  }
   else rc = set_error(BF_EUNSUPPORTED, "bootstrap particle filter: %d particles exceed the compiled capacity of 4096 per trajectory", NP);
   hipError_t fe = hipFreeAsync(d_mdl, stream);
   if (rc != BF_OK) return rc;

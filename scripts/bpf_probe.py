@@ -10,10 +10,12 @@ g = nl.pick_even(16); R = 0.5 * np.eye(8, dtype=F32)
 p = bfa.ParamsBPF(8 * np.ones(16, F32), np.eye(16, dtype=F32), nl.lorenz96(16), np.zeros(16, F32), 1e-1 * np.eye(16, dtype=F32),
                   g, np.zeros(8, F32), R, nl.gaussian_log_prob(g, R))
 y = 8.0 + torch.randn((B, T, 8), device="cuda")
-for rep in range(3):
+from bayesianfiltering_amd import _lib
+for rep in range(4):
+    _lib.require_gpu().bf_set_option(b"bpf_variant", rep % 2)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     out = bfa.bootstrap_particle_filter(p, y, N, np.array([0, 1], np.uint32), output="summary")
     e.record(); torch.cuda.synchronize()
     ms = s.elapsed_time(e)
-    print(f"B={B} T={T} N={N}: {ms:8.2f} ms  {B*T/ms/1e3:8.3f} Mstep/s  {B*T*N/ms/1e6:8.2f} G particle-steps/s  resampled {out['resampled'].mean().item():.2f}", flush=True)
+    print(f"variant={rep % 2} B={B} T={T} N={N}: {ms:8.2f} ms  {B*T/ms/1e3:8.3f} Mstep/s  {B*T*N/ms/1e6:8.2f} G particle-steps/s  resampled {out['resampled'].mean().item():.2f}", flush=True)
