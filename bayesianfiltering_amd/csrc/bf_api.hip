@@ -27,7 +27,7 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
 int launch_collapse(const bf_stream* w, const bf_stream* m, const bf_stream* P, long long B, long long T, int K, int n,
                     float* mean_out, float* cov_out, hipStream_t stream);
 int launch_gsf_ekf(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int K,
-                   const bf_carry* carry, const bf_out_desc* out, hipStream_t stream, int force_mode);
+                   const bf_carry* carry, const bf_out_desc* out, hipStream_t stream, int force_mode, int lanes);
 
 int launch_bpf(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP,
                float ess, int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o,
@@ -121,7 +121,8 @@ int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream*
   if (!model->Q || !model->R) return bf::set_error(BF_EINVAL, "Q and R are required");
   if (!y->ptr) return bf::set_error(BF_EINVAL, "observations pointer is NULL");
   if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
-  return bf::launch_gsf_ekf(model, y, u, B, T, K, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode);
+  return bf::launch_gsf_ekf(model, y, u, B, T, K, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode,
+                            bf::g_kf_lanes);
 }
 
 int bf_collapse_f32(const bf_stream* weights, const bf_stream* means, const bf_stream* covs, int64_t B, int64_t T,

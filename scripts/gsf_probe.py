@@ -13,8 +13,11 @@ dev = torch.device("cuda")
 y = 8.0 + torch.randn((B, T, 4), device=dev)
 init = 8.0 + torch.randn((B, K, 8), device=dev)
 lib = _lib.require_gpu()
-for fields, name in ((bfa.FULL5, "FULL5"), (bfa.FILTERED, "FILTERED"), ((), "none")):
-    for mode in (-1, 0):
+for lanes in (2, 4, 8):
+  lib.bf_set_option(b"kf_lanes", lanes)
+  print("lanes", lanes)
+  for fields, name in ((bfa.FULL5, "FULL5"), ((), "none")):
+    for mode in (-1,):
         lib.bf_set_option(b"kf_emit_mode", mode)
         post = bfa.gaussian_sum_filter(p, y, K, 1, initial_means=init, fields=fields, return_carry=True)
         torch.cuda.synchronize()
