@@ -136,3 +136,15 @@ def test_mfma_path_n64_m32():
     whole = post.predicted_covariances.cpu().numpy()
     parts = np.concatenate([p1.predicted_covariances.cpu().numpy(), p2.predicted_covariances.cpu().numpy()], axis=2)
     assert np.array_equal(whole, parts)
+
+
+def test_golden_kalman_fixtures(golden_dir):
+    """The committed golden vectors (tests/golden/make_golden.py) through the C-ABI."""
+    import bayesianfiltering_amd as bfa
+    for name in ("kalman_cv_n4_m2_T64", "kalman_random_n3_m3_T40"):
+        d = np.load(f"{golden_dir}/{name}.npz")
+        a = {k: d[k] for k in ("A", "G", "H", "D", "Q", "R", "m0", "P0", "q0", "r0")}
+        post, ll = bfa.kalman_filter(cm.product_params(a), d["emissions"], initial_means=d["initial_means"], return_loglik=True)
+        for k in FIELDS:
+            assert cm.rel_err(getattr(post, k).cpu().numpy(), d["out_" + k]) < TOL, (name, k)
+        assert cm.rel_err(ll.cpu().numpy(), d["out_loglik"]) < 2e-5
