@@ -1,386 +1,10 @@
-// bpf_scan: batched bootstrap particle filter, one workgroup per trajectory.
-//
-// Replaces the lax.scan body of bootstrap_particle_filter (gaussfiltax/inference.py:1330-1377):
-//   keys = split(key, N+1)                                     :1342
-//   x_i  = f(x_i, q0 + chol(Q) normal(keys[1+i]), u)            :1344-1345, models.py:82-84
-//   lls  = emission_distribution_log_prob(x_i, y, u)            :1348-1349
-//   lls -= max; w = exp(lls) * w; w /= sum(w)                   :1350-1353
-//   if 1 / sum(w^2) < ess_threshold * N: _resample              :1356-1357, utils.py:207-214
-// and the initial draw  x_i ~ MVN(m0, P0) with keys[1+i] of split(key, N+1)  (:1369-1373).
-//
-// Mapping (gfx950).  The N particles of a trajectory live in the VGPRs of one workgroup:
-// thread tid owns the PPT consecutive particles tid*PPT .. tid*PPT+PPT-1 (state never leaves
-// registers except to be gathered on a resample).  All randomness is counter-based Threefry
-// evaluated per lane (bf_rng.hpp) with JAX's split / bits layout, so the stream depends only
-// on (key, N), not on the launch geometry.
-//   * max / sum over particles: thread-local adjacent-pair tree, xor-butterfly across lanes
-//     (adjacent lanes first), then across waves through LDS -- the adjacent-pair tree of the
-//     oracle's sum, so the normalised weights feed the CDF with identical rounding;
-//   * CDF: workgroup Brent-Kung scan == lax.associative_scan(add) order (the cumsum_assoc of the test oracle
-//     cumsum_assoc), kept in LDS; inverse-CDF draw r_i = c[N-1] * (1 - u_i) and a binary search
-//     per slot (searchsorted side='left');
-//   * gather x <- x[idx]: through an LDS tile, DCH state dimensions per pass.
-// Outputs: FULL (weights (N,T), particles (N,T,n) per trajectory, the reference's return value,
-// inference.py:1359-1362,1378) and/or SUMMARY per step (weighted mean, ESS, log-evidence
-// increment, resampled flag) -- the full history of cfg4 is 4.6 TB and does not fit HBM.
-#include <cstring>
-#include "bf_common.hpp"
-#include "kf_math.hpp"
-#include "bf_rng.hpp"
-#include "models.hpp"
-#include "ssm_device.hpp"
+// Dispatch of the bootstrap particle filter over the compiled (n, dq, m) table (instantiations in
+// bpf_group_{a,b,c}.hip) and the stand-alone resampler.
+#include "bpf_scan.hpp"
 
 namespace bf {
 
-struct BpfCarry {
-  const float* x_in;       // [B][NP][n] or NULL (draw from N(m0, P0))
-  const float* w_in;       // [B][NP]
-  const uint32_t* key_in;  // [B][2] or NULL (use the launch key for every trajectory)
-  float* x_out;
-  float* w_out;
-  uint32_t* key_out;
-};
-
-struct BpfOut {
-  float* w;                // weights, element (b, i, t) at b*w_sB + i*w_sN + t*w_sT
-  long long w_sB, w_sN, w_sT;
-  float* x;                // particles, element (b, i, t, d) at b*x_sB + i*x_sN + t*x_sT + d
-  long long x_sB, x_sN, x_sT;
-  int* anc;                // ancestors (b, i, t), same strides as w; NULL = not emitted
-  float* mean;             // [B][T][n]   sum_i w_i x_i after the resampling decision
-  float* ess;              // [B][T]      1 / sum w^2 before resampling
-  float* logz;             // [B][T]      log sum_i w_{t-1,i} p(y_t | x_i)
-  float* resampled;        // [B][T]      1.0 if resampled at t
-};
-
-// Ancestor indices of utils.py:210: idx = choice(key, N, (N,), p = w) = searchsorted(cumsum(w), c[N-1] * (1 - u)),
-// with the CDF in lax.associative_scan order (== Brent-Kung: thread tree, wave up-sweep,
-// cross-wave scan, down-sweeps) so that it matches the test oracle (cumsum_assoc) bit for bit.
-// resampler 1 = systematic positions (i + u0) / N instead of N independent uniforms.
-template <int PPT, int NW>
-__device__ __forceinline__ void resample_indices(const float* wn, const bool* valid, int NP, U32x2 kc, int resampler,
-                                                 float* cdf, float* red, int* anc) {
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // CDF in lax.associative_scan order == Brent-Kung: thread tree, wave up-sweep, cross-wave scan, down-sweep
-  float tsum[PPT];  // partial sums of the thread tree: tsum[p] = sum of the aligned block ending at p
-  BF_UNROLL for (int p = 0; p < PPT; ++p) tsum[p] = wn[p];
-  BF_UNROLL for (int s = 1; s < PPT; s <<= 1) BF_UNROLL for (int p = 2 * s - 1; p < PPT; p += 2 * s) tsum[p] += tsum[p - s];
-  float v = tsum[PPT - 1];  // thread total
-  BF_UNROLL for (int d = 0; d < 6; ++d) {  // wave up-sweep
-    const float o = __shfl_up(v, 1 << d, 64);
-    if (((lane + 1) & ((2 << d) - 1)) == 0) v += o;
-  }
-  float excl_wave = 0.f;  // inclusive scan value at the end of the previous wave
-  if constexpr (NW > 1) {
-    __syncthreads();
-    if (lane == 63) red[16 + wave] = v;
-    __syncthreads();
-    float r = (lane < NW) ? red[16 + lane] : 0.f;
-    BF_UNROLL for (int d = 0; (1 << d) < NW; ++d) {  // up-sweep over the NW wave totals
-      const float o = __shfl_up(r, 1 << d, 64);
-      if (lane < NW && ((lane + 1) & ((2 << d) - 1)) == 0) r += o;
-    }
-    BF_UNROLL for (int d = 4; d >= 1; --d) {  // down-sweep
-      if ((1 << d) <= NW) {
-        const float o = __shfl_up(r, 1 << (d - 1), 64);
-        if (lane < NW && lane >= (1 << d) && ((lane + 1) & ((1 << d) - 1)) == (1 << (d - 1))) r += o;
-      }
-    }
-    const float mine = __shfl(r, wave, 64);
-    const float prev = __shfl(r, wave > 0 ? wave - 1 : 0, 64);
-    excl_wave = wave > 0 ? prev : 0.f;
-    if (lane == 63) v = mine;
-  }
-  BF_UNROLL for (int d = 6; d >= 1; --d) {  // wave down-sweep (virtual lane -1 = excl_wave)
-    const float o = __shfl_up(v, 1 << (d - 1), 64);
-    if (((lane + 1) & ((1 << d) - 1)) == (1 << (d - 1))) v += (lane >= (1 << (d - 1))) ? o : excl_wave;
-  }
-  // v = inclusive scan at the thread's last slot; E = exclusive prefix of the thread
-  float E = __shfl_up(v, 1, 64);
-  if (lane == 0) E = excl_wave;
-  float c[PPT];
-  c[PPT - 1] = v;
-  // down-sweep inside the thread: node at p (end of a left half-block of size s) += prefix before its block
-  BF_UNROLL for (int p = 0; p < PPT - 1; ++p) c[p] = tsum[p];
-  BF_UNROLL for (int s = PPT / 2; s >= 1; s >>= 1) BF_UNROLL for (int p = s - 1; p < PPT - 1; p += 2 * s) {
-    // prefix before the block of size 2s that contains p: E for the first block, else c[block_start - 1]
-    const int bs = (p / (2 * s)) * (2 * s);
-    c[p] = ((bs == 0) ? E : c[bs - 1]) + tsum[p];
-  }
-  __syncthreads();
-  BF_UNROLL for (int p = 0; p < PPT; ++p) cdf[tid * PPT + p] = c[p];
-  __syncthreads();
-  const float total = cdf[NP - 1];
-  float u_sys = 0.f;
-  if (resampler == 1) u_sys = bits_to_unit(threefry_bits(kc.x, kc.y, 0u, 1u));
-  BF_UNROLL for (int p = 0; p < PPT; ++p) {
-    const uint32_t i = (uint32_t)(tid * PPT + p);
-    float r;
-    if (resampler == 1) r = (((float)i + u_sys) / (float)NP) * total;
-    else r = total * (1.0f - bits_to_unit(threefry_bits(kc.x, kc.y, valid[p] ? i : 0u, (uint32_t)NP)));
-    int lo = 0, hi = NP;  // first index with cdf[idx] >= r
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (cdf[mid] < r) lo = mid + 1; else hi = mid;
-    }
-    anc[p] = lo < NP - 1 ? lo : NP - 1;
-  }
-}
-
-// NaN-propagating maximum (jnp.max semantics)
-__device__ __forceinline__ float nanmax(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); }
-
-template <int N, int DQ, int M, int PPT, int NW>
-__global__ void __launch_bounds__(64 * NW)
-bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const float* __restrict__ uptr, long long u_sB,
-                long long u_sT, BpfCarry carry, BpfOut out, long long B, long long T, int NP, float ess_threshold,
-                int resampler, uint32_t key0, uint32_t key1) {
-  constexpr int NT = 64 * NW;
-  constexpr int CAP = NT * PPT;                 // particle slots (power of two)
-  constexpr int DCH = (N >= 8) ? 8 : N;         // state dimensions gathered per LDS pass
-  const BpfModel<N, DQ, M>& mdl = *mdlp;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long long b = blockIdx.x;
-
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* cdf = lds;                 // CAP floats
-  float* red = lds + CAP;           // 2 * 16 floats of cross-wave scratch
-  float* tile = lds + CAP + 64;     // CAP * DCH floats (gather tile; also N-vector reductions)
-
-  // ---- workgroup reductions in the oracle's adjacent-pair tree order
-  auto block_reduce = [&](float v, auto op) {  // v already reduced over the thread's own slots
-    BF_UNROLL for (int off = 1; off < 64; off <<= 1) v = op(v, __shfl_xor(v, off, 64));
-    if constexpr (NW > 1) {
-      __syncthreads();
-      if (lane == 0) red[wave] = v;
-      __syncthreads();
-      float r = (lane < NW) ? red[lane] : red[0];
-      BF_UNROLL for (int off = 1; off < NW; off <<= 1) r = op(r, __shfl_xor(r, off, 64));
-      v = __shfl(r, 0, 64);
-    }
-    return v;
-  };
-  auto thread_tree = [&](const float* e, auto op) {  // adjacent-pair tree over the PPT own slots
-    float t[PPT];
-    BF_UNROLL for (int p = 0; p < PPT; ++p) t[p] = e[p];
-    BF_UNROLL for (int s = 1; s < PPT; s <<= 1) BF_UNROLL for (int p = 0; p + s < PPT; p += 2 * s) t[p] = op(t[p], t[p + s]);
-    return t[0];
-  };
-  auto fadd = [](float a, float c) { return a + c; };
-
-  // ---- state
-  float x[PPT][N], w[PPT];
-  uint32_t k0, k1;
-  bool valid[PPT];
-  BF_UNROLL for (int p = 0; p < PPT; ++p) valid[p] = (tid * PPT + p) < NP;
-  if (carry.key_in) {
-    k0 = carry.key_in[b * 2];
-    k1 = carry.key_in[b * 2 + 1];
-  } else {
-    k0 = key0;
-    k1 = key1;
-  }
-  if (carry.x_in) {
-    BF_UNROLL for (int p = 0; p < PPT; ++p) {
-      const int i = valid[p] ? tid * PPT + p : 0;
-      BF_UNROLL for (int d = 0; d < N; ++d) x[p][d] = carry.x_in[(b * NP + i) * N + d];
-      w[p] = valid[p] ? carry.w_in[b * NP + i] : 0.f;
-    }
-  } else {
-    // inference.py:1369-1373: keys = split(key, N+1); next_key = keys[0]; x_i ~ MVN(m0, P0) with keys[1+i]
-    BF_UNROLL for (int p = 0; p < PPT; ++p) {
-      const uint32_t i = valid[p] ? (uint32_t)(tid * PPT + p) : 0u;
-      const U32x2 ki = threefry_split(k0, k1, i + 1u, (uint32_t)NP + 1u);
-      float z[N];
-      BF_UNROLL for (int d = 0; d < N; ++d) z[d] = bits_to_normal(threefry_bits(ki.x, ki.y, (uint32_t)d, (uint32_t)N));
-      BF_UNROLL for (int d = 0; d < N; ++d) {
-        float s = 0.f;
-        BF_UNROLL for (int c = 0; c <= d; ++c) s = fmaf(mdl.L0[d * N + c], z[c], s);
-        x[p][d] = mdl.m0[d] + s;
-      }
-      w[p] = valid[p] ? 1.0f / (float)NP : 0.f;
-    }
-    const U32x2 nk = threefry_split(k0, k1, 0u, (uint32_t)NP + 1u);
-    k0 = nk.x;
-    k1 = nk.y;
-  }
-
-  for (long long t = 0; t < T; ++t) {
-    float yv[M];
-    BF_UNROLL for (int a = 0; a < M; ++a) yv[a] = y.p[b * y.sB + t * y.sT + a * y.sE];
-    const float u0 = uptr ? uptr[b * u_sB + t * u_sT] : 0.f;
-
-    // ---- propagate (inference.py:1342-1345, models.py:82-84) and log-weight (:1348-1349)
-    const U32x2 nk = threefry_split(k0, k1, 0u, (uint32_t)NP + 1u);  // next_key = keys[0]
-    float ll[PPT];
-    BF_UNROLL for (int p = 0; p < PPT; ++p) {
-      const uint32_t i = valid[p] ? (uint32_t)(tid * PPT + p) : 0u;
-      const U32x2 ki = threefry_split(k0, k1, i + 1u, (uint32_t)NP + 1u);
-      float z[DQ], q[DQ], xn[N];
-      // normal(key_i, (dq,)): block j yields entries j and h + j
-      constexpr int h = (DQ + 1) / 2;
-      BF_UNROLL for (int j = 0; j < h; ++j) {
-        const U32x2 o = threefry2x32(ki.x, ki.y, (uint32_t)j, (h + j < DQ) ? (uint32_t)(h + j) : 0u);
-        z[j] = bits_to_normal(o.x);
-        if (h + j < DQ) z[h + j] = bits_to_normal(o.y);
-      }
-      BF_UNROLL for (int d = 0; d < DQ; ++d) {
-        float s = 0.f;
-        BF_UNROLL for (int c = 0; c <= d; ++c) s = fmaf(mdl.LQ[d * DQ + c], z[c], s);
-        q[d] = mdl.q0[d] + s;
-      }
-      dyn_value<N, DQ, M>(mdl, x[p], q, u0, xn);
-      BF_UNROLL for (int d = 0; d < N; ++d) x[p][d] = xn[d];
-      // MVN(h(x), R).log_prob(y) through the Cholesky factor (tfp), forward substitution
-      float hx[M], zz[M];
-      emi_value<N, DQ, M>(mdl, xn, u0, hx);
-      float quad = 0.f;
-      BF_UNROLL for (int a = 0; a < M; ++a) {
-        float s = yv[a] - hx[a];
-        BF_UNROLL for (int c = 0; c < a; ++c) s = fmaf(-mdl.LR[a * M + c], zz[c], s);
-        zz[a] = s * mdl.rdLR[a];
-        quad = fmaf(zz[a], zz[a], quad);
-      }
-      ll[p] = valid[p] ? (-0.5f * quad + mdl.lp_const) : -__builtin_inff();
-    }
-
-    // ---- reweight (inference.py:1350-1353)
-    const float mx = block_reduce(thread_tree(ll, nanmax), nanmax);
-    float e[PPT];
-    BF_UNROLL for (int p = 0; p < PPT; ++p) e[p] = valid[p] ? expf(ll[p] - mx) * w[p] : 0.f;
-    const float tot = block_reduce(thread_tree(e, fadd), fadd);
-    float wn[PPT], w2[PPT];
-    BF_UNROLL for (int p = 0; p < PPT; ++p) {
-      wn[p] = valid[p] ? e[p] / tot : 0.f;
-      w2[p] = wn[p] * wn[p];
-    }
-    const float ess = 1.0f / block_reduce(thread_tree(w2, fadd), fadd);
-    const bool do_resample = ess < ess_threshold * (float)NP;  // inference.py:1356 (NaN compares false)
-
-    int anc[PPT];
-    BF_UNROLL for (int p = 0; p < PPT; ++p) anc[p] = tid * PPT + p;
-    if (do_resample) {
-      // ---- utils.py:207-214: keys = split(key, 2); idx = choice(keys[0], N, (N,), p = w); next_key = keys[1]
-      const U32x2 kc = threefry_split(nk.x, nk.y, 0u, 2u);
-      const U32x2 kn = threefry_split(nk.x, nk.y, 1u, 2u);
-      resample_indices<PPT, NW>(wn, valid, NP, kc, resampler, cdf, red, anc);
-      // gather through LDS, DCH dimensions per pass
-      BF_UNROLL for (int d0 = 0; d0 < N; d0 += DCH) {
-        __syncthreads();
-        BF_UNROLL for (int p = 0; p < PPT; ++p) BF_UNROLL for (int d = 0; d < DCH; ++d)
-            if (d0 + d < N) tile[d * CAP + tid * PPT + p] = x[p][d0 + d];
-        __syncthreads();
-        BF_UNROLL for (int p = 0; p < PPT; ++p) BF_UNROLL for (int d = 0; d < DCH; ++d)
-            if (d0 + d < N) x[p][d0 + d] = tile[d * CAP + anc[p]];
-      }
-      BF_UNROLL for (int p = 0; p < PPT; ++p) w[p] = valid[p] ? 1.0f / (float)NP : 0.f;
-      k0 = kn.x;
-      k1 = kn.y;
-    } else {
-      BF_UNROLL for (int p = 0; p < PPT; ++p) w[p] = wn[p];
-      k0 = nk.x;
-      k1 = nk.y;
-    }
-
-    // ---- emit
-    BF_UNROLL for (int p = 0; p < PPT; ++p) if (valid[p]) {
-      const long long i = tid * PPT + p;
-      if (out.w) out.w[b * out.w_sB + i * out.w_sN + t * out.w_sT] = w[p];
-      if (out.anc) out.anc[b * out.w_sB + i * out.w_sN + t * out.w_sT] = anc[p];
-      if (out.x) BF_UNROLL for (int d = 0; d < N; ++d) out.x[b * out.x_sB + i * out.x_sN + t * out.x_sT + d] = x[p][d];
-    }
-    if (out.mean) {
-      float part[N];
-      BF_UNROLL for (int d = 0; d < N; ++d) {
-        float s = 0.f;
-        BF_UNROLL for (int p = 0; p < PPT; ++p) s = fmaf(w[p], x[p][d], s);
-        BF_UNROLL for (int off = 1; off < 64; off <<= 1) s += __shfl_xor(s, off, 64);
-        part[d] = s;
-      }
-      __syncthreads();
-      if (lane == 0) BF_UNROLL for (int d = 0; d < N; ++d) tile[wave * N + d] = part[d];
-      __syncthreads();
-      if (tid < N) {
-        float s = 0.f;
-        for (int wv = 0; wv < NW; ++wv) s += tile[wv * N + tid];
-        out.mean[(b * T + t) * N + tid] = s;
-      }
-    }
-    if (tid == 0) {
-      if (out.ess) out.ess[b * T + t] = ess;
-      if (out.logz) out.logz[b * T + t] = mx + logf(tot);
-      if (out.resampled) out.resampled[b * T + t] = do_resample ? 1.0f : 0.0f;
-    }
-  }
-
-  BF_UNROLL for (int p = 0; p < PPT; ++p) if (valid[p]) {
-    const long long i = tid * PPT + p;
-    if (carry.x_out) BF_UNROLL for (int d = 0; d < N; ++d) carry.x_out[(b * NP + i) * N + d] = x[p][d];
-    if (carry.w_out) carry.w_out[b * NP + i] = w[p];
-  }
-  if (tid == 0 && carry.key_out) {
-    carry.key_out[b * 2] = k0;
-    carry.key_out[b * 2 + 1] = k1;
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-template <int N, int DQ, int M, int PPT, int NW>
-static int launch_bpf_cfg(const BpfModel<N, DQ, M>* d_mdl, const bf_cstream* y, const bf_cstream* u, long long B,
-                          long long T, int NP, float ess, int resampler, const uint32_t key[2], const BpfCarry& cr,
-                          const BpfOut& out, hipStream_t stream) {
-  constexpr int CAP = 64 * NW * PPT;
-  constexpr int DCH = (N >= 8) ? 8 : N;
-  const size_t lds_bytes = sizeof(float) * (size_t)(CAP + 64 + CAP * DCH);
-  if (lds_bytes > 160 * 1024) return set_error(BF_EUNSUPPORTED, "particle tile exceeds the 160 KiB LDS");
-  CView yv{y->ptr, y->sB, y->sT, y->sE};
-  auto kern = bpf_scan_kernel<N, DQ, M, PPT, NW>;
-  if (lds_bytes > 64 * 1024)
-    BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64 * NW), lds_bytes, stream, d_mdl, yv, (u && u->ptr) ? u->ptr : nullptr,
-                     u ? u->sB : 0, u ? u->sT : 0, cr, out, B, T, NP, ess, resampler, key[0], key[1]);
-  BF_HIP_CHECK(hipGetLastError());
-  return BF_OK;
-}
-
 int g_bpf_variant = 0;  // tuning hook (bf_set_option "bpf_variant")
-
-template <int N, int DQ, int M>
-static int launch_bpf_dims(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
-                           int NP, float ess, int resampler, const uint32_t key[2], const BpfCarry& cr, const BpfOut& out,
-                           hipStream_t stream) {
-  BpfModel<N, DQ, M> h;
-  int rc = fill_bpf_model<N, DQ, M>(bp, h);
-  if (rc != BF_OK) return rc;
-  BpfModel<N, DQ, M>* d_mdl = nullptr;
-  BF_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&d_mdl), sizeof(h), stream));
-  hipError_t e = hipMemcpyAsync(d_mdl, &h, sizeof(h), hipMemcpyHostToDevice, stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(stream);  // h lives on this stack frame
-  if (e != hipSuccess) {
-    (void)hipFreeAsync(d_mdl, stream);
-    BF_HIP_CHECK(e);
-  }
-  // smallest compiled particle capacity that holds NP
-  if (NP <= 64) rc = launch_bpf_cfg<N, DQ, M, 1, 1>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
-  else if (NP <= 256) rc = launch_bpf_cfg<N, DQ, M, 1, 4>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
-  else if (NP <= 1024) rc = launch_bpf_cfg<N, DQ, M, 1, 16>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
-  else if (NP <= 4096) {
-    // two geometries for the largest capacity: 1024 threads x 4 particles (128-VGPR budget) or
-    // 512 threads x 8 particles (256-VGPR budget); variant 0 = 1024 x 4 is the default
-    // (measured at cfg4's shape: 1024 x 4 = 28.0 ms per 50 steps, 512 x 8 = 33.8 ms)
-    if (g_bpf_variant == 1) rc = launch_bpf_cfg<N, DQ, M, 8, 8>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
-    else rc = launch_bpf_cfg<N, DQ, M, 4, 16>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
-  }
-  else rc = set_error(BF_EUNSUPPORTED, "bootstrap particle filter: %d particles exceed the compiled capacity of 4096 per trajectory", NP);
-  hipError_t fe = hipFreeAsync(d_mdl, stream);
-  if (rc != BF_OK) return rc;
-  BF_HIP_CHECK(fe);
-  return BF_OK;
-}
 
 // Stand-alone resampler: idx[b][:] = choice(key_b, N, (N,), p = w[b]) (the index draw of utils.py:210)
 template <int PPT, int NW>
@@ -413,6 +37,14 @@ int launch_resample(const float* d_w, const uint32_t* d_keys, long long B, int N
   return BF_OK;
 }
 
+#define BF_DECL(F_)                                                                                                   \
+  int F_(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP, float ess, \
+         int resampler, const uint32_t key[2], const BpfCarry& cr, const BpfOut& out, hipStream_t stream, bool* matched)
+BF_DECL(launch_bpf_group_a);
+BF_DECL(launch_bpf_group_b);
+BF_DECL(launch_bpf_group_c);
+#undef BF_DECL
+
 int launch_bpf(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP,
                float ess, int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o,
                hipStream_t stream) {
@@ -420,16 +52,14 @@ int launch_bpf(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u,
               carry ? carry->x_out : nullptr, carry ? carry->w_out : nullptr, carry ? carry->key_out : nullptr};
   BpfOut out{o->weights, o->w_sB, o->w_sN, o->w_sT, o->particles, o->x_sB, o->x_sN, o->x_sT, o->ancestors,
              o->mean, o->ess, o->logz, o->resampled};
+  bool matched = false;
+  int rc = launch_bpf_group_a(bp, y, u, B, T, NP, ess, resampler, key, cr, out, stream, &matched);
+  if (matched) return rc;
+  rc = launch_bpf_group_b(bp, y, u, B, T, NP, ess, resampler, key, cr, out, stream, &matched);
+  if (matched) return rc;
+  rc = launch_bpf_group_c(bp, y, u, B, T, NP, ess, resampler, key, cr, out, stream, &matched);
+  if (matched) return rc;
   const bf_model* p = &bp->ssm;
-#define BF_CASE(N_, DQ_, M_) \
-  if (p->n == N_ && p->dq == DQ_ && p->m == M_) return launch_bpf_dims<N_, DQ_, M_>(bp, y, u, B, T, NP, ess, resampler, key, cr, out, stream)
-  BF_CASE(1, 1, 1);
-  BF_CASE(3, 3, 1);
-  BF_CASE(3, 3, 3);
-  BF_CASE(4, 2, 2);
-  BF_CASE(8, 8, 4);
-  BF_CASE(16, 16, 8);
-#undef BF_CASE
   return set_error(BF_EUNSUPPORTED, "bootstrap particle filter: (n=%d, dq=%d, m=%d) is not compiled in", p->n, p->dq, p->m);
 }
 

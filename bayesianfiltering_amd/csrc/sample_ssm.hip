@@ -149,12 +149,17 @@ int launch_sample_ssm(const bf_bpf_model* bp, const uint32_t* d_keys, const bf_c
 #define BF_CASE(N_, DQ_, M_) \
   if (p->n == N_ && p->dq == DQ_ && p->m == M_) return launch_sample_dims<N_, DQ_, M_>(bp, d_keys, u, B, T, d_states, d_emis, stream)
   BF_CASE(1, 1, 1);
+  BF_CASE(2, 2, 1);
+  BF_CASE(2, 2, 2);
   BF_CASE(3, 3, 1);
   BF_CASE(3, 3, 3);
-  BF_CASE(4, 2, 2);
+  BF_CASE(4, 4, 1);
   BF_CASE(4, 4, 2);
+  BF_CASE(4, 2, 2);
+  BF_CASE(6, 6, 3);
   BF_CASE(8, 8, 4);
   BF_CASE(16, 16, 8);
+  BF_CASE(4, 4, 4);
 #undef BF_CASE
   return set_error(BF_EUNSUPPORTED, "sample_ssm: (n=%d, dq=%d, m=%d) is not compiled in", p->n, p->dq, p->m);
 }

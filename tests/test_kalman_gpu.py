@@ -44,7 +44,8 @@ def test_cv_model_matches_oracle(lanes, layout, mode):
 
 
 @pytest.mark.parametrize("n,m,dq,dr", [(1, 1, 1, 1), (2, 1, 2, 1), (2, 2, 1, 2), (3, 1, 3, 1), (3, 3, 3, 3),
-                                       (4, 1, 2, 1), (4, 2, 4, 2), (4, 4, 3, 4), (6, 3, 6, 3), (8, 4, 8, 4)])
+                                       (4, 1, 2, 1), (4, 2, 4, 2), (4, 4, 3, 4), (5, 2, 5, 2), (6, 3, 6, 3),
+                                       (7, 4, 3, 4), (8, 1, 8, 1), (8, 4, 8, 4)])
 def test_random_lgssm_dims(n, m, dq, dr):
     a = cm.random_stable_lgssm(n, m, seed=10 * n + m, dq=dq, dr=dr, bias=True)
     B, T = 70, 48
@@ -100,7 +101,7 @@ def test_time_varying_covariances():
 def test_errors_are_loud():
     import bayesianfiltering_amd as bfa
     from bayesianfiltering_amd import _lib
-    a = cm.random_stable_lgssm(5, 2, seed=1)
+    a = cm.random_stable_lgssm(9, 2, seed=1)
     ys = cm.simulate_batch(a, 2, 8, seed=1)
     with pytest.raises(_lib.BayesFiltError) as e:
         bfa.kalman_filter(cm.product_params(a), ys)
