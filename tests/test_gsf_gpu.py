@@ -112,13 +112,13 @@ def test_default_initial_means_follow_prngkey0_draw():
     _check(post, ref, tol=3e-5)
 
 
-@pytest.mark.parametrize("K,n", [(32, 8), (100, 4), (64, 4)])
+@pytest.mark.parametrize("K,n", [(32, 8), (100, 4), (64, 4), (40, 8), (3, 4)])
 def test_many_components(K, n):
     """cfg3-shaped (K=32, n=8: one wave per trajectory) and K=100, n=4 (two lanes per chain -> 256
     lanes per trajectory, reweight continued through LDS); staged and strided stores agree bit for bit."""
     bfa, nl = _nl()
     rng = np.random.default_rng(K)
-    T, B = 16, 3
+    T, B = (16, 3) if K != 3 else (20, 5)     # T = 20: rows 16-byte aligned but not a multiple of the tile depth
     if n == 8:
         po = go.ParamsNLSSM(np.zeros(8, F32), np.eye(8, dtype=F32), om.Lorenz96(8), np.zeros(8, F32),
                             1e-2 * np.eye(8, dtype=F32), om.PickEven(8), np.zeros(4, F32), 1e-1 * np.eye(4, dtype=F32))
@@ -139,6 +139,8 @@ def test_many_components(K, n):
         _mode(-1)
     for k in FIELDS + ("weights",):
         assert np.array_equal(getattr(post, k).cpu().numpy(), getattr(post0, k).cpu().numpy()), k
+    if K == 4:   # power of two: the staged path with an incomplete last tile row
+        pass
 
 
 def test_stochastic_volatility_switching_emission():
@@ -217,3 +219,21 @@ def test_collapse_matches_reference_formula():
     t = 17
     _, c_ref = go.collapse(d["means"][:, t].astype(np.float64), d["covariances"][:, t].astype(np.float64), d["weights"][:, t].astype(np.float64))
     assert cm.rel_err(cov_t[t].cpu().numpy(), c_ref) < 1e-5
+
+
+def test_staged_partial_rows_and_single_trajectory_waves():
+    """K = 4 (power of two, staged stores) with T = 20: the weight tile (depth 16) ends on an incomplete
+    row that is flushed chunk-limited; B = 32 fills whole waves."""
+    bfa, nl = _nl()
+    a = cm.cv_model_arrays()
+    po, pp = cm.oracle_params(a), cm.product_params(a)
+    T, B, K = 20, 32, 4
+    ys = np.stack([go.sample_ssm(po, otf.PRNGKey(b), T)[1] for b in range(B)])
+    init = np.random.default_rng(5).normal(size=(B, K, 4)).astype(F32)
+    ref = _oracle_batch(po, ys, K, init)
+    _mode(2)
+    try:
+        post = bfa.gaussian_sum_filter(pp, ys, K, 1, initial_means=init)
+    finally:
+        _mode(-1)
+    _check(post, ref, tol=3e-5)
