@@ -138,6 +138,40 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
     });
   };
 
+  // _predict (inference.py:51-70), linearised at the current (filtered) mean; also run once before the
+  // scan for the legacy classes' predict -> update order (gaussfilt.py:113-121)
+  auto predict = [&](float u0) __attribute__((always_inline)) {
+    float xf[NS];
+    float F[NS * NS], fx[NS];
+    gather(mj, xf);
+    dyn_linearize<NS, M>(mdl, xf, u0, F, fx);
+    float APc[CPL][NS];
+    BF_UNROLL for (int cc = 0; cc < CPL; ++cc) BF_UNROLL for (int i = 0; i < NS; ++i) {
+      float s = F[i * NS] * Pc[cc][0];
+      BF_UNROLL for (int kk = 1; kk < NS; ++kk) s = fmaf(F[i * NS + kk], Pc[cc][kk], s);
+      APc[cc][i] = s;
+    }
+    float Pc0[CPL][NS];
+    BF_UNROLL for (int cc = 0; cc < CPL; ++cc) BF_UNROLL for (int i = 0; i < NS; ++i) Pc0[cc][i] = Pc[cc][i];
+    float Frow[CPL][NS];
+    BF_UNROLL for (int cc = 0; cc < CPL; ++cc) BF_UNROLL for (int l = 0; l < NS; ++l)
+        Frow[cc][l] = pick<NL>(F, NS * NS, jl, CPL * NS, cc * NS + l);
+    BF_UNROLL for (int i = 0; i < NS; ++i) {
+      float acc[CPL];
+      static_for<0, NS>([&](auto L) {
+        constexpr int l = decltype(L)::value;
+        const float ap_l = group_bcast<NL, l / CPL>(APc[l % CPL][i]);
+        BF_UNROLL for (int cc = 0; cc < CPL; ++cc) acc[cc] = (l == 0) ? ap_l * Frow[cc][0] : fmaf(ap_l, Frow[cc][l], acc[cc]);
+      });
+      BF_UNROLL for (int cc = 0; cc < CPL; ++cc)
+          Pc[cc][i] = acc[cc] + (mdl.cov_quirk ? Pc0[cc][i] : pick<NL>(mdl.GQG, NS * NS, jl, CPL, i * NS + cc));
+    }
+    BF_UNROLL for (int cc = 0; cc < CPL; ++cc) mj[cc] = pick<NL>(fx, NS, jl, CPL, cc);
+
+  };
+
+  if (mdl.predict_first) predict(uin.p ? uin.p[b * uin.sB] : 0.f);
+
   for (long long t = 0; t < T; ++t) {
     float yv[M];
     BF_UNROLL for (int a = 0; a < M; ++a) yv[a] = y.p[b * y.sB + t * y.sT + a * y.sE];
@@ -164,7 +198,7 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
       BF_UNROLL for (int cc = 1; cc < CPL; ++cc) s = fmaf(X[a * CPL + cc], Hcol[cc][bb], s);
       S[a * M + bb] = HrRHr[a * M + bb] + group_sum<NL>(s);
     }
-    psd_solve<M, CPL>(S, X);
+    psd_solve<M, CPL>(S, X, mdl.jitter);
     float KS[CPL][M];
     BF_UNROLL for (int cc = 0; cc < CPL; ++cc) BF_UNROLL for (int bb = 0; bb < M; ++bb) {
       float s = X[cc] * S[bb];
@@ -231,30 +265,8 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
       }
     }
 
-    // ================= _predict (inference.py:51-70), linearised at the filtered mean
-    float F[NS * NS], fx[NS];
-    gather(mj, xf);
-    dyn_linearize<NS, M>(mdl, xf, u0, F, fx);
-    float APc[CPL][NS];
-    BF_UNROLL for (int cc = 0; cc < CPL; ++cc) BF_UNROLL for (int i = 0; i < NS; ++i) {
-      float s = F[i * NS] * Pc[cc][0];
-      BF_UNROLL for (int kk = 1; kk < NS; ++kk) s = fmaf(F[i * NS + kk], Pc[cc][kk], s);
-      APc[cc][i] = s;
-    }
-    float Frow[CPL][NS];
-    BF_UNROLL for (int cc = 0; cc < CPL; ++cc) BF_UNROLL for (int l = 0; l < NS; ++l)
-        Frow[cc][l] = pick<NL>(F, NS * NS, jl, CPL * NS, cc * NS + l);
-    BF_UNROLL for (int i = 0; i < NS; ++i) {
-      float acc[CPL];
-      static_for<0, NS>([&](auto L) {
-        constexpr int l = decltype(L)::value;
-        const float ap_l = group_bcast<NL, l / CPL>(APc[l % CPL][i]);
-        BF_UNROLL for (int cc = 0; cc < CPL; ++cc) acc[cc] = (l == 0) ? ap_l * Frow[cc][0] : fmaf(ap_l, Frow[cc][l], acc[cc]);
-      });
-      BF_UNROLL for (int cc = 0; cc < CPL; ++cc)
-          Pc[cc][i] = acc[cc] + pick<NL>(mdl.GQG, NS * NS, jl, CPL, i * NS + cc);
-    }
-    BF_UNROLL for (int cc = 0; cc < CPL; ++cc) mj[cc] = pick<NL>(fx, NS, jl, CPL, cc);
+    // ================= _predict
+    predict(u0);
 
     // ---- emit predicted streams, flush completed rows
     if constexpr (MODE == EMIT_STAGED) {
@@ -329,6 +341,9 @@ static inline int fill_model(const bf_model* p, EkfModel<N, M>& e) {
   std::memset(&e, 0, sizeof(e));
   e.dyn_id = p->dyn_id;
   e.emi_id = p->emi_id;
+  e.jitter = (p->flags & BF_MODEL_NO_JITTER) ? 0.0f : 1e-6f;
+  e.predict_first = (p->flags & BF_MODEL_PREDICT_FIRST) ? 1 : 0;
+  e.cov_quirk = (p->flags & BF_MODEL_LEGACY_GSF_COV) ? 1 : 0;
   const int dq = p->dq, dr = p->dr;
   // F_q / H_r of every registry function are constant matrices (identity unless stated)
   float G[N * 64] = {0}, D[M * 64] = {0};

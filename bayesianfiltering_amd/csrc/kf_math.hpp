@@ -61,10 +61,10 @@ __device__ __forceinline__ void mv(const float* a, const float* x, float* c) {
 // the order of LAPACK getrf/getrs (what jnp.linalg.solve runs): gaussfiltax/utils.py:256-259.
 // Row swaps are done with selects so lanes with different pivots stay convergent.
 template <int M, int C>
-__device__ __forceinline__ void psd_solve(const float* S, float* X /* in: Bm, out: X */) {
+__device__ __forceinline__ void psd_solve(const float* S, float* X /* in: Bm, out: X */, float jitter = 1e-6f) {
   float a[M * M];
   float rdiag[M];
-  BF_UNROLL for (int i = 0; i < M * M; ++i) a[i] = S[i] + 1e-6f;
+  BF_UNROLL for (int i = 0; i < M * M; ++i) a[i] = S[i] + jitter;
   BF_UNROLL for (int k = 0; k < M; ++k) {
     // pivot search: first row of maximal |a[i][k]|, i >= k (isamax semantics)
     int p = k;

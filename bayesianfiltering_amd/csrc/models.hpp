@@ -31,6 +31,9 @@ struct EkfModel {
   float Dr0[M];      // H_r r0 when H_r is constant
   float R[M * M];    // emission noise covariance (state-dependent H_r: stochastic volatility)
   float r0[M];
+  float jitter;       // added to every entry of S before the gain solve (1e-6: gaussfiltax/utils.py:258; 0: legacy classes)
+  int predict_first;  // legacy class order predict -> update (gaussfiltax/gaussfilt.py:113-121)
+  int cov_quirk;      // legacy GaussSumFilt predict: P + J P J^T, Q never added (gaussfiltax/gausssumfilt.py:59)
 };
 
 // f(x, q0, u) and F_x = df/dx at x (dense, row-major).  The noise bias enters additively for

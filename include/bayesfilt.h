@@ -130,7 +130,13 @@ typedef struct bf_model {
   int32_t n_emi_theta;
   const float *q0, *r0; /* noise biases, NULL = zeros                */
   const float *Q, *R;   /* noise covariances [dq,dq], [dr,dr]        */
+  int32_t flags;        /* 0 = the JAX path's semantics; BF_MODEL_* bits for the legacy NumPy classes */
 } bf_model;
+
+/* Legacy-class semantics (gaussfiltax/gaussfilt.py, gausssumfilt.py), honoured by bf_gsf_ekf_f32: */
+#define BF_MODEL_PREDICT_FIRST 1  /* step order predict -> update (gaussfilt.py:113-121); carry = filtered state   */
+#define BF_MODEL_NO_JITTER 2      /* gain from S itself, no 1e-6 (gaussfilt.py:118 `Cxy @ inv(Sy)`)                 */
+#define BF_MODEL_LEGACY_GSF_COV 4 /* predicted covariance P + J P J^T, Q never added (gausssumfilt.py:59)           */
 
 /* Batched Gaussian-sum filter (bank of K extended Kalman filters + weight update): replaces the
  * lax.scan of gaussian_sum_filter (inference.py:333-371) for K >= 1 and nonlinear f, h.
