@@ -16,6 +16,10 @@ BF_DECL(launch_gsf_group_d);
 // n = 1..8 with m = 1..min(n, 4); `lanes` = 0 picks the default lanes per chain.
 int launch_gsf_ekf(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int K,
                    const bf_carry* carry, const bf_out_desc* out, hipStream_t stream, int force_mode, int lanes) {
+  if (lanes == 0) {  // default lanes per chain: the largest column block per lane that divides n (fewest redundant VALU ops)
+    static const int kDefault[9] = {0, 1, 1, 1, 2, 1, 2, 1, 2};
+    if (p->n >= 1 && p->n <= 8) lanes = kDefault[p->n];
+  }
   bool matched = false;
   int rc = launch_gsf_group_a(p, y, u, B, T, K, carry, out, stream, force_mode, lanes, &matched);
   if (matched) return rc;

@@ -16,6 +16,7 @@ BF_DECL(launch_kf_group_d);
 // n = 1..8 with m = 1..min(n, 4); `lanes` = 0 picks the default lanes per trajectory.
 int launch_kf_group(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
                     const bf_out_desc* out, hipStream_t stream, int force_mode, int lanes) {
+  if (lanes == 0 && p->n >= 1 && p->n <= 8) lanes = p->n <= 2 ? 1 : (p->n <= 4 ? 2 : 4);  // default lanes per trajectory
   bool matched = false;
   int rc = launch_kf_group_a(p, y, B, T, carry, out, stream, force_mode, lanes, &matched);
   if (matched) return rc;
