@@ -10,8 +10,8 @@
 // (ti, tj) = (w >> 1, w & 1) of every 64x64 product.  P lives in LDS (65-float pitch: both the
 // row-indexed and the column-indexed MFMA operand patterns are bank-conflict free) and, tile by
 // tile, in the accumulator registers of its owner wave across steps; the constant operands (the
-// wave's row blocks of A, H, and its tiles of G Q G^T, D R D^T) stay in VGPRs in MFMA operand
-// layout for the whole scan.  Per step:
+// wave's row blocks of A and its tile of G Q G^T) stay in VGPRs in MFMA operand layout for the
+// whole scan; H and D R D^T are LDS-resident.  Per step:
 //   A  H P            (waves 0,1; K = 64)          hm = H m, v = y - hm                 (wave 2)
 //   B  S = (H P) H^T + D R D^T                     (wave 0; K = 64)
 //   C  chol(S + 1e-6) and its inverse L^-1         (wave 0, rows in registers, v_readlane broadcasts)
@@ -54,11 +54,16 @@ __device__ __forceinline__ float rdlane(float v, int l) {
 __device__ __forceinline__ void chol32_rows(float* a, int li) {
   static_for<0, 32>([&](auto J) {
     constexpr int j = decltype(J)::value;
-    float s = a[j];
+    // four interleaved partial sums: a single accumulation chain would serialise on the FMA latency
+    float s = a[j], s1 = 0.f, s2 = 0.f, s3 = 0.f;
     static_for<0, j>([&](auto Kk) {
       constexpr int k = decltype(Kk)::value;
-      s = fmaf(-a[k], rdlane(a[k], j), s);
+      if constexpr (k % 4 == 0) s = fmaf(-a[k], rdlane(a[k], j), s);
+      else if constexpr (k % 4 == 1) s1 = fmaf(-a[k], rdlane(a[k], j), s1);
+      else if constexpr (k % 4 == 2) s2 = fmaf(-a[k], rdlane(a[k], j), s2);
+      else s3 = fmaf(-a[k], rdlane(a[k], j), s3);
     });
+    s = (s + s1) + (s2 + s3);
     // IEEE sqrt / division here: the 32-step factorization and its explicit inverse compound
     // rounding errors, and these 64 scalar ops per step are noise against the MFMA work
     const float d = sqrtf(rdlane(s, j));  // NaN if not positive definite
@@ -90,18 +95,20 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
   float* sm2 = sm + N;             // [64] mean (ping-pong)
   float* sv = sm2 + N;             // [32] innovation
   float* sy = sv + M;              // [32] observation
+  float* sH = sy + M;              // [32][65]  H (operand source; keeping it in VGPRs spills the factorization)
+  float* sD = sH + M * PP;         // [32][33]  D R D^T
 
   // ---- constant operands in MFMA layout: lane holds X[32*blk + (l & 31)][2 s + (l >> 5)]
-  float Ati[32], Atj[32], Hr[32];
+  float Ati[32], Atj[32];
   BF_UNROLL for (int s = 0; s < 32; ++s) {
     Ati[s] = cst->A[(32 * ti + lr) * N + 2 * s + lk];
     Atj[s] = cst->A[(32 * tj + lr) * N + 2 * s + lk];
-    Hr[s] = cst->H[lr * N + 2 * s + lk];
   }
-  f32x16 gqg, drd, Pacc;
+  for (int e = tid; e < M * N; e += 256) sH[(e / N) * PP + (e % N)] = cst->H[e];
+  for (int e = tid; e < M * M; e += 256) sD[(e / M) * PS + (e % M)] = cst->DRD[e];
+  f32x16 gqg, Pacc;
   BF_UNROLL for (int r = 0; r < 16; ++r) {
     gqg[r] = cst->GQG[(32 * ti + c_row(r, lane)) * N + 32 * tj + lr];
-    drd[r] = cst->DRD[c_row(r, lane) * M + lr];
     Pacc[r] = carry.P_in[b * N * N + (32 * ti + c_row(r, lane)) * N + 32 * tj + lr];
     sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = Pacc[r];
   }
@@ -116,22 +123,23 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
     // ================= phase A: H P (waves 0,1); innovation (wave 2)
     if (wave < 2) {
       f32x16 acc = {0};
-      BF_UNROLL for (int s = 0; s < 32; ++s) acc = mfma2(Hr[s], sP[(2 * s + lk) * PP + 32 * tj + lr], acc);
+      BF_UNROLL for (int s = 0; s < 32; ++s) acc = mfma2(sH[lr * PP + 2 * s + lk], sP[(2 * s + lk) * PP + 32 * tj + lr], acc);
       BF_UNROLL for (int r = 0; r < 16; ++r) sT[c_row(r, lane) * PP + 32 * tj + lr] = acc[r];
     } else if (wave == 2) {
       if (lane < M) sy[lane] = ynext;
       const long long tn = t + 1 < T ? t + 1 : t;
       if (lane < M) ynext = y.p[b * y.sB + tn * y.sT + lane * y.sE];  // prefetch
       float s = 0.f;
-      BF_UNROLL for (int q = 0; q < 32; ++q) s = fmaf(Hr[q], mcur[2 * q + lk], s);
+      BF_UNROLL for (int q = 0; q < 32; ++q) s = fmaf(sH[lr * PP + 2 * q + lk], mcur[2 * q + lk], s);
       s += __shfl_xor(s, 32, 64);
       if (lane < M) sv[lane] = sy[lane] - (s + cst->Dr0[lane]);
     }
     __syncthreads();
     // ================= phase B: S = (H P) H^T + D R D^T (wave 0)
     if (wave == 0) {
-      f32x16 acc = drd;
-      BF_UNROLL for (int s = 0; s < 32; ++s) acc = mfma2(sT[lr * PP + 2 * s + lk], Hr[s], acc);
+      f32x16 acc;
+      BF_UNROLL for (int r = 0; r < 16; ++r) acc[r] = sD[c_row(r, lane) * PS + lr];
+      BF_UNROLL for (int s = 0; s < 32; ++s) acc = mfma2(sT[lr * PP + 2 * s + lk], sH[lr * PP + 2 * s + lk], acc);
       BF_UNROLL for (int r = 0; r < 16; ++r) sS[c_row(r, lane) * PS + lr] = acc[r];
     }
     __syncthreads();
@@ -144,11 +152,15 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
       // column (l & 31) of L^-1: x[i] = (delta_ic - sum_{k<i} L[i][k] x[k]) / L[i][i]
       static_for<0, 32>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        float s = (lr == i) ? 1.f : 0.f;
+        float s = (lr == i) ? 1.f : 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         static_for<0, i>([&](auto Kk) {
           constexpr int k = decltype(Kk)::value;
-          s = fmaf(-rdlane(a[k], i), x[k], s);
+          if constexpr (k % 4 == 0) s = fmaf(-rdlane(a[k], i), x[k], s);
+          else if constexpr (k % 4 == 1) s1 = fmaf(-rdlane(a[k], i), x[k], s1);
+          else if constexpr (k % 4 == 2) s2 = fmaf(-rdlane(a[k], i), x[k], s2);
+          else s3 = fmaf(-rdlane(a[k], i), x[k], s3);
         });
+        s = (s + s1) + (s2 + s3);
         x[i] = s / rdlane(a[i], i);
       });
       if (lane < 32) BF_UNROLL for (int i = 0; i < 32; ++i) sLi[i * PS + lr] = x[i];
@@ -304,7 +316,7 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
   CarryView cv{carry->w_in, carry->m_in, carry->P_in, carry->w_out, carry->m_out, carry->P_out};
   OutViews ov{make_sview(out->weights), make_sview(out->means), make_sview(out->covs),
               make_sview(out->pred_means), make_sview(out->pred_covs), make_sview(out->loglik)};
-  const size_t lds_bytes = sizeof(float) * (size_t)(2 * N * (N + 1) + N * (M + 1) + 2 * M * (M + 1) + 2 * N + 2 * M);
+  const size_t lds_bytes = sizeof(float) * (size_t)(2 * N * (N + 1) + N * (M + 1) + 3 * M * (M + 1) + M * (N + 1) + 2 * N + 2 * M);
   auto kern = kf_scan_mfma_kernel<N, M>;
   if (lds_bytes > 64 * 1024)
     BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
