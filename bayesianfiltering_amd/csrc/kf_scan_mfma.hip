@@ -54,16 +54,13 @@ __device__ __forceinline__ float rdlane(float v, int l) {
 __device__ __forceinline__ void chol32_rows(float* a, int li) {
   static_for<0, 32>([&](auto J) {
     constexpr int j = decltype(J)::value;
-    // four interleaved partial sums: a single accumulation chain would serialise on the FMA latency
-    float s = a[j], s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    // (one accumulation chain on purpose: splitting it into partial sums, or the right-looking
+    // outer-product form, raises register pressure past the 256-VGPR budget and spills)
+    float s = a[j];
     static_for<0, j>([&](auto Kk) {
       constexpr int k = decltype(Kk)::value;
-      if constexpr (k % 4 == 0) s = fmaf(-a[k], rdlane(a[k], j), s);
-      else if constexpr (k % 4 == 1) s1 = fmaf(-a[k], rdlane(a[k], j), s1);
-      else if constexpr (k % 4 == 2) s2 = fmaf(-a[k], rdlane(a[k], j), s2);
-      else s3 = fmaf(-a[k], rdlane(a[k], j), s3);
+      s = fmaf(-a[k], rdlane(a[k], j), s);
     });
-    s = (s + s1) + (s2 + s3);
     // IEEE sqrt / division here: the 32-step factorization and its explicit inverse compound
     // rounding errors, and these 64 scalar ops per step are noise against the MFMA work
     const float d = sqrtf(rdlane(s, j));  // NaN if not positive definite
@@ -152,15 +149,11 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
       // column (l & 31) of L^-1: x[i] = (delta_ic - sum_{k<i} L[i][k] x[k]) / L[i][i]
       static_for<0, 32>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        float s = (lr == i) ? 1.f : 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        float s = (lr == i) ? 1.f : 0.f;
         static_for<0, i>([&](auto Kk) {
           constexpr int k = decltype(Kk)::value;
-          if constexpr (k % 4 == 0) s = fmaf(-rdlane(a[k], i), x[k], s);
-          else if constexpr (k % 4 == 1) s1 = fmaf(-rdlane(a[k], i), x[k], s1);
-          else if constexpr (k % 4 == 2) s2 = fmaf(-rdlane(a[k], i), x[k], s2);
-          else s3 = fmaf(-rdlane(a[k], i), x[k], s3);
+          s = fmaf(-rdlane(a[k], i), x[k], s);
         });
-        s = (s + s1) + (s2 + s3);
         x[i] = s / rdlane(a[i], i);
       });
       if (lane < 32) BF_UNROLL for (int i = 0; i < 32; ++i) sLi[i * PS + lr] = x[i];
