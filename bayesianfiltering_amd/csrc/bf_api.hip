@@ -38,6 +38,7 @@ int launch_resample(const float* d_w, const uint32_t* d_keys, long long B, int N
                     hipStream_t stream);
 
 extern int g_bpf_variant;
+extern int g_gsf_structured;
 static int g_kf_emit_mode = -1;  // -1 = choose from the layout
 static int g_kf_lanes = 0;       // 0 = default lanes per trajectory for the (n, m) pair
 
@@ -69,6 +70,11 @@ int bf_set_option(const char* name, int value) {
   if (name && std::strcmp(name, "kf_lanes") == 0) {
     if (value < 0 || value > 64 || (value & (value - 1)) != 0) return bf::set_error(BF_EINVAL, "kf_lanes must be 0 or a power of two <= 64");
     bf::g_kf_lanes = value;
+    return BF_OK;
+  }
+  if (name && std::strcmp(name, "gsf_structured") == 0) {
+    if (value < 0 || value > 1) return bf::set_error(BF_EINVAL, "gsf_structured must be 0 or 1");
+    bf::g_gsf_structured = value;
     return BF_OK;
   }
   if (name && std::strcmp(name, "bpf_variant") == 0) {

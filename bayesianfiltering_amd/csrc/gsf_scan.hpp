@@ -17,6 +17,15 @@
 // registry model redundantly (models.hpp: O(n) work against O(n^3 / NL) for the covariance
 // algebra), and runs the same update/predict algebra as the Kalman kernel with the Jacobians in
 // VGPRs instead of kernel-argument constants.
+// SPEC_L96_PICK: structure-aware instance for the Lorenz-96 dynamics with the even-state-picking
+// emission (gaussfiltax/nonlinearities.py:37-50), the model of BASELINE config 3.  F_x is a
+// circulant band (4 entries per row) and H_x a selection, so the dense products shrink to 4-term
+// rows and register selects.  Every lane keeps its covariance columns in coordinates relative to
+// its own first column (slot i = row (base + i) mod n): the band pattern is then the same
+// compile-time pattern in every lane, and what a lane needs from its neighbours arrives through
+// DPP group rotations (lane_group.hpp: group_rot) instead of broadcast + lane-dependent selects.
+// Skipped terms are exact zeros of the dense product, so results differ from the generic
+// instance only in summation order.
 // Stores: EMIT_STAGED (contiguous reference layout [B][K][T][E], K a power of two) goes through
 // the per-wave LDS time-transpose tiles of scan_common.hpp; everything else through strided
 // dword stores.
@@ -51,7 +60,14 @@ struct UView {
   long long sB, sT;
 };
 
-template <int NS, int M, int NL, int MODE>
+enum { SPEC_GENERIC = 0, SPEC_L96_PICK = 1 };
+
+template <int N>
+constexpr int wrap_mod(int i) {
+  return ((i % N) + N) % N;
+}
+
+template <int NS, int M, int NL, int MODE, int SPEC>
 __global__ void __launch_bounds__(256, 2)
 gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutViews out, long long B, long long T, int K,
                 int KP, int lds_per_wave) {
@@ -80,11 +96,25 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
   // first chain of this wave in the contiguous [B][K] order (staged mode: K == KP, whole waves)
   const long long chain0w = ((long long)blockIdx.x * 4 + wave_in_blk) * CPW;
 
-  // ---- state: Pc[cc][i] = P[i][jl*CPL + cc]
+  constexpr bool L96 = SPEC == SPEC_L96_PICK;
+  static_assert(!L96 || (NS >= 4 && 2 * M == NS && NL <= 4), "Lorenz-96 instance: n >= 4, m = n / 2, at most 4 lanes");
+  const int base = jl * CPL;
+  // row of P held in slot i: the row itself, or (base + i) mod n in the relative coordinates of L96
+  auto rowabs = [&](int i) __attribute__((always_inline)) {
+    if constexpr (L96) {
+      const int r = base + i;
+      return r >= NS ? r - NS : r;
+    } else {
+      return i;
+    }
+  };
+  constexpr auto wrapn = wrap_mod<NS>;
+
+  // ---- state: Pc[cc][i] = P[rowabs(i)][jl*CPL + cc]
   float Pc[CPL][NS], mj[CPL], w;
   BF_UNROLL for (int cc = 0; cc < CPL; ++cc) {
     const int col = jl * CPL + cc;
-    BF_UNROLL for (int i = 0; i < NS; ++i) Pc[cc][i] = carry.P_in[chain * EP + i * NS + col];
+    BF_UNROLL for (int i = 0; i < NS; ++i) Pc[cc][i] = carry.P_in[chain * EP + rowabs(i) * NS + col];
     mj[cc] = carry.m_in[chain * NS + col];
   }
   w = comp_ok ? (carry.w_in ? carry.w_in[chain] : 1.0f / (float)K) : 0.f;
@@ -92,7 +122,12 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
   // ---- LDS: staging tiles (per wave) + reduction scratch (per workgroup)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* red = lds;  // 8 floats: per-wave partials of max / sum
-  int q = 8 + wave_in_blk * lds_per_wave;
+  constexpr int GQ = L96 ? EP : 0;  // L96: F_q Q F_q^T, read back by every lane in its own coordinates
+  if constexpr (L96) {
+    if (tid == 0) BF_UNROLL for (int i = 0; i < EP; ++i) lds[8 + i] = mdl.GQG[i];
+    __syncthreads();
+  }
+  int q = 8 + GQ + wave_in_blk * lds_per_wave;
   int oP = q, opP = q, oM = q, opM = q, oW = q, oL = q;
   if constexpr (MODE == EMIT_STAGED) {
     // a covariance row completes every step when TS == 1 (n*n >= 32): the filtered and the predicted
@@ -141,6 +176,64 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
   // _predict (inference.py:51-70), linearised at the current (filtered) mean; also run once before the
   // scan for the legacy classes' predict -> update order (gaussfilt.py:113-121)
   auto predict = [&](float u0) __attribute__((always_inline)) {
+    if constexpr (L96) {
+      (void)u0;
+      const float alpha = mdl.dth[0], beta = mdl.dth[1], gamma = mdl.dth[2], dt = mdl.dth[3];
+      const bool mp = mdl.dth[4] != 0.f;
+      // xr[l] = x[(base + l) mod n]
+      float xr[NS];
+      static_for<0, NS>([&](auto L) {
+        constexpr int l = decltype(L)::value;
+        xr[l] = group_rot<NL, l / CPL>(mj[l % CPL]);
+      });
+      // row i of F_x (relative): d0 on the diagonal, cm1[i] at i-1, cp1[i] at i+1, -cp1[i] at i-2
+      const float d0 = 1.0f - dt * beta;
+      float cm1[NS], cp1[NS];
+      BF_UNROLL for (int i = 0; i < NS; ++i) {
+        const float bx = mp ? (xr[wrapn(i + 1)] - xr[wrapn(i - 2)]) : 0.f;
+        cm1[i] = mp ? dt * alpha * bx : 0.f;
+        cp1[i] = mp ? dt * alpha * xr[wrapn(i - 1)] : 0.f;
+      }
+      float APc[CPL][NS];
+      BF_UNROLL for (int cc = 0; cc < CPL; ++cc) BF_UNROLL for (int i = 0; i < NS; ++i) {
+        float s = d0 * Pc[cc][i];
+        s = fmaf(-cp1[i], Pc[cc][wrapn(i - 2)], s);
+        s = fmaf(cm1[i], Pc[cc][wrapn(i - 1)], s);
+        s = fmaf(cp1[i], Pc[cc][wrapn(i + 1)], s);
+        APc[cc][i] = s;
+      }
+      // column l (relative) of F_x P, row slot i in THIS lane's coordinates
+      auto ap_col = [&](auto Lr, auto I) __attribute__((always_inline)) {
+        constexpr int l = wrapn(decltype(Lr)::value), i = decltype(I)::value;
+        constexpr int r = l / CPL;
+        return group_rot<NL, r>(APc[l % CPL][wrapn(i - r * CPL)]);
+      };
+      static_for<0, NS>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        float gq[CPL];
+        {
+          const int o = 8 + rowabs(i) * NS + base;
+          BF_UNROLL for (int cc = 0; cc < CPL; ++cc) gq[cc] = lds[o + cc];
+        }
+        static_for<0, CPL>([&](auto C) {
+          constexpr int cc = decltype(C)::value;
+          float s = d0 * APc[cc][i];
+          s = fmaf(-cp1[cc], ap_col(std::integral_constant<int, cc - 2 + NS>{}, I), s);
+          s = fmaf(cm1[cc], ap_col(std::integral_constant<int, cc - 1 + NS>{}, I), s);
+          s = fmaf(cp1[cc], ap_col(std::integral_constant<int, cc + 1>{}, I), s);
+          Pc[cc][i] = s + gq[cc];
+        });
+      });
+      BF_UNROLL for (int cc = 0; cc < CPL; ++cc) {
+        const float ax = xr[wrapn(cc - 1)];
+        const float bx = mp ? (xr[wrapn(cc + 1)] - xr[wrapn(cc - 2)]) : 0.f;
+        // x + dt (alpha ax bx - beta x + gamma), spelled out so that every copy of the loop body the
+        // compiler makes (peeled, versioned) contracts it the same way: chunked scans stay bit-identical
+        const float drift = fmaf(-beta, xr[cc], alpha * (ax * bx)) + gamma;
+        mj[cc] = fmaf(dt, drift, xr[cc]) + pick<NL>(mdl.Gq0, NS, jl, CPL, cc);
+      }
+      return;
+    }
     float xf[NS];
     float F[NS * NS], fx[NS];
     gather(mj, xf);
@@ -178,25 +271,45 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
     const float u0 = uin.p ? uin.p[b * uin.sB + t * uin.sT] : 0.f;
 
     // ================= _condition_on (inference.py:72-105), linearised at the predicted mean
-    float xf[NS], H[M * NS], hx[M], HrRHr[M * M];
-    gather(mj, xf);
-    emi_linearize<NS, M>(mdl, xf, u0, H, hx, HrRHr);
-    float Hcol[CPL][M];
-    BF_UNROLL for (int cc = 0; cc < CPL; ++cc) BF_UNROLL for (int a = 0; a < M; ++a)
-        Hcol[cc][a] = pick<NL>(H, M * NS, jl, CPL, a * NS + cc);
-    float v[M];
-    BF_UNROLL for (int a = 0; a < M; ++a) v[a] = yv[a] - hx[a];
-    float X[M * CPL];
-    BF_UNROLL for (int a = 0; a < M; ++a) BF_UNROLL for (int cc = 0; cc < CPL; ++cc) {
-      float s = H[a * NS] * Pc[cc][0];
-      BF_UNROLL for (int i = 1; i < NS; ++i) s = fmaf(H[a * NS + i], Pc[cc][i], s);
-      X[a * CPL + cc] = s;
-    }
-    float S[M * M];
-    BF_UNROLL for (int a = 0; a < M; ++a) BF_UNROLL for (int bb = 0; bb < M; ++bb) {
-      float s = X[a * CPL] * Hcol[0][bb];
-      BF_UNROLL for (int cc = 1; cc < CPL; ++cc) s = fmaf(X[a * CPL + cc], Hcol[cc][bb], s);
-      S[a * M + bb] = HrRHr[a * M + bb] + group_sum<NL>(s);
+    float v[M], X[M * CPL], S[M * M];
+    if constexpr (L96) {
+      // h picks the even states: H_x P and H_x P H_x^T are rows / entries of P
+      static_for<0, M>([&](auto A) {
+        constexpr int a = decltype(A)::value;
+        v[a] = yv[a] - (group_bcast<NL, (2 * a) / CPL>(mj[(2 * a) % CPL]) + mdl.Dr0[a]);
+        static_for<0, CPL>([&](auto C) {
+          constexpr int cc = decltype(C)::value;
+          float x = Pc[cc][wrapn(2 * a)];
+          static_for<1, NL>([&](auto Q) {
+            constexpr int ql = decltype(Q)::value;
+            x = (jl == ql) ? Pc[cc][wrapn(2 * a - ql * CPL)] : x;
+          });
+          X[a * CPL + cc] = x;
+        });
+        static_for<0, M>([&](auto Bb) {
+          constexpr int bb = decltype(Bb)::value;
+          constexpr int own = (2 * bb) / CPL;
+          S[a * M + bb] = mdl.DRD[a * M + bb] + group_bcast<NL, own>(Pc[(2 * bb) % CPL][wrapn(2 * a - own * CPL)]);
+        });
+      });
+    } else {
+      float xf[NS], H[M * NS], hx[M], HrRHr[M * M];
+      gather(mj, xf);
+      emi_linearize<NS, M>(mdl, xf, u0, H, hx, HrRHr);
+      float Hcol[CPL][M];
+      BF_UNROLL for (int cc = 0; cc < CPL; ++cc) BF_UNROLL for (int a = 0; a < M; ++a)
+          Hcol[cc][a] = pick<NL>(H, M * NS, jl, CPL, a * NS + cc);
+      BF_UNROLL for (int a = 0; a < M; ++a) v[a] = yv[a] - hx[a];
+      BF_UNROLL for (int a = 0; a < M; ++a) BF_UNROLL for (int cc = 0; cc < CPL; ++cc) {
+        float s = H[a * NS] * Pc[cc][0];
+        BF_UNROLL for (int i = 1; i < NS; ++i) s = fmaf(H[a * NS + i], Pc[cc][i], s);
+        X[a * CPL + cc] = s;
+      }
+      BF_UNROLL for (int a = 0; a < M; ++a) BF_UNROLL for (int bb = 0; bb < M; ++bb) {
+        float s = X[a * CPL] * Hcol[0][bb];
+        BF_UNROLL for (int cc = 1; cc < CPL; ++cc) s = fmaf(X[a * CPL + cc], Hcol[cc][bb], s);
+        S[a * M + bb] = HrRHr[a * M + bb] + group_sum<NL>(s);
+      }
     }
     psd_solve<M, CPL>(S, X, mdl.jitter);
     float KS[CPL][M];
@@ -208,7 +321,11 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
     static_for<0, NS>([&](auto I) {
       constexpr int i = decltype(I)::value;
       float ks_i[M];
-      BF_UNROLL for (int bb = 0; bb < M; ++bb) ks_i[bb] = group_bcast<NL, i / CPL>(KS[i % CPL][bb]);
+      // K S of the column that is row i of this lane's slots
+      BF_UNROLL for (int bb = 0; bb < M; ++bb) {
+        if constexpr (L96) ks_i[bb] = group_rot<NL, i / CPL>(KS[i % CPL][bb]);
+        else ks_i[bb] = group_bcast<NL, i / CPL>(KS[i % CPL][bb]);
+      }
       BF_UNROLL for (int cc = 0; cc < CPL; ++cc) {
         float s = ks_i[0] * X[cc];
         BF_UNROLL for (int bb = 1; bb < M; ++bb) s = fmaf(ks_i[bb], X[bb * CPL + cc], s);
@@ -237,7 +354,7 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
       if (out.m.p) BF_UNROLL for (int cc = 0; cc < CPL; ++cc) lds[oM + putM + int(t % TM::TS) * NS + cc] = mj[cc];
       if (out.P.p) {
         const int o = oP + putP + int(t % TP::TS) * EP;
-        BF_UNROLL for (int i = 0; i < NS; ++i) BF_UNROLL for (int cc = 0; cc < CPL; ++cc) lds[o + i * NS + cc] = Pc[cc][i];
+        BF_UNROLL for (int i = 0; i < NS; ++i) BF_UNROLL for (int cc = 0; cc < CPL; ++cc) lds[o + rowabs(i) * NS + cc] = Pc[cc][i];
       }
       if (jl == 0) {
         if (out.w.p) lds[oW + putW + int(t % TW::TS)] = w;
@@ -257,7 +374,7 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
         const int col = jl * CPL + cc;
         if (out.m.p) out.m.p[b * out.m.sB + k * out.m.sK + t * out.m.sT + col * out.m.sE] = mj[cc];
         if (out.P.p) BF_UNROLL for (int i = 0; i < NS; ++i)
-            out.P.p[b * out.P.sB + k * out.P.sK + t * out.P.sT + (i * NS + col) * out.P.sE] = Pc[cc][i];
+            out.P.p[b * out.P.sB + k * out.P.sK + t * out.P.sT + (rowabs(i) * NS + col) * out.P.sE] = Pc[cc][i];
       }
       if (jl == 0) {
         if (out.w.p) out.w.p[b * out.w.sB + k * out.w.sK + t * out.w.sT] = w;
@@ -273,7 +390,7 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
       if (out.pm.p) BF_UNROLL for (int cc = 0; cc < CPL; ++cc) lds[opM + putM + int(t % TM::TS) * NS + cc] = mj[cc];
       if (out.pP.p) {
         const int o = opP + putP + int(t % TP::TS) * EP;
-        BF_UNROLL for (int i = 0; i < NS; ++i) BF_UNROLL for (int cc = 0; cc < CPL; ++cc) lds[o + i * NS + cc] = Pc[cc][i];
+        BF_UNROLL for (int i = 0; i < NS; ++i) BF_UNROLL for (int cc = 0; cc < CPL; ++cc) lds[o + rowabs(i) * NS + cc] = Pc[cc][i];
       }
       const long long t1 = t + 1;
       const bool last = t1 == T;
@@ -314,7 +431,7 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
         const int col = jl * CPL + cc;
         if (out.pm.p) out.pm.p[b * out.pm.sB + k * out.pm.sK + t * out.pm.sT + col * out.pm.sE] = mj[cc];
         if (out.pP.p) BF_UNROLL for (int i = 0; i < NS; ++i)
-            out.pP.p[b * out.pP.sB + k * out.pP.sK + t * out.pP.sT + (i * NS + col) * out.pP.sE] = Pc[cc][i];
+            out.pP.p[b * out.pP.sB + k * out.pP.sK + t * out.pP.sT + (rowabs(i) * NS + col) * out.pP.sE] = Pc[cc][i];
       }
     }
   }
@@ -323,7 +440,7 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
     BF_UNROLL for (int cc = 0; cc < CPL; ++cc) {
       const int col = jl * CPL + cc;
       if (carry.m_out) carry.m_out[chain * NS + col] = mj[cc];
-      if (carry.P_out) BF_UNROLL for (int i = 0; i < NS; ++i) carry.P_out[chain * EP + i * NS + col] = Pc[cc][i];
+      if (carry.P_out) BF_UNROLL for (int i = 0; i < NS; ++i) carry.P_out[chain * EP + rowabs(i) * NS + col] = Pc[cc][i];
     }
     if (carry.w_out && jl == 0) carry.w_out[chain] = w;
   }
@@ -446,7 +563,23 @@ static inline bool gsf_stream_is_reference(const bf_stream& s, long long E, long
                               (reinterpret_cast<uintptr_t>(s.ptr) % 16 == 0));
 }
 
-template <int N, int M, int NL>
+// Lorenz-96 dynamics (F_q = I) observed through the matrix that picks the even states with H_r = I:
+// the model SPEC_L96_PICK is written for
+static inline bool gsf_is_l96_pick(const bf_model* p) {
+  const int n = p->n, m = p->m;
+  if (p->dyn_id != DYN_LORENZ96 || p->emi_id != EMI_LINEAR || n < 4 || 2 * m != n || p->dq != n || p->dr != m) return false;
+  if (p->flags & BF_MODEL_LEGACY_GSF_COV) return false;
+  if (p->n_emi_theta != m * n + m * m) return false;
+  for (int a = 0; a < m; ++a)
+    for (int i = 0; i < n; ++i)
+      if (p->emi_theta[a * n + i] != ((i == 2 * a) ? 1.0f : 0.0f)) return false;
+  for (int a = 0; a < m; ++a)
+    for (int b = 0; b < m; ++b)
+      if (p->emi_theta[m * n + a * m + b] != ((a == b) ? 1.0f : 0.0f)) return false;
+  return true;
+}
+
+template <int N, int M, int NL, int SPEC = SPEC_GENERIC>
 static inline int launch_gsf(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int K,
                       const bf_carry* carry, const bf_out_desc* out, hipStream_t stream, int force_mode) {
   using Cfg = GsfCfg<N, M, NL>;
@@ -485,16 +618,16 @@ static inline int launch_gsf(const bf_model* p, const bf_cstream* y, const bf_cs
     if (mode == EMIT_STAGED)
       lds_per_wave = ((Cfg::TP::TS == 1 && nP == 2) ? 1 : nP) * Cfg::TP::FLOATS + nM * Cfg::TM::FLOATS + nW * Cfg::TW::FLOATS;
   lds_per_wave = (lds_per_wave + 3) & ~3;
-  const size_t lds_bytes = sizeof(float) * (8 + (size_t)lds_per_wave * 4);
+  const size_t lds_bytes = sizeof(float) * (8 + (SPEC == SPEC_L96_PICK ? N * N : 0) + (size_t)lds_per_wave * 4);
   if (lds_bytes > 160 * 1024) return set_error(BF_EUNSUPPORTED, "staging tiles exceed the 160 KiB LDS");
   dim3 block(256);
   dim3 grid((unsigned)((B + tpb - 1) / tpb));
   if (mode == EMIT_SCALAR) {
-    hipLaunchKernelGGL((gsf_scan_kernel<N, M, NL, EMIT_SCALAR>), grid, block, lds_bytes, stream, e, yv, uv, cv, ov, B, T, K,
+    hipLaunchKernelGGL((gsf_scan_kernel<N, M, NL, EMIT_SCALAR, SPEC>), grid, block, lds_bytes, stream, e, yv, uv, cv, ov, B, T, K,
                        KP, lds_per_wave);
   } else {
     if constexpr (Cfg::STAGED_OK)
-      hipLaunchKernelGGL((gsf_scan_kernel<N, M, NL, EMIT_STAGED>), grid, block, lds_bytes, stream, e, yv, uv, cv, ov, B, T, K,
+      hipLaunchKernelGGL((gsf_scan_kernel<N, M, NL, EMIT_STAGED, SPEC>), grid, block, lds_bytes, stream, e, yv, uv, cv, ov, B, T, K,
                          KP, lds_per_wave);
   }
   BF_HIP_CHECK(hipGetLastError());

@@ -40,6 +40,20 @@ __device__ __forceinline__ float group_bcast(float v) {
   }
 }
 
+// value of the lane R places further round the caller's NL-lane group: lane j reads lane (j + R) mod NL
+template <int NL, int R>
+__device__ __forceinline__ float group_rot(float v) {
+  static_assert(NL == 1 || NL == 2 || NL == 4, "rotations are DPP quad permutations");
+  constexpr int r = ((R % NL) + NL) % NL;
+  if constexpr (r == 0) {
+    return v;
+  } else if constexpr (NL == 2) {
+    return dpp_mov<0xB1>(v);  // quad_perm [1,0,3,2]
+  } else {
+    return dpp_mov<(r & 3) | (((r + 1) & 3) << 2) | (((r + 2) & 3) << 4) | (((r + 3) & 3) << 6)>(v);
+  }
+}
+
 // sum over the NL lanes of the group, result in every lane (xor butterfly: 1, 2, 4, ...)
 template <int NL>
 __device__ __forceinline__ float group_sum(float v) {

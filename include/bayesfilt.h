@@ -108,7 +108,10 @@ int bf_device_count(void);
  *   "kf_emit_mode": -1 = choose the store path from the layout (default), 0 = strided dword
  *                   stores, 2 = LDS time-transpose (contiguous reference layout only).
  *   "kf_lanes":     lanes that cooperate on one trajectory (0 = default for the dimensions;
- *                   otherwise one of the compiled powers of two, e.g. 1, 2 or 4 at n = 4). */
+ *                   otherwise one of the compiled powers of two, e.g. 1, 2 or 4 at n = 4).
+ *   "gsf_structured": 1 (default) lets bf_gsf_ekf_f32 use the structure-aware kernel instances
+ *                   (banded Lorenz-96 Jacobian, selection emission) when the model qualifies;
+ *                   0 forces the dense generic instances. */
 int bf_set_option(const char* name, int value);
 
 /* Batched Kalman filter: B independent trajectories, one component each (K = 1), T steps.

@@ -237,3 +237,59 @@ def test_staged_partial_rows_and_single_trajectory_waves():
     finally:
         _mode(-1)
     _check(post, ref, tol=3e-5)
+
+
+def _opt(name, value):
+    from bayesianfiltering_amd import _lib
+    lib = _lib.require_gpu()
+    _lib.check(lib.bf_set_option(name, value))
+
+
+@pytest.mark.parametrize("n,lanes", [(8, 2), (8, 1), (8, 4), (4, 2), (4, 1), (6, 2)])
+@pytest.mark.parametrize("lmode", ["matrix_power", "as_written"])
+def test_structured_lorenz96_instances(n, lanes, lmode):
+    """The structure-aware Lorenz-96 instances (banded Jacobian, selection emission, relative
+    covariance coordinates) against the oracle and against the dense generic instances, with a
+    non-diagonal Q, non-zero noise biases, K = 8 and both store paths; the scan is also split in two
+    chunks through the carry."""
+    bfa, nl = _nl()
+    rng = np.random.default_rng(100 * n + lanes)
+    m, K, T, B = n // 2, 8, 24, 8
+    Lq = (0.1 * np.eye(n) + 0.02 * rng.normal(size=(n, n))).astype(F32)
+    Q = (Lq @ Lq.T).astype(F32)
+    R = (1e-1 * np.eye(m) + 0.01 * np.ones((m, m))).astype(F32)
+    q0 = (0.01 * rng.normal(size=n)).astype(F32)
+    r0 = (0.01 * rng.normal(size=m)).astype(F32)
+    po = go.ParamsNLSSM(np.zeros(n, F32), np.eye(n, dtype=F32), om.Lorenz96(n, mode=lmode), q0, Q, om.PickEven(n), r0, R)
+    pp = bfa.ParamsNLSSM(np.zeros(n, F32), np.eye(n, dtype=F32), nl.lorenz96(n, mode=lmode), q0, Q, nl.pick_even(n), r0, R)
+    ys = np.stack([go.sample_ssm(po, otf.PRNGKey(b), T)[1] for b in range(B)])
+    init = rng.normal(size=(B, K, n)).astype(F32)
+    ref = _oracle_batch(po, ys, K, init)
+    res = {}
+    for structured in (1, 0):
+        _opt(b"gsf_structured", structured)
+        _opt(b"kf_lanes", lanes if structured else 0)   # the dense table holds one lane count per (n, m)
+        try:
+            for mode in (-1, 0):
+                _mode(mode)
+                res[structured, mode] = bfa.gaussian_sum_filter(pp, ys, K, 1, initial_means=init)
+        finally:
+            _mode(-1)
+            _opt(b"kf_lanes", 0)
+            _opt(b"gsf_structured", 1)
+    _check(res[1, -1], ref, tol=3e-5)
+    _check(res[0, -1], ref, tol=3e-5)
+    for k in FIELDS + ("weights",):
+        a, b = getattr(res[1, -1], k).cpu().numpy(), getattr(res[1, 0], k).cpu().numpy()
+        assert np.array_equal(a, b), k                      # staged == strided stores, bit for bit
+        assert cm.rel_err(a, getattr(res[0, -1], k).cpu().numpy()) < 1e-5, k   # structured ~ dense
+    # two chunks through the carry reproduce the single scan bit for bit
+    _opt(b"kf_lanes", lanes)
+    try:
+        p1, c1 = bfa.gaussian_sum_filter(pp, ys[:, :16], K, 1, initial_means=init, return_carry=True)
+        p2 = bfa.gaussian_sum_filter(pp, ys[:, 16:], K, 1, carry=c1)
+    finally:
+        _opt(b"kf_lanes", 0)
+    for k in FIELDS + ("weights",):
+        full = getattr(res[1, -1], k).cpu().numpy()
+        assert np.array_equal(np.concatenate([getattr(p1, k).cpu().numpy(), getattr(p2, k).cpu().numpy()], axis=2), full), k
