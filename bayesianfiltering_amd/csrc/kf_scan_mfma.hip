@@ -13,11 +13,11 @@
 // wave's row blocks of A and its tile of G Q G^T) stay in VGPRs in MFMA operand layout for the
 // whole scan; H and D R D^T are LDS-resident.  Per step:
 //   A  H P            (waves 0,1; K = 64)          hm = H m, v = y - hm                 (wave 2)
-//   B  S = (H P) H^T + D R D^T                     (wave 0; K = 64)
+//   B  S = (H P) H^T + D R D^T                     (wave 3; K = 64)
 //   C  chol(S + 1e-6) and its inverse L^-1         (wave 0, rows in registers, v_readlane broadcasts)
-//      chol(S), z = L^-1 v, log-likelihood         (wave 1)
-//   E  W = L^-1 (H P),  F  X = L^-T W = (S + 1e-6)^-1 H P   (waves 0,1; K = 32)     K = X^T
-//   G  K S = X^T S    (waves 0,1; K = 32)          m+ = m + X^T v                       (wave 2)
+//      chol(S), z = L^-1 v, log-likelihood         (wave 3)
+//   E  W = L^-1 (H P),  F  X = L^-T W = (S + 1e-6)^-1 H P   (waves 2,3; K = 32)     K = X^T
+//   G  K S = X^T S    (waves 2,3; K = 32)          m+ = m + X^T v                       (wave 1)
 //   H  P+ = P - (K S) X                            (all waves; K = 32)
 //   I  A P+           (all waves; K = 64)          m- = A m+ + G q0                 (waves 0,3)
 //   J  P- = (A P+) A^T + G Q G^T                   (all waves; K = 64)
@@ -48,24 +48,36 @@ __device__ __forceinline__ float rdlane(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
-// In-wave Cholesky of a 32x32 SPD matrix: lane (l & 31) holds row l of the matrix in a[0..31];
-// on return a[k] (k <= row) holds L[row][k].  Column j: every lane forms its s = A[i][j] -
-// sum_k L[i][k] L[j][k] with L[j][k] broadcast from lane j by v_readlane.
-__device__ __forceinline__ void chol32_rows(float* a, int li) {
+// In-wave Cholesky of a 32x32 SPD matrix, right-looking: lane (l & 31) holds row l of the matrix in
+// a[0..31]; on return a[k] (k <= row) holds L[row][k] and lane k of rdv holds 1 / L[k][k].  Column j
+// is scaled by 1 / sqrt(A[j][j]) (broadcast from lane j by v_readlane) and the trailing rows are
+// updated with the outer product at once: the 31 - j updates of a step are independent, so the wave
+// issues them back to back instead of waiting on one accumulation chain per column.
+__device__ __forceinline__ void chol32_rows(float* a, float& rdv, int li) {
   static_for<0, 32>([&](auto J) {
     constexpr int j = decltype(J)::value;
-    // (one accumulation chain on purpose: splitting it into partial sums, or the right-looking
-    // outer-product form, raises register pressure past the 256-VGPR budget and spills)
-    float s = a[j];
-    static_for<0, j>([&](auto Kk) {
-      constexpr int k = decltype(Kk)::value;
-      s = fmaf(-a[k], rdlane(a[k], j), s);
+    // 1 / sqrt(A[j][j]): v_rsq_f32 plus one Newton step (~1 ulp; the raw approximation alone costs
+    // the 1e-5 parity budget over 32 columns, the IEEE sqrt + division sequences are ~35 dependent
+    // instructions per column on the serial path).  NaN if not positive definite.
+    const float dj = rdlane(a[j], j);
+    const float y0 = __builtin_amdgcn_rsqf(dj);
+    const float e0 = fmaf(-(dj * y0), y0, 1.0f);
+    const float rinv = fmaf(0.5f * y0, e0, y0);
+    rdv = (li == j) ? rinv : rdv;
+    const float lj = a[j] * rinv;            // L[row][j] for row > j (rows < j: unused upper triangle)
+    a[j] = lj;
+    // broadcasts in batches of 8 into distinct SGPRs, then the 8 updates: a v_readlane result needs
+    // wait states before a VALU may read it, which the batch hides (the scheduler would otherwise
+    // funnel every broadcast through one SGPR with s_nops in between)
+    static_for<0, (31 - j + 7) / 8>([&](auto Cc) {
+      constexpr int k0 = j + 1 + 8 * decltype(Cc)::value;
+      constexpr int kn = (32 - k0) < 8 ? (32 - k0) : 8;
+      float bc[8];
+      static_for<0, kn>([&](auto Q) { bc[decltype(Q)::value] = rdlane(lj, k0 + decltype(Q)::value); });
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, kn>([&](auto Q) { a[k0 + decltype(Q)::value] = fmaf(-lj, bc[decltype(Q)::value], a[k0 + decltype(Q)::value]); });
+      __builtin_amdgcn_sched_barrier(0);
     });
-    // IEEE sqrt / division here: the 32-step factorization and its explicit inverse compound
-    // rounding errors, and these 64 scalar ops per step are noise against the MFMA work
-    const float d = sqrtf(rdlane(s, j));  // NaN if not positive definite
-    const float rinv = 1.0f / d;
-    a[j] = (li == j) ? d : s * rinv;
   });
 }
 
@@ -77,7 +89,10 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
   constexpr int PS = M + 1;  // LDS pitch of 32-wide matrices
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Roles are assigned to a rotated wave index: the wave that runs the serial factorization (role 0)
+  // then sits on a different SIMD in neighbouring workgroups, so the two workgroups a CU holds do
+  // not queue their scalar-heavy phases on the same SIMD.
+  const int wave = __builtin_amdgcn_readfirstlane(((tid >> 6) + (int)blockIdx.x) & 3);
   const int ti = wave >> 1, tj = wave & 1;
   const int lr = lane & 31, lk = lane >> 5;
   const long long b = blockIdx.x;
@@ -94,13 +109,11 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
   float* sy = sv + M;              // [32] observation
   float* sH = sy + M;              // [32][65]  H (operand source; keeping it in VGPRs spills the factorization)
   float* sD = sH + M * PP;         // [32][33]  D R D^T
+  float* sA = sD + M * PS;         // [64][65]  A
 
-  // ---- constant operands in MFMA layout: lane holds X[32*blk + (l & 31)][2 s + (l >> 5)]
-  float Ati[32], Atj[32];
-  BF_UNROLL for (int s = 0; s < 32; ++s) {
-    Ati[s] = cst->A[(32 * ti + lr) * N + 2 * s + lk];
-    Atj[s] = cst->A[(32 * tj + lr) * N + 2 * s + lk];
-  }
+  // ---- constant operands: A, H, D R D^T in LDS (the MFMA operand pattern X[32*blk + (l & 31)][2 s + (l >> 5)]
+  // is conflict-free with the odd pitch); keeping A in VGPRs spills the factorization
+  for (int e = tid; e < N * N; e += 256) sA[(e / N) * PP + (e % N)] = cst->A[e];
   for (int e = tid; e < M * N; e += 256) sH[(e / N) * PP + (e % N)] = cst->H[e];
   for (int e = tid; e < M * M; e += 256) sD[(e / M) * PS + (e % M)] = cst->DRD[e];
   f32x16 gqg, Pacc;
@@ -114,6 +127,13 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
   float ynext = (wave == 2 && lane < M) ? y.p[b * y.sB + lane * y.sE] : 0.f;
   __syncthreads();
 
+#ifdef BF_MFMA_PHASE_TIMERS  // debug build: per-phase wall-clock ticks of workgroup 0 (scripts/mfma_phase_probe.py)
+  long long tacc[10] = {0};
+  long long tprev = wall_clock64();
+#define BF_TICK(i) { const long long tn_ = wall_clock64(); tacc[i] += tn_ - tprev; tprev = tn_; }
+#else
+#define BF_TICK(i)
+#endif
   float* mcur = sm;
   float* mnxt = sm2;
   for (long long t = 0; t < T; ++t) {
@@ -131,77 +151,90 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
       s += __shfl_xor(s, 32, 64);
       if (lane < M) sv[lane] = sy[lane] - (s + cst->Dr0[lane]);
     }
+    BF_TICK(0)
     __syncthreads();
-    // ================= phase B: S = (H P) H^T + D R D^T (wave 0)
-    if (wave == 0) {
+    // ================= phase B: S = (H P) H^T + D R D^T (wave 3)
+    if (wave == 3) {
       f32x16 acc;
       BF_UNROLL for (int r = 0; r < 16; ++r) acc[r] = sD[c_row(r, lane) * PS + lr];
       BF_UNROLL for (int s = 0; s < 32; ++s) acc = mfma2(sT[lr * PP + 2 * s + lk], sH[lr * PP + 2 * s + lk], acc);
       BF_UNROLL for (int r = 0; r < 16; ++r) sS[c_row(r, lane) * PS + lr] = acc[r];
     }
+    BF_TICK(1)
     __syncthreads();
-    // ================= phase C: factorizations (waves 0 and 1)
+    // ================= phase C: factorizations (waves 0 and 3)
     float ll = 0.f;
     if (wave == 0) {
       float a[32], x[32];
       BF_UNROLL for (int k = 0; k < 32; ++k) a[k] = sS[lr * PS + k] + 1e-6f;  // psd_solve's jitter on every entry
-      chol32_rows(a, lr);
-      // column (l & 31) of L^-1: x[i] = (delta_ic - sum_{k<i} L[i][k] x[k]) / L[i][i]
+      float rdv = 0.f;
+      chol32_rows(a, rdv, lr);
+      // column (l & 31) of L^-1 by forward substitution, right-looking: once x[i] is final, every
+      // later row takes its L[r][i] x[i] off at once (independent updates, L[r][i] = a[i] of lane r)
+      BF_UNROLL for (int i = 0; i < 32; ++i) x[i] = (lr == i) ? 1.f : 0.f;
       static_for<0, 32>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        float s = (lr == i) ? 1.f : 0.f;
-        static_for<0, i>([&](auto Kk) {
-          constexpr int k = decltype(Kk)::value;
-          s = fmaf(-rdlane(a[k], i), x[k], s);
+        x[i] *= rdlane(rdv, i);
+        static_for<0, (31 - i + 7) / 8>([&](auto Cc) {
+          constexpr int r0 = i + 1 + 8 * decltype(Cc)::value;
+          constexpr int rn = (32 - r0) < 8 ? (32 - r0) : 8;
+          float bc[8];
+          static_for<0, rn>([&](auto Q) { bc[decltype(Q)::value] = rdlane(a[i], r0 + decltype(Q)::value); });
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<0, rn>([&](auto Q) { x[r0 + decltype(Q)::value] = fmaf(-bc[decltype(Q)::value], x[i], x[r0 + decltype(Q)::value]); });
+          __builtin_amdgcn_sched_barrier(0);
         });
-        x[i] = s / rdlane(a[i], i);
       });
       if (lane < 32) BF_UNROLL for (int i = 0; i < 32; ++i) sLi[i * PS + lr] = x[i];
-    } else if (wave == 1) {
+    } else if (wave == 3) {
       float a[32];
       BF_UNROLL for (int k = 0; k < 32; ++k) a[k] = sS[lr * PS + k];
-      chol32_rows(a, lr);
+      float rdv = 0.f;
+      chol32_rows(a, rdv, lr);
       // z = L^-1 v by forward substitution across lanes; lane i carries the running residual of row i
       float acc = sv[lr], quad = 0.f, dprod = 1.f;
       static_for<0, 32>([&](auto Kk) {
         constexpr int k = decltype(Kk)::value;
-        const float lkk = rdlane(a[k], k);
-        const float zk = rdlane(acc, k) / lkk;
+        const float zk = rdlane(acc, k) * rdlane(rdv, k);
         quad = fmaf(zk, zk, quad);
-        dprod *= lkk;
+        dprod *= rdlane(a[k], k);
         acc = fmaf(-a[k], zk, acc);
       });
       // sum of 32 log-diagonals as log of the product, split in two to stay in range
       ll = -0.5f * quad - 0.5f * float(M) * 1.8378770664093453f - fast_log(dprod);
     }
+    BF_TICK(2)
     __syncthreads();
-    // ================= phase E: W = L^-1 (H P) -> sT rows 32..63 (waves 0,1; K = 32)
-    if (wave < 2) {
+    // ================= phase E: W = L^-1 (H P) -> sT rows 32..63 (waves 2,3; K = 32)
+    if (wave >= 2) {
       f32x16 acc = {0};
       BF_UNROLL for (int s = 0; s < 16; ++s)
           acc = mfma2(sLi[lr * PS + 2 * s + lk], sT[(2 * s + lk) * PP + 32 * tj + lr], acc);
       BF_UNROLL for (int r = 0; r < 16; ++r) sT[(32 + c_row(r, lane)) * PP + 32 * tj + lr] = acc[r];
     }
+    BF_TICK(3)
     __syncthreads();
-    // ================= phase F: X = L^-T W -> sT rows 0..31
-    if (wave < 2) {
+    // ================= phase F: X = L^-T W -> sT rows 0..31 (waves 2,3)
+    if (wave >= 2) {
       f32x16 acc = {0};
       BF_UNROLL for (int s = 0; s < 16; ++s)
           acc = mfma2(sLi[(2 * s + lk) * PS + lr], sT[(32 + 2 * s + lk) * PP + 32 * tj + lr], acc);
       BF_UNROLL for (int r = 0; r < 16; ++r) sT[c_row(r, lane) * PP + 32 * tj + lr] = acc[r];
     }
+    BF_TICK(4)
     __syncthreads();
-    // ================= phase G: -(K S) = -(X^T S), row block `wave` (waves 0,1); m+ (wave 2)
-    if (wave < 2) {
+    // ================= phase G: -(K S) = -(X^T S), row block tj (waves 2,3); m+ (wave 1)
+    if (wave >= 2) {
       f32x16 acc = {0};
       BF_UNROLL for (int s = 0; s < 16; ++s)
-          acc = mfma2(sT[(2 * s + lk) * PP + 32 * wave + lr], sS[(2 * s + lk) * PS + lr], acc);
-      BF_UNROLL for (int r = 0; r < 16; ++r) sKS[(32 * wave + c_row(r, lane)) * PS + lr] = -acc[r];
-    } else if (wave == 2) {
+          acc = mfma2(sT[(2 * s + lk) * PP + 32 * tj + lr], sS[(2 * s + lk) * PS + lr], acc);
+      BF_UNROLL for (int r = 0; r < 16; ++r) sKS[(32 * tj + c_row(r, lane)) * PS + lr] = -acc[r];
+    } else if (wave == 1) {
       float s = mcur[lane];
       BF_UNROLL for (int a = 0; a < M; ++a) s = fmaf(sT[a * PP + lane], sv[a], s);
       mnxt[lane] = s;  // filtered mean
     }
+    BF_TICK(5)
     __syncthreads();
     // ================= phase H: P+ = P - (K S) X (all waves; K = 32); emit filtered streams
     BF_UNROLL for (int s = 0; s < 16; ++s)
@@ -210,39 +243,46 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
     if (out.P.p) BF_UNROLL for (int r = 0; r < 16; ++r)
         out.P.p[b * out.P.sB + t * out.P.sT + ((32 * ti + c_row(r, lane)) * N + 32 * tj + lr) * out.P.sE] = Pacc[r];
     if (wave == 2 && out.m.p) out.m.p[b * out.m.sB + t * out.m.sT + lane * out.m.sE] = mnxt[lane];
-    if (wave == 1 && lane == 0) {
+    if (wave == 3 && lane == 0) {
       w = reweight_single(ll, w);
       if (out.w.p) out.w.p[b * out.w.sB + t * out.w.sT] = w;
       if (out.ll.p) out.ll.p[b * out.ll.sB + t * out.ll.sT] = ll;
     }
+    BF_TICK(6)
     __syncthreads();
     // ================= phase I: A P+ -> sT (all waves; K = 64); m- = A m+ + G q0 (waves 0, 3)
     {
       f32x16 acc = {0};
-      BF_UNROLL for (int s = 0; s < 32; ++s) acc = mfma2(Ati[s], sP[(2 * s + lk) * PP + 32 * tj + lr], acc);
+      BF_UNROLL for (int s = 0; s < 32; ++s) acc = mfma2(sA[(32 * ti + lr) * PP + 2 * s + lk], sP[(2 * s + lk) * PP + 32 * tj + lr], acc);
       BF_UNROLL for (int r = 0; r < 16; ++r) sT[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = acc[r];
     }
     if (wave == 0 || wave == 3) {
       float s = 0.f;
-      BF_UNROLL for (int q = 0; q < 32; ++q) s = fmaf(Ati[q], mnxt[2 * q + lk], s);
+      BF_UNROLL for (int q = 0; q < 32; ++q) s = fmaf(sA[(32 * ti + lr) * PP + 2 * q + lk], mnxt[2 * q + lk], s);
       s += __shfl_xor(s, 32, 64);
       if (lane < 32) mcur[32 * ti + lane] = s + cst->Gq0[32 * ti + lane];  // predicted mean
     }
+    BF_TICK(7)
     __syncthreads();
     // ================= phase J: P- = (A P+) A^T + G Q G^T (all waves; K = 64); emit predicted streams
     Pacc = gqg;
-    BF_UNROLL for (int s = 0; s < 32; ++s) Pacc = mfma2(sT[(32 * ti + lr) * PP + 2 * s + lk], Atj[s], Pacc);
+    BF_UNROLL for (int s = 0; s < 32; ++s) Pacc = mfma2(sT[(32 * ti + lr) * PP + 2 * s + lk], sA[(32 * tj + lr) * PP + 2 * s + lk], Pacc);
     BF_UNROLL for (int r = 0; r < 16; ++r) sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = Pacc[r];
     if (out.pP.p) BF_UNROLL for (int r = 0; r < 16; ++r)
         out.pP.p[b * out.pP.sB + t * out.pP.sT + ((32 * ti + c_row(r, lane)) * N + 32 * tj + lr) * out.pP.sE] = Pacc[r];
     if (wave == 2 && out.pm.p) out.pm.p[b * out.pm.sB + t * out.pm.sT + lane * out.pm.sE] = mcur[lane];
+    BF_TICK(8)
     __syncthreads();
   }
 
   if (carry.P_out) BF_UNROLL for (int r = 0; r < 16; ++r)
       carry.P_out[b * N * N + (32 * ti + c_row(r, lane)) * N + 32 * tj + lr] = Pacc[r];
   if (carry.m_out && tid < N) carry.m_out[b * N + tid] = mcur[tid];
-  if (carry.w_out && wave == 1 && lane == 0) carry.w_out[b] = w;
+  if (carry.w_out && wave == 3 && lane == 0) carry.w_out[b] = w;
+#ifdef BF_MFMA_PHASE_TIMERS
+  __syncthreads();
+  if (b == 0 && lane == 0 && carry.P_out) for (int i = 0; i < 10; ++i) carry.P_out[wave * 16 + i] = (float)tacc[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -309,7 +349,7 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
   CarryView cv{carry->w_in, carry->m_in, carry->P_in, carry->w_out, carry->m_out, carry->P_out};
   OutViews ov{make_sview(out->weights), make_sview(out->means), make_sview(out->covs),
               make_sview(out->pred_means), make_sview(out->pred_covs), make_sview(out->loglik)};
-  const size_t lds_bytes = sizeof(float) * (size_t)(2 * N * (N + 1) + N * (M + 1) + 3 * M * (M + 1) + M * (N + 1) + 2 * N + 2 * M);
+  const size_t lds_bytes = sizeof(float) * (size_t)(3 * N * (N + 1) + N * (M + 1) + 3 * M * (M + 1) + M * (N + 1) + 2 * N + 2 * M);
   auto kern = kf_scan_mfma_kernel<N, M>;
   if (lds_bytes > 64 * 1024)
     BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
