@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbayesfilt_hip.so")
+# BAYESFILT_HIP_LIB: load another build of the same C-ABI (e.g. one with debug timers compiled in)
+LIB_PATH = os.environ.get("BAYESFILT_HIP_LIB") or os.path.join(_HERE, "libbayesfilt_hip.so")
 
 BF_OK, BF_EINVAL, BF_EUNSUPPORTED, BF_EHIP, BF_ENOGPU = 0, -1, -2, -3, -4
 

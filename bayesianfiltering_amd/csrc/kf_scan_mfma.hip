@@ -33,6 +33,9 @@
 namespace bf {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using lds_f = __attribute__((address_space(3))) float;
+using v4f = __attribute__((ext_vector_type(4))) float;
+using lds_f4 = const __attribute__((address_space(3))) v4f;
 
 template <int N, int M>
 struct MfmaConst {  // device-resident (too large for kernel arguments)
@@ -48,37 +51,125 @@ __device__ __forceinline__ float rdlane(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
+// A zero the compiler cannot see through, produced inside the time loop: LDS addresses formed from it
+// are loop-variant, so they stay "register + immediate offset" operands instead of being hoisted out
+// of the loop as hundreds of loop-invariant address registers (which then spill).
+__device__ __forceinline__ int opaque_zero() {
+  int z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+  return z;
+}
+
+__device__ __forceinline__ void wave_lds_order() {  // order one wave's LDS traffic (the hardware runs it in issue order)
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 // In-wave Cholesky of a 32x32 SPD matrix, right-looking: lane (l & 31) holds row l of the matrix in
-// a[0..31]; on return a[k] (k <= row) holds L[row][k] and lane k of rdv holds 1 / L[k][k].  Column j
-// is scaled by 1 / sqrt(A[j][j]) (broadcast from lane j by v_readlane) and the trailing rows are
-// updated with the outer product at once: the 31 - j updates of a step are independent, so the wave
-// issues them back to back instead of waiting on one accumulation chain per column.
-__device__ __forceinline__ void chol32_rows(float* a, float& rdv, int li) {
+// a[0..31]; on return a[k] (k < row) holds L[row][k], lane k of rdv holds 1 / L[k][k], and the LDS
+// block Lc holds the factor by columns, Lc[32 j + i] = L[i][j] for i > j with 1 / L[j][j] on the
+// diagonal.  Column j is scaled by 1 / sqrt(A[j][j]) and the trailing rows take the outer product
+// off at once (31 - j independent updates).  The multipliers L[k][j], k > j, are the same for every
+// lane: the column goes to LDS and comes back as broadcast ds_read_b128s -- a v_readlane per
+// multiplier (SGPR write + wait states + one VALU slot each) was 3x slower on the serial path.
+__device__ __forceinline__ float rsqrt_newton(float d) {
+  // 1 / sqrt(d): v_rsq_f32 plus one Newton step (~1 ulp; the raw approximation alone costs the 1e-5
+  // parity budget over 32 columns, the IEEE sqrt + division sequences are ~35 dependent instructions
+  // per column on the serial path).  NaN for d < 0 (matrix not positive definite).
+  const float y0 = __builtin_amdgcn_rsqf(d);
+  const float e0 = fmaf(-(d * y0), y0, 1.0f);
+  return fmaf(0.5f * y0, e0, y0);
+}
+
+template <class LP>
+__device__ __forceinline__ void chol32_rows(float* a, float& rdv, int li, LP Lc) {
+  float rinv = rsqrt_newton(rdlane(a[0], 0));
   static_for<0, 32>([&](auto J) {
     constexpr int j = decltype(J)::value;
-    // 1 / sqrt(A[j][j]): v_rsq_f32 plus one Newton step (~1 ulp; the raw approximation alone costs
-    // the 1e-5 parity budget over 32 columns, the IEEE sqrt + division sequences are ~35 dependent
-    // instructions per column on the serial path).  NaN if not positive definite.
-    const float dj = rdlane(a[j], j);
-    const float y0 = __builtin_amdgcn_rsqf(dj);
-    const float e0 = fmaf(-(dj * y0), y0, 1.0f);
-    const float rinv = fmaf(0.5f * y0, e0, y0);
     rdv = (li == j) ? rinv : rdv;
     const float lj = a[j] * rinv;            // L[row][j] for row > j (rows < j: unused upper triangle)
     a[j] = lj;
-    // broadcasts in batches of 8 into distinct SGPRs, then the 8 updates: a v_readlane result needs
-    // wait states before a VALU may read it, which the batch hides (the scheduler would otherwise
-    // funnel every broadcast through one SGPR with s_nops in between)
-    static_for<0, (31 - j + 7) / 8>([&](auto Cc) {
-      constexpr int k0 = j + 1 + 8 * decltype(Cc)::value;
-      constexpr int kn = (32 - k0) < 8 ? (32 - k0) : 8;
-      float bc[8];
-      static_for<0, kn>([&](auto Q) { bc[decltype(Q)::value] = rdlane(lj, k0 + decltype(Q)::value); });
-      __builtin_amdgcn_sched_barrier(0);
-      static_for<0, kn>([&](auto Q) { a[k0 + decltype(Q)::value] = fmaf(-lj, bc[decltype(Q)::value], a[k0 + decltype(Q)::value]); });
-      __builtin_amdgcn_sched_barrier(0);
+    Lc[32 * j + li] = (li == j) ? rinv : lj;
+    if constexpr (j < 31) {
+      // look-ahead: row j + 1 takes its update through a lane broadcast and the next column's
+      // reciprocal square root starts at once, overlapping the LDS round trip of the other rows
+      a[j + 1] = fmaf(-lj, rdlane(lj, j + 1), a[j + 1]);
+      rinv = rsqrt_newton(rdlane(a[j + 1], j + 1));
+      wave_lds_order();
+      // rows up to the next multiple of four one by one, the rest as whole float4s
+      constexpr int kq = (j + 2 + 3) / 4 * 4;
+      static_for<j + 2, (kq < 32 ? kq : 32)>([&](auto Kk) {
+        constexpr int k = decltype(Kk)::value;
+        a[k] = fmaf(-lj, Lc[32 * j + k], a[k]);
+      });
+      static_for<kq / 4, 8>([&](auto Qd) {
+        constexpr int q = decltype(Qd)::value;
+        const v4f v = *reinterpret_cast<lds_f4*>(Lc + 32 * j + 4 * q);
+        a[4 * q + 0] = fmaf(-lj, v.x, a[4 * q + 0]);
+        a[4 * q + 1] = fmaf(-lj, v.y, a[4 * q + 1]);
+        a[4 * q + 2] = fmaf(-lj, v.z, a[4 * q + 2]);
+        a[4 * q + 3] = fmaf(-lj, v.w, a[4 * q + 3]);
+      });
+    }
+  });
+}
+
+// Phase C of the scan as out-of-line functions: everything they touch lives in LDS, so the call costs
+// a few scalar moves, and the factorization gets a register allocation of its own (inlined into the
+// 10-phase kernel body the compiler hoists address arithmetic across the time loop and spills).
+//
+// chol(S + 1e-6) and its inverse: sLi[i][c] = (L^-1)[i][c]
+__device__ __attribute__((noinline)) void factor_and_invert(lds_f* sS, lds_f* Lc, lds_f* sLi, int lane) {
+  constexpr int PS = 33;
+  const int lr = lane & 31;
+  float a[32], x[32];
+  BF_UNROLL for (int k = 0; k < 32; ++k) a[k] = sS[lr * PS + k] + 1e-6f;  // psd_solve's jitter on every entry
+  float rdv = 0.f;
+  chol32_rows(a, rdv, lr, Lc);
+  wave_lds_order();
+  // column (l & 31) of L^-1 by forward substitution, right-looking: once x[i] is final, every later
+  // row takes its L[r][i] x[i] off at once (independent updates, multipliers broadcast from Lc)
+  BF_UNROLL for (int i = 0; i < 32; ++i) x[i] = (lr == i) ? 1.f : 0.f;
+  static_for<0, 32>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    x[i] *= Lc[32 * i + i];  // 1 / L[i][i]
+    constexpr int rq = (i + 1 + 3) / 4 * 4;
+    static_for<i + 1, (rq < 32 ? rq : 32)>([&](auto R) {
+      constexpr int r = decltype(R)::value;
+      x[r] = fmaf(-Lc[32 * i + r], x[i], x[r]);
+    });
+    static_for<rq / 4, 8>([&](auto Qd) {
+      constexpr int q = decltype(Qd)::value;
+      const v4f v = *reinterpret_cast<lds_f4*>(Lc + 32 * i + 4 * q);
+      x[4 * q + 0] = fmaf(-v.x, x[i], x[4 * q + 0]);
+      x[4 * q + 1] = fmaf(-v.y, x[i], x[4 * q + 1]);
+      x[4 * q + 2] = fmaf(-v.z, x[i], x[4 * q + 2]);
+      x[4 * q + 3] = fmaf(-v.w, x[i], x[4 * q + 3]);
     });
   });
+  if (lane < 32) BF_UNROLL for (int i = 0; i < 32; ++i) sLi[i * PS + lr] = x[i];
+}
+
+// chol(S) (no jitter), z = L^-1 v, log N(v; 0, S) -- inference.py:104, :24
+__device__ __attribute__((noinline)) float factor_loglik(lds_f* sS, lds_f* Lc, lds_f* sv, int lane) {
+  constexpr int PS = 33;
+  const int lr = lane & 31;
+  float a[32];
+  BF_UNROLL for (int k = 0; k < 32; ++k) a[k] = sS[lr * PS + k];
+  float rdv = 0.f;
+  chol32_rows(a, rdv, lr, Lc);
+  // z = L^-1 v by forward substitution across lanes; lane i carries the running residual of row i
+  float acc = sv[lr], quad = 0.f, dprod = 1.f;
+  static_for<0, 32>([&](auto Kk) {
+    constexpr int k = decltype(Kk)::value;
+    const float zk = rdlane(acc, k) * rdlane(rdv, k);
+    quad = fmaf(zk, zk, quad);
+    dprod *= rdlane(a[k], k);
+    acc = fmaf(-a[k], zk, acc);
+  });
+  // sum of 32 log-diagonals as log of the product (32 factors of O(1) stay in range)
+  return -0.5f * quad - 0.5f * 32.0f * 1.8378770664093453f - fast_log(dprod);
 }
 
 template <int N, int M>
@@ -116,12 +207,10 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
   for (int e = tid; e < N * N; e += 256) sA[(e / N) * PP + (e % N)] = cst->A[e];
   for (int e = tid; e < M * N; e += 256) sH[(e / N) * PP + (e % N)] = cst->H[e];
   for (int e = tid; e < M * M; e += 256) sD[(e / M) * PS + (e % M)] = cst->DRD[e];
-  f32x16 gqg, Pacc;
-  BF_UNROLL for (int r = 0; r < 16; ++r) {
-    gqg[r] = cst->GQG[(32 * ti + c_row(r, lane)) * N + 32 * tj + lr];
-    Pacc[r] = carry.P_in[b * N * N + (32 * ti + c_row(r, lane)) * N + 32 * tj + lr];
-    sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = Pacc[r];
-  }
+  // the wave's tile of P lives in LDS between phases (and in the accumulators inside H and J):
+  // nothing but scalars is live in registers across the factorization phase
+  BF_UNROLL for (int r = 0; r < 16; ++r)
+    sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = carry.P_in[b * N * N + (32 * ti + c_row(r, lane)) * N + 32 * tj + lr];
   if (tid < N) sm[tid] = carry.m_in[b * N + tid];
   float w = carry.w_in ? carry.w_in[b] : 1.0f;
   float ynext = (wave == 2 && lane < M) ? y.p[b * y.sB + lane * y.sE] : 0.f;
@@ -165,43 +254,10 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
     // ================= phase C: factorizations (waves 0 and 3)
     float ll = 0.f;
     if (wave == 0) {
-      float a[32], x[32];
-      BF_UNROLL for (int k = 0; k < 32; ++k) a[k] = sS[lr * PS + k] + 1e-6f;  // psd_solve's jitter on every entry
-      float rdv = 0.f;
-      chol32_rows(a, rdv, lr);
-      // column (l & 31) of L^-1 by forward substitution, right-looking: once x[i] is final, every
-      // later row takes its L[r][i] x[i] off at once (independent updates, L[r][i] = a[i] of lane r)
-      BF_UNROLL for (int i = 0; i < 32; ++i) x[i] = (lr == i) ? 1.f : 0.f;
-      static_for<0, 32>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        x[i] *= rdlane(rdv, i);
-        static_for<0, (31 - i + 7) / 8>([&](auto Cc) {
-          constexpr int r0 = i + 1 + 8 * decltype(Cc)::value;
-          constexpr int rn = (32 - r0) < 8 ? (32 - r0) : 8;
-          float bc[8];
-          static_for<0, rn>([&](auto Q) { bc[decltype(Q)::value] = rdlane(a[i], r0 + decltype(Q)::value); });
-          __builtin_amdgcn_sched_barrier(0);
-          static_for<0, rn>([&](auto Q) { x[r0 + decltype(Q)::value] = fmaf(-bc[decltype(Q)::value], x[i], x[r0 + decltype(Q)::value]); });
-          __builtin_amdgcn_sched_barrier(0);
-        });
-      });
-      if (lane < 32) BF_UNROLL for (int i = 0; i < 32; ++i) sLi[i * PS + lr] = x[i];
+      // -(K S) is dead between phases H and G: scratch for the factor columns of both factorizations
+      factor_and_invert((lds_f*)sS, (lds_f*)sKS, (lds_f*)sLi, lane);
     } else if (wave == 3) {
-      float a[32];
-      BF_UNROLL for (int k = 0; k < 32; ++k) a[k] = sS[lr * PS + k];
-      float rdv = 0.f;
-      chol32_rows(a, rdv, lr);
-      // z = L^-1 v by forward substitution across lanes; lane i carries the running residual of row i
-      float acc = sv[lr], quad = 0.f, dprod = 1.f;
-      static_for<0, 32>([&](auto Kk) {
-        constexpr int k = decltype(Kk)::value;
-        const float zk = rdlane(acc, k) * rdlane(rdv, k);
-        quad = fmaf(zk, zk, quad);
-        dprod *= rdlane(a[k], k);
-        acc = fmaf(-a[k], zk, acc);
-      });
-      // sum of 32 log-diagonals as log of the product, split in two to stay in range
-      ll = -0.5f * quad - 0.5f * float(M) * 1.8378770664093453f - fast_log(dprod);
+      ll = factor_loglik((lds_f*)sS, (lds_f*)(sKS + 1024), (lds_f*)sv, lane);
     }
     BF_TICK(2)
     __syncthreads();
@@ -237,6 +293,8 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
     BF_TICK(5)
     __syncthreads();
     // ================= phase H: P+ = P - (K S) X (all waves; K = 32); emit filtered streams
+    f32x16 Pacc;
+    BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] = sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr];
     BF_UNROLL for (int s = 0; s < 16; ++s)
         Pacc = mfma2(sKS[(32 * ti + lr) * PS + 2 * s + lk], sT[(2 * s + lk) * PP + 32 * tj + lr], Pacc);
     BF_UNROLL for (int r = 0; r < 16; ++r) sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = Pacc[r];
@@ -265,7 +323,7 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
     BF_TICK(7)
     __syncthreads();
     // ================= phase J: P- = (A P+) A^T + G Q G^T (all waves; K = 64); emit predicted streams
-    Pacc = gqg;
+    BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] = cst->GQG[(32 * ti + c_row(r, lane)) * N + 32 * tj + lr];
     BF_UNROLL for (int s = 0; s < 32; ++s) Pacc = mfma2(sT[(32 * ti + lr) * PP + 2 * s + lk], sA[(32 * tj + lr) * PP + 2 * s + lk], Pacc);
     BF_UNROLL for (int r = 0; r < 16; ++r) sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = Pacc[r];
     if (out.pP.p) BF_UNROLL for (int r = 0; r < 16; ++r)
@@ -276,7 +334,7 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
   }
 
   if (carry.P_out) BF_UNROLL for (int r = 0; r < 16; ++r)
-      carry.P_out[b * N * N + (32 * ti + c_row(r, lane)) * N + 32 * tj + lr] = Pacc[r];
+      carry.P_out[b * N * N + (32 * ti + c_row(r, lane)) * N + 32 * tj + lr] = sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr];
   if (carry.m_out && tid < N) carry.m_out[b * N + tid] = mcur[tid];
   if (carry.w_out && wave == 3 && lane == 0) carry.w_out[b] = w;
 #ifdef BF_MFMA_PHASE_TIMERS
