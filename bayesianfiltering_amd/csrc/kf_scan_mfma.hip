@@ -14,7 +14,8 @@
 // whole scan; H and D R D^T are LDS-resident.  Per step:
 //   A  H P            (waves 0,1; K = 64)          hm = H m, v = y - hm                 (wave 2)
 //   B  S = (H P) H^T + D R D^T                     (wave 3; K = 64)
-//   C  chol(S + 1e-6) and its inverse L^-1         (wave 0, rows in registers, v_readlane broadcasts)
+//   C  chol(S + 1e-6) (wave 0, rows in registers, multipliers broadcast through LDS) with its inverse
+//      L^-1 trailing it column block by column block on wave 1
 //      chol(S), z = L^-1 v, log-likelihood         (wave 3)
 //   E  W = L^-1 (H P),  F  X = L^-T W = (S + 1e-6)^-1 H P   (waves 2,3; K = 32)     K = X^T
 //   G  K S = X^T S    (waves 2,3; K = 32)          m+ = m + X^T v                       (wave 1)
@@ -34,6 +35,7 @@ namespace bf {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using lds_f = __attribute__((address_space(3))) float;
+using lds_i = __attribute__((address_space(3))) int;
 using v4f = __attribute__((ext_vector_type(4))) float;
 using lds_f4 = const __attribute__((address_space(3))) v4f;
 
@@ -82,8 +84,8 @@ __device__ __forceinline__ float rsqrt_newton(float d) {
   return fmaf(0.5f * y0, e0, y0);
 }
 
-template <class LP>
-__device__ __forceinline__ void chol32_rows(float* a, float& rdv, int li, LP Lc) {
+template <bool PUBLISH, class LP>
+__device__ __forceinline__ void chol32_rows(float* a, float& rdv, int li, LP Lc, lds_i* progress) {
   float rinv = rsqrt_newton(rdlane(a[0], 0));
   static_for<0, 32>([&](auto J) {
     constexpr int j = decltype(J)::value;
@@ -91,6 +93,10 @@ __device__ __forceinline__ void chol32_rows(float* a, float& rdv, int li, LP Lc)
     const float lj = a[j] * rinv;            // L[row][j] for row > j (rows < j: unused upper triangle)
     a[j] = lj;
     Lc[32 * j + li] = (li == j) ? rinv : lj;
+    if constexpr (PUBLISH && j % 4 == 3) {  // columns up to j are in LDS: let the inverting wave proceed
+      wave_lds_order();
+      *progress = j + 1;
+    }
     if constexpr (j < 31) {
       // look-ahead: row j + 1 takes its update through a lane broadcast and the next column's
       // reciprocal square root starts at once, overlapping the LDS round trip of the other rows
@@ -119,20 +125,33 @@ __device__ __forceinline__ void chol32_rows(float* a, float& rdv, int li, LP Lc)
 // a few scalar moves, and the factorization gets a register allocation of its own (inlined into the
 // 10-phase kernel body the compiler hoists address arithmetic across the time loop and spills).
 //
-// chol(S + 1e-6) and its inverse: sLi[i][c] = (L^-1)[i][c]
-__device__ __attribute__((noinline)) void factor_and_invert(lds_f* sS, lds_f* Lc, lds_f* sLi, int lane) {
+// chol(S + 1e-6), published four columns at a time: Lc[32 j + i] = L[i][j] (1 / L[j][j] on the
+// diagonal) and *progress = number of finished columns
+__device__ __attribute__((noinline)) void factor_publish(lds_f* sS, lds_f* Lc, lds_i* progress, int lane) {
   constexpr int PS = 33;
   const int lr = lane & 31;
-  float a[32], x[32];
+  float a[32];
   BF_UNROLL for (int k = 0; k < 32; ++k) a[k] = sS[lr * PS + k] + 1e-6f;  // psd_solve's jitter on every entry
   float rdv = 0.f;
-  chol32_rows(a, rdv, lr, Lc);
-  wave_lds_order();
-  // column (l & 31) of L^-1 by forward substitution, right-looking: once x[i] is final, every later
-  // row takes its L[r][i] x[i] off at once (independent updates, multipliers broadcast from Lc)
+  chol32_rows<true>(a, rdv, lr, Lc, progress);
+}
+
+// The inverse of that factor, computed by another wave while the factorization is still running:
+// step i of the forward substitution needs column i of L only, so this wave trails the factorizing
+// one by a block of columns (it polls *progress) and the two serial chains overlap instead of adding
+// up.  sLi[i][c] = (L^-1)[i][c]; lane (l & 31) holds column c = l & 31.
+__device__ __attribute__((noinline)) void invert_following(lds_f* Lc, lds_i* progress, lds_f* sLi, int lane) {
+  constexpr int PS = 33;
+  const int lr = lane & 31;
+  float x[32];
   BF_UNROLL for (int i = 0; i < 32; ++i) x[i] = (lr == i) ? 1.f : 0.f;
+  int seen = 0;
   static_for<0, 32>([&](auto I) {
     constexpr int i = decltype(I)::value;
+    if constexpr (i % 4 == 0) {  // columns are published four at a time
+      while (seen < i + 4) seen = *(volatile lds_i*)progress;  // wave-uniform; the producer always reaches 32
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     x[i] *= Lc[32 * i + i];  // 1 / L[i][i]
     constexpr int rq = (i + 1 + 3) / 4 * 4;
     static_for<i + 1, (rq < 32 ? rq : 32)>([&](auto R) {
@@ -158,7 +177,7 @@ __device__ __attribute__((noinline)) float factor_loglik(lds_f* sS, lds_f* Lc, l
   float a[32];
   BF_UNROLL for (int k = 0; k < 32; ++k) a[k] = sS[lr * PS + k];
   float rdv = 0.f;
-  chol32_rows(a, rdv, lr, Lc);
+  chol32_rows<false>(a, rdv, lr, Lc, nullptr);
   // z = L^-1 v by forward substitution across lanes; lane i carries the running residual of row i
   float acc = sv[lr], quad = 0.f, dprod = 1.f;
   static_for<0, 32>([&](auto Kk) {
@@ -198,7 +217,8 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
   float* sm2 = sm + N;             // [64] mean (ping-pong)
   float* sv = sm2 + N;             // [32] innovation
   float* sy = sv + M;              // [32] observation
-  float* sH = sy + M;              // [32][65]  H (operand source; keeping it in VGPRs spills the factorization)
+  int* sflag = reinterpret_cast<int*>(sy + M);  // [4] columns of chol(S + 1e-6) published so far
+  float* sH = sy + M + 4;          // [32][65]  H (operand source; keeping it in VGPRs spills the factorization)
   float* sD = sH + M * PP;         // [32][33]  D R D^T
   float* sA = sD + M * PS;         // [64][65]  A
 
@@ -212,6 +232,7 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
   BF_UNROLL for (int r = 0; r < 16; ++r)
     sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = carry.P_in[b * N * N + (32 * ti + c_row(r, lane)) * N + 32 * tj + lr];
   if (tid < N) sm[tid] = carry.m_in[b * N + tid];
+  if (tid == 0) sflag[0] = 0;
   float w = carry.w_in ? carry.w_in[b] : 1.0f;
   float ynext = (wave == 2 && lane < M) ? y.p[b * y.sB + lane * y.sE] : 0.f;
   __syncthreads();
@@ -255,7 +276,9 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
     float ll = 0.f;
     if (wave == 0) {
       // -(K S) is dead between phases H and G: scratch for the factor columns of both factorizations
-      factor_and_invert((lds_f*)sS, (lds_f*)sKS, (lds_f*)sLi, lane);
+      factor_publish((lds_f*)sS, (lds_f*)sKS, (lds_i*)sflag, lane);
+    } else if (wave == 1) {
+      invert_following((lds_f*)sKS, (lds_i*)sflag, (lds_f*)sLi, lane);
     } else if (wave == 3) {
       ll = factor_loglik((lds_f*)sS, (lds_f*)(sKS + 1024), (lds_f*)sv, lane);
     }
@@ -301,6 +324,7 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
     if (out.P.p) BF_UNROLL for (int r = 0; r < 16; ++r)
         out.P.p[b * out.P.sB + t * out.P.sT + ((32 * ti + c_row(r, lane)) * N + 32 * tj + lr) * out.P.sE] = Pacc[r];
     if (wave == 2 && out.m.p) out.m.p[b * out.m.sB + t * out.m.sT + lane * out.m.sE] = mnxt[lane];
+    if (wave == 0 && lane == 0) sflag[0] = 0;  // re-armed two barriers before the next factorization
     if (wave == 3 && lane == 0) {
       w = reweight_single(ll, w);
       if (out.w.p) out.w.p[b * out.w.sB + t * out.w.sT] = w;
@@ -407,7 +431,7 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
   CarryView cv{carry->w_in, carry->m_in, carry->P_in, carry->w_out, carry->m_out, carry->P_out};
   OutViews ov{make_sview(out->weights), make_sview(out->means), make_sview(out->covs),
               make_sview(out->pred_means), make_sview(out->pred_covs), make_sview(out->loglik)};
-  const size_t lds_bytes = sizeof(float) * (size_t)(3 * N * (N + 1) + N * (M + 1) + 3 * M * (M + 1) + M * (N + 1) + 2 * N + 2 * M);
+  const size_t lds_bytes = sizeof(float) * (size_t)(3 * N * (N + 1) + N * (M + 1) + 3 * M * (M + 1) + M * (N + 1) + 2 * N + 2 * M + 4);
   auto kern = kf_scan_mfma_kernel<N, M>;
   if (lds_bytes > 64 * 1024)
     BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
