@@ -221,19 +221,25 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
     BF_UNROLL for (int p = 0; p < PPT; ++p) {
       const uint32_t i = valid[p] ? (uint32_t)(tid * PPT + p) : 0u;
       const U32x2 ki = threefry_split(k0, k1, i + 1u, (uint32_t)NP + 1u);
-      float z[DQ], q[DQ], xn[N];
+      float q[DQ], xn[N];
+      // q = q0 + chol(Q) z accumulated column by column as the normals arrive (same fmaf order per
+      // entry as the row-wise product: ascending column), so no z vector stays live.
       // normal(key_i, (dq,)): block j yields entries j and h + j
       constexpr int h = (DQ + 1) / 2;
+      float zhi[h];
+      BF_UNROLL for (int d = 0; d < DQ; ++d) q[d] = 0.f;
       BF_UNROLL for (int j = 0; j < h; ++j) {
         const U32x2 o = threefry2x32(ki.x, ki.y, (uint32_t)j, (h + j < DQ) ? (uint32_t)(h + j) : 0u);
-        z[j] = bits_to_normal(o.x);
-        if (h + j < DQ) z[h + j] = bits_to_normal(o.y);
+        const float zj = bits_to_normal(o.x);
+        zhi[j] = (h + j < DQ) ? bits_to_normal(o.y) : 0.f;
+        if (mdl.lq_diag) q[j] = mdl.LQ[j * DQ + j] * zj;
+        else BF_UNROLL for (int d = j; d < DQ; ++d) q[d] = fmaf(mdl.LQ[d * DQ + j], zj, q[d]);
       }
-      BF_UNROLL for (int d = 0; d < DQ; ++d) {
-        float s = 0.f;
-        BF_UNROLL for (int c = 0; c <= d; ++c) s = fmaf(mdl.LQ[d * DQ + c], z[c], s);
-        q[d] = mdl.q0[d] + s;
+      BF_UNROLL for (int j = 0; h + j < DQ; ++j) {
+        if (mdl.lq_diag) q[h + j] = mdl.LQ[(h + j) * DQ + h + j] * zhi[j];
+        else BF_UNROLL for (int d = h + j; d < DQ; ++d) q[d] = fmaf(mdl.LQ[d * DQ + h + j], zhi[j], q[d]);
       }
+      BF_UNROLL for (int d = 0; d < DQ; ++d) q[d] = mdl.q0[d] + q[d];
       dyn_value<N, DQ, M>(mdl, x[p], q, u0, xn);
       BF_UNROLL for (int d = 0; d < N; ++d) x[p][d] = xn[d];
       // MVN(h(x), R).log_prob(y) through the Cholesky factor (tfp), forward substitution
@@ -247,6 +253,9 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
         quad = fmaf(zz[a], zz[a], quad);
       }
       ll[p] = valid[p] ? (-0.5f * quad + mdl.lp_const) : -__builtin_inff();
+      // one particle at a time: interleaving the PPT independent Threefry / erfinv chains overruns the
+      // 128-VGPR budget of the 1024-thread geometry and spills
+      __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- reweight (inference.py:1350-1353)

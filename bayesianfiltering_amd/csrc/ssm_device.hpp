@@ -11,7 +11,7 @@ namespace bf {
 
 template <int N, int DQ, int M>
 struct BpfModel {
-  int dyn_id, emi_id, g_identity, pad_;
+  int dyn_id, emi_id, g_identity, lq_diag;  // lq_diag: chol(Q) is diagonal (its zero entries are skipped)
   float dth[8], eth[8];
   float A[N * N];     // linear dynamics
   float Gm[N * DQ];   // F_q (noise input matrix); identity when g_identity
@@ -191,6 +191,10 @@ static inline int fill_bpf_model(const bf_bpf_model* bp, BpfModel<N, DQ, M>& e) 
   }
   for (int i = 0; i < DQ; ++i) e.q0[i] = p->q0 ? p->q0[i] : 0.f;
   if (cholesky_lower(p->Q, DQ, e.LQ) != 0) return set_error(BF_EINVAL, "dynamics noise covariance is not positive definite");
+  e.lq_diag = 1;
+  for (int i = 0; i < DQ; ++i)
+    for (int k = 0; k < i; ++k)
+      if (e.LQ[i * DQ + k] != 0.f) e.lq_diag = 0;
   if (cholesky_lower(bp->lp_cov, M, e.LR) != 0) return set_error(BF_EINVAL, "log-prob covariance is not positive definite");
   float logdet = 0.f;
   for (int i = 0; i < M; ++i) {
