@@ -183,3 +183,81 @@ def require_device_function(fn, kind, what):
             f"(got {type(fn).__name__}): Python callables cannot run inside the HIP kernels, and "
             "there is no CPU fallback.")
     return fn
+
+
+# ---------------------------------------------------------------------------------------------
+# Scalar test nonlinearities of gaussfiltax/nonlinearities.py:4-34 (f1..f5 with gradient J and
+# Hessian H).  Host-side NumPy helpers: the reference only uses them to exercise second-order
+# moment approximations on the CPU, they are not part of the device registry.  The reference's H1
+# and H2 read an undefined global `dx`; here the dimension comes from the argument.
+class ScalarTestFunction:
+    """value / gradient / hessian triple of one scalar-valued test function."""
+
+    def __init__(self, name, value, gradient, hessian):
+        self.name, self.value, self.gradient, self.hessian = name, value, gradient, hessian
+
+    def __call__(self, x, *args):
+        return self.value(np.asarray(x, dtype=np.float64), *args)
+
+    def __repr__(self):
+        return f"<scalar test function {self.name}>"
+
+
+def _f1():  # (1 + x.x)^(p/2)                                            nonlinearities.py:5-7
+    def val(x, p):
+        return (1.0 + x @ x) ** (p / 2)
+
+    def grad(x, p):
+        x = np.asarray(x, dtype=np.float64)
+        return p * (1.0 + x @ x) ** (p / 2 - 1) * x
+
+    def hess(x, p):
+        x = np.asarray(x, dtype=np.float64)
+        s = 1.0 + x @ x
+        return 2 * p * (p / 2 - 1) * s ** (p / 2 - 2) * np.outer(x, x) + p * s ** (p / 2 - 1) * np.eye(x.size)
+
+    return ScalarTestFunction("f1", val, grad, hess)
+
+
+def _f2():  # sinc of the squared norm: sin(x.x) / x.x                     nonlinearities.py:10-17
+    def val(x):
+        r = x @ x
+        return np.sin(r) / r
+
+    def grad(x):
+        x = np.asarray(x, dtype=np.float64)
+        r = x @ x
+        return 2.0 * (r * np.cos(r) - np.sin(r)) / r ** 2 * x
+
+    def hess(x):
+        x = np.asarray(x, dtype=np.float64)
+        r = x @ x
+        g = (r * np.cos(r) - np.sin(r)) / r ** 2          # d/dr [sin r / r]
+        gp = -np.sin(r) / r - 2.0 * (r * np.cos(r) - np.sin(r)) / r ** 3
+        return 4.0 * gp * np.outer(x, x) + 2.0 * g * np.eye(x.size)
+
+    return ScalarTestFunction("f2", val, grad, hess)
+
+
+def _f3():  # x0 sin x1                                                    nonlinearities.py:20-22
+    return ScalarTestFunction(
+        "f3", lambda x: x[0] * np.sin(x[1]),
+        lambda x: np.array([np.sin(x[1]), x[0] * np.cos(x[1])]),
+        lambda x: np.array([[0.0, np.cos(x[1])], [np.cos(x[1]), -x[0] * np.sin(x[1])]]))
+
+
+def _f4():  # x0 + sin x1                                                  nonlinearities.py:25-27
+    return ScalarTestFunction(
+        "f4", lambda x: x[0] + np.sin(x[1]),
+        lambda x: np.array([1.0, np.cos(x[1])]),
+        lambda x: np.array([[0.0, 0.0], [0.0, -np.sin(x[1])]]))
+
+
+def _f5(a=1.0, b=1.0):  # x^T diag(a, b) x / 2                             nonlinearities.py:30-34
+    A = np.diag([float(a), float(b)])
+    return ScalarTestFunction("f5", lambda x: 0.5 * (x @ A @ x), lambda x: A @ np.asarray(x, dtype=np.float64), lambda x: A)
+
+
+f1, f2, f3, f4, f5 = _f1(), _f2(), _f3(), _f4(), _f5()
+J1, J2, J3, J4, J5 = f1.gradient, f2.gradient, f3.gradient, f4.gradient, f5.gradient
+H1, H2, H3, H4, H5 = f1.hessian, f2.hessian, f3.hessian, f4.hessian, f5.hessian

@@ -1,0 +1,36 @@
+"""Scalar test nonlinearities f1..f5 (gaussfiltax/nonlinearities.py:4-34): gradients and Hessians
+against central finite differences (CPU, float64)."""
+import numpy as np
+import pytest
+
+
+def _fd_grad(f, x, h=1e-6):
+    g = np.zeros_like(x)
+    for i in range(x.size):
+        e = np.zeros_like(x); e[i] = h
+        g[i] = (f(x + e) - f(x - e)) / (2 * h)
+    return g
+
+
+def _fd_hess(grad, x, h=1e-6):
+    H = np.zeros((x.size, x.size))
+    for i in range(x.size):
+        e = np.zeros_like(x); e[i] = h
+        H[:, i] = (grad(x + e) - grad(x - e)) / (2 * h)
+    return H
+
+
+@pytest.mark.parametrize("name,args,dim", [("f1", (3.0,), 3), ("f1", (0.5,), 2), ("f2", (), 3), ("f3", (), 2),
+                                           ("f4", (), 2), ("f5", (), 2)])
+def test_gradient_and_hessian(name, args, dim):
+    from bayesianfiltering_amd import nonlinearities as nl
+    fn = getattr(nl, name)
+    rng = np.random.default_rng(dim * 7 + len(name))
+    for _ in range(5):
+        x = rng.normal(size=dim) + 0.3
+        g = fn.gradient(x, *args)
+        H = fn.hessian(x, *args)
+        assert np.allclose(g, _fd_grad(lambda z: fn(z, *args), x), rtol=1e-5, atol=1e-7)
+        assert np.allclose(H, _fd_hess(lambda z: fn.gradient(z, *args), x), rtol=1e-4, atol=1e-6)
+        assert np.allclose(H, H.T)
+    assert nl.J3 is nl.f3.gradient and nl.H5 is nl.f5.hessian
