@@ -6,9 +6,10 @@ from .containers import GaussianComponent, GaussianSum
 from .inference import (PosteriorGaussianSumFiltered, gaussian_sum_filter, kalman_filter, FilterCarry,
                         FULL5, FILTERED, PRNGKey, sample_initial_component_means,
                         bootstrap_particle_filter, ParticleCarry, resample_indices)
+from ._lib import BayesFiltError
 from . import nonlinearities, utils
 
 __all__ = ["ParamsNLSSM", "ParamsBPF", "NonlinearSSM", "GaussianComponent", "GaussianSum", "PosteriorGaussianSumFiltered",
            "gaussian_sum_filter", "kalman_filter", "FilterCarry", "FULL5", "FILTERED", "PRNGKey",
            "sample_initial_component_means", "bootstrap_particle_filter", "ParticleCarry", "resample_indices",
-           "nonlinearities", "utils"]
+           "nonlinearities", "utils", "BayesFiltError"]

@@ -50,7 +50,8 @@ class bf_lgssm(C.Structure):
 class bf_model(C.Structure):
     _fields_ = [("dyn_id", C.c_int32), ("emi_id", C.c_int32), ("n", C.c_int32), ("dq", C.c_int32), ("m", C.c_int32),
                 ("dr", C.c_int32), ("dyn_theta", _FP), ("n_dyn_theta", C.c_int32), ("emi_theta", _FP),
-                ("n_emi_theta", C.c_int32), ("q0", _FP), ("r0", _FP), ("Q", _FP), ("R", _FP), ("flags", C.c_int32)]
+                ("n_emi_theta", C.c_int32), ("q0", _FP), ("r0", _FP), ("Q", _FP), ("R", _FP), ("flags", C.c_int32),
+                ("Q_steps", C.c_int32), ("R_steps", C.c_int32)]
 
 
 BF_MODEL_PREDICT_FIRST, BF_MODEL_NO_JITTER, BF_MODEL_LEGACY_GSF_COV = 1, 2, 4

@@ -31,6 +31,7 @@
 // dword stores.
 #pragma once
 #include <cstring>
+#include <vector>
 #include "bf_common.hpp"
 #include "kf_math.hpp"
 #include "lane_group.hpp"
@@ -70,7 +71,7 @@ constexpr int wrap_mod(int i) {
 template <int NS, int M, int NL, int MODE, int SPEC>
 __global__ void __launch_bounds__(256, 2)
 gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutViews out, long long B, long long T, int K,
-                int KP, int lds_per_wave) {
+                int KP, int lds_per_wave, const float* __restrict__ tv_gqg, const float* __restrict__ tv_drd) {
   using Cfg = GsfCfg<NS, M, NL>;
   constexpr int CPL = Cfg::CPL, CPW = Cfg::CPW, EP = Cfg::EP;
   using TP = typename Cfg::TP;
@@ -175,7 +176,9 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
 
   // _predict (inference.py:51-70), linearised at the current (filtered) mean; also run once before the
   // scan for the legacy classes' predict -> update order (gaussfilt.py:113-121)
-  auto predict = [&](float u0) __attribute__((always_inline)) {
+  // tv_gqg / tv_drd: per-step F_q Q_t F_q^T [T][n*n] and H_r R_t H_r^T [T][m*m] when the covariances vary in
+  // time (_get_params(..., 2, t), inference.py:21,:337-340); NULL = the constants in mdl
+  auto predict = [&](float u0, long long tq) __attribute__((always_inline)) {
     if constexpr (L96) {
       (void)u0;
       const float alpha = mdl.dth[0], beta = mdl.dth[1], gamma = mdl.dth[2], dt = mdl.dth[3];
@@ -257,13 +260,15 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
         BF_UNROLL for (int cc = 0; cc < CPL; ++cc) acc[cc] = (l == 0) ? ap_l * Frow[cc][0] : fmaf(ap_l, Frow[cc][l], acc[cc]);
       });
       BF_UNROLL for (int cc = 0; cc < CPL; ++cc)
-          Pc[cc][i] = acc[cc] + (mdl.cov_quirk ? Pc0[cc][i] : pick<NL>(mdl.GQG, NS * NS, jl, CPL, i * NS + cc));
+          Pc[cc][i] = acc[cc] + (mdl.cov_quirk ? Pc0[cc][i]
+                                     : tv_gqg   ? tv_gqg[tq * EP + i * NS + jl * CPL + cc]
+                                                : pick<NL>(mdl.GQG, NS * NS, jl, CPL, i * NS + cc));
     }
     BF_UNROLL for (int cc = 0; cc < CPL; ++cc) mj[cc] = pick<NL>(fx, NS, jl, CPL, cc);
 
   };
 
-  if (mdl.predict_first) predict(uin.p ? uin.p[b * uin.sB] : 0.f);
+  if (mdl.predict_first) predict(uin.p ? uin.p[b * uin.sB] : 0.f, 0);
 
   for (long long t = 0; t < T; ++t) {
     float yv[M];
@@ -296,6 +301,7 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
       float xf[NS], H[M * NS], hx[M], HrRHr[M * M];
       gather(mj, xf);
       emi_linearize<NS, M>(mdl, xf, u0, H, hx, HrRHr);
+      if (tv_drd) BF_UNROLL for (int i = 0; i < M * M; ++i) HrRHr[i] = tv_drd[t * (M * M) + i];
       float Hcol[CPL][M];
       BF_UNROLL for (int cc = 0; cc < CPL; ++cc) BF_UNROLL for (int a = 0; a < M; ++a)
           Hcol[cc][a] = pick<NL>(H, M * NS, jl, CPL, a * NS + cc);
@@ -383,7 +389,7 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
     }
 
     // ================= _predict
-    predict(u0);
+    predict(u0, t);
 
     // ---- emit predicted streams, flush completed rows
     if constexpr (MODE == EMIT_STAGED) {
@@ -453,8 +459,10 @@ static inline int next_pow2_i(int v) {
   return p;
 }
 
+// tvq / tvr: filled with the per-step F_q Q_t F_q^T / H_r R_t H_r^T when p->Q_steps / p->R_steps > 1
 template <int N, int M>
-static inline int fill_model(const bf_model* p, EkfModel<N, M>& e) {
+static inline int fill_model(const bf_model* p, EkfModel<N, M>& e, std::vector<float>* tvq = nullptr,
+                             std::vector<float>* tvr = nullptr) {
   std::memset(&e, 0, sizeof(e));
   e.dyn_id = p->dyn_id;
   e.emi_id = p->emi_id;
@@ -521,26 +529,44 @@ static inline int fill_model(const bf_model* p, EkfModel<N, M>& e) {
     default: return set_error(BF_EUNSUPPORTED, "unknown emission function id %d", p->emi_id);
   }
   // (F_q Q) F_q^T, (H_r R) H_r^T, F_q q0, H_r r0 in fp32 with the association of inference.py:69,:100
-  for (int i = 0; i < N; ++i)
-    for (int j = 0; j < N; ++j) {
-      float s = 0.f;
-      for (int l = 0; l < dq; ++l) {
-        float gq = 0.f;
-        for (int kq = 0; kq < dq; ++kq) gq = fmaf(G[i * dq + kq], p->Q[kq * dq + l], gq);
-        s = fmaf(gq, G[j * dq + l], s);
+  auto gqg_of = [&](const float* Q, float* out) {
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < N; ++j) {
+        float s = 0.f;
+        for (int l = 0; l < dq; ++l) {
+          float gq = 0.f;
+          for (int kq = 0; kq < dq; ++kq) gq = fmaf(G[i * dq + kq], Q[kq * dq + l], gq);
+          s = fmaf(gq, G[j * dq + l], s);
+        }
+        out[i * N + j] = s;
       }
-      e.GQG[i * N + j] = s;
-    }
-  for (int i = 0; i < M; ++i)
-    for (int j = 0; j < M; ++j) {
-      float s = 0.f;
-      for (int l = 0; l < dr; ++l) {
-        float d1 = 0.f;
-        for (int kr = 0; kr < dr; ++kr) d1 = fmaf(D[i * dr + kr], p->R[kr * dr + l], d1);
-        s = fmaf(d1, D[j * dr + l], s);
+  };
+  auto drd_of = [&](const float* R, float* out) {
+    for (int i = 0; i < M; ++i)
+      for (int j = 0; j < M; ++j) {
+        float s = 0.f;
+        for (int l = 0; l < dr; ++l) {
+          float d1 = 0.f;
+          for (int kr = 0; kr < dr; ++kr) d1 = fmaf(D[i * dr + kr], R[kr * dr + l], d1);
+          s = fmaf(d1, D[j * dr + l], s);
+        }
+        out[i * M + j] = s;
       }
-      e.DRD[i * M + j] = s;
-    }
+  };
+  gqg_of(p->Q, e.GQG);
+  drd_of(p->R, e.DRD);
+  if (p->Q_steps > 1) {
+    if (!tvq) return set_error(BF_EUNSUPPORTED, "time-varying Q is not supported on this path");
+    tvq->resize((size_t)p->Q_steps * N * N);
+    for (int t = 0; t < p->Q_steps; ++t) gqg_of(p->Q + (size_t)t * dq * dq, tvq->data() + (size_t)t * N * N);
+  }
+  if (p->R_steps > 1) {
+    if (!tvr) return set_error(BF_EUNSUPPORTED, "time-varying R is not supported on this path");
+    if (p->emi_id == EMI_STOCH_VOL)
+      return set_error(BF_EUNSUPPORTED, "time-varying R needs an emission with a constant noise Jacobian H_r");
+    tvr->resize((size_t)p->R_steps * M * M);
+    for (int t = 0; t < p->R_steps; ++t) drd_of(p->R + (size_t)t * dr * dr, tvr->data() + (size_t)t * M * M);
+  }
   for (int i = 0; i < N; ++i) {
     float s = 0.f;
     for (int kq = 0; kq < dq; ++kq) s = fmaf(G[i * dq + kq], p->q0 ? p->q0[kq] : 0.f, s);
@@ -569,6 +595,7 @@ static inline bool gsf_is_l96_pick(const bf_model* p) {
   const int n = p->n, m = p->m;
   if (p->dyn_id != DYN_LORENZ96 || p->emi_id != EMI_LINEAR || n < 4 || 2 * m != n || p->dq != n || p->dr != m) return false;
   if (p->flags & BF_MODEL_LEGACY_GSF_COV) return false;
+  if (p->Q_steps > 1 || p->R_steps > 1) return false;
   if (p->n_emi_theta != m * n + m * m) return false;
   for (int a = 0; a < m; ++a)
     for (int i = 0; i < n; ++i)
@@ -584,8 +611,13 @@ static inline int launch_gsf(const bf_model* p, const bf_cstream* y, const bf_cs
                       const bf_carry* carry, const bf_out_desc* out, hipStream_t stream, int force_mode) {
   using Cfg = GsfCfg<N, M, NL>;
   EkfModel<N, M> e;
-  int rc = fill_model<N, M>(p, e);
+  std::vector<float> tvq, tvr;
+  int rc = fill_model<N, M>(p, e, &tvq, &tvr);
   if (rc != BF_OK) return rc;
+  if ((p->Q_steps > 1 && p->Q_steps != T) || (p->R_steps > 1 && p->R_steps != T))
+    return set_error(BF_EINVAL, "time-varying covariances need one matrix per step (Q_steps / R_steps = T = %lld)", T);
+  if (SPEC != SPEC_GENERIC && (!tvq.empty() || !tvr.empty()))
+    return set_error(BF_EUNSUPPORTED, "structure-aware instances take constant covariances");
   const int KP = next_pow2_i(K);
   if (KP * NL > 256)
     return set_error(BF_EUNSUPPORTED, "gaussian-sum filter: %d components x %d lanes exceed one workgroup (256 lanes)", K, NL);
@@ -620,17 +652,36 @@ static inline int launch_gsf(const bf_model* p, const bf_cstream* y, const bf_cs
   lds_per_wave = (lds_per_wave + 3) & ~3;
   const size_t lds_bytes = sizeof(float) * (8 + (SPEC == SPEC_L96_PICK ? N * N : 0) + (size_t)lds_per_wave * 4);
   if (lds_bytes > 160 * 1024) return set_error(BF_EUNSUPPORTED, "staging tiles exceed the 160 KiB LDS");
+  // per-step covariance products: device copies for the duration of the launch
+  float* d_tv = nullptr;
+  const float *d_tvq = nullptr, *d_tvr = nullptr;
+  if (!tvq.empty() || !tvr.empty()) {
+    BF_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&d_tv), sizeof(float) * (tvq.size() + tvr.size()), stream));
+    hipError_t ce = hipSuccess;
+    if (!tvq.empty()) ce = hipMemcpyAsync(d_tv, tvq.data(), sizeof(float) * tvq.size(), hipMemcpyHostToDevice, stream);
+    if (ce == hipSuccess && !tvr.empty())
+      ce = hipMemcpyAsync(d_tv + tvq.size(), tvr.data(), sizeof(float) * tvr.size(), hipMemcpyHostToDevice, stream);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(stream);  // the host vectors die with this frame
+    if (ce != hipSuccess) {
+      (void)hipFreeAsync(d_tv, stream);
+      BF_HIP_CHECK(ce);
+    }
+    if (!tvq.empty()) d_tvq = d_tv;
+    if (!tvr.empty()) d_tvr = d_tv + tvq.size();
+  }
   dim3 block(256);
   dim3 grid((unsigned)((B + tpb - 1) / tpb));
   if (mode == EMIT_SCALAR) {
     hipLaunchKernelGGL((gsf_scan_kernel<N, M, NL, EMIT_SCALAR, SPEC>), grid, block, lds_bytes, stream, e, yv, uv, cv, ov, B, T, K,
-                       KP, lds_per_wave);
+                       KP, lds_per_wave, d_tvq, d_tvr);
   } else {
     if constexpr (Cfg::STAGED_OK)
       hipLaunchKernelGGL((gsf_scan_kernel<N, M, NL, EMIT_STAGED, SPEC>), grid, block, lds_bytes, stream, e, yv, uv, cv, ov, B, T, K,
-                         KP, lds_per_wave);
+                         KP, lds_per_wave, d_tvq, d_tvr);
   }
-  BF_HIP_CHECK(hipGetLastError());
+  const hipError_t le = hipGetLastError();
+  if (d_tv) (void)hipFreeAsync(d_tv, stream);
+  BF_HIP_CHECK(le);
   return BF_OK;
 }
 

@@ -125,6 +125,8 @@ static inline int cholesky_lower(const float* A, int n, float* L) {  // fp32, ro
 template <int N, int DQ, int M>
 static inline int fill_bpf_model(const bf_bpf_model* bp, BpfModel<N, DQ, M>& e) {
   const bf_model* p = &bp->ssm;
+  if (p->Q_steps > 1 || p->R_steps > 1)
+    return set_error(BF_EUNSUPPORTED, "time-varying Q/R are not supported by the sampling kernels (particle filter, data generator)");
   std::memset(&e, 0, sizeof(e));
   e.dyn_id = p->dyn_id;
   e.emi_id = p->emi_id;

@@ -240,16 +240,15 @@ class _Model:
         self.emi_theta = np.ascontiguousarray(h.theta if h.theta.size else np.zeros(1, F32))
         self.q0 = _host_f32(params.dynamics_noise_bias).reshape(self.dq)
         self.r0 = _host_f32(params.emission_noise_bias).reshape(self.dr)
-        self.Q = _host_f32(params.dynamics_noise_covariance)
-        self.R = _host_f32(params.emission_noise_covariance)
-        if self.Q.shape != (self.dq, self.dq) or self.R.shape != (self.dr, self.dr):
-            raise _lib.BayesFiltError(_lib.BF_EUNSUPPORTED,
-                                      "time-varying Q/R are only supported on the linear Kalman path (kalman_filter)")
+        # (T, d, d) covariances vary in time exactly as _get_params(x, 2, t) selects them (inference.py:21)
+        self.Q, self.Q_steps = _time_varying(params.dynamics_noise_covariance, self.dq)
+        self.R, self.R_steps = _time_varying(params.emission_noise_covariance, self.dr)
         c = _lib.bf_model()
         c.dyn_id, c.emi_id, c.n, c.dq, c.m, c.dr = f.fn_id, h.fn_id, self.n, self.dq, self.m, self.dr
         c.dyn_theta, c.n_dyn_theta = _fp(self.dyn_theta), int(f.theta.size)
         c.emi_theta, c.n_emi_theta = _fp(self.emi_theta), int(h.theta.size)
         c.q0, c.r0, c.Q, c.R = _fp(self.q0), _fp(self.r0), _fp(self.Q), _fp(self.R)
+        c.Q_steps, c.R_steps = self.Q_steps, self.R_steps
         self.c = c
 
 

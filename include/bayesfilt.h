@@ -132,8 +132,11 @@ typedef struct bf_model {
   const float* emi_theta;
   int32_t n_emi_theta;
   const float *q0, *r0; /* noise biases, NULL = zeros                */
-  const float *Q, *R;   /* noise covariances [dq,dq], [dr,dr]        */
+  const float *Q, *R;   /* noise covariances [dq,dq], [dr,dr]; [steps,d,d] when Q_steps / R_steps > 1 */
   int32_t flags;        /* 0 = the JAX path's semantics; BF_MODEL_* bits for the legacy NumPy classes */
+  int32_t Q_steps, R_steps; /* 0 or 1 = constant; T = one covariance per step, the (T,d,d) arrays that
+                               _get_params(..., 2, t) selects from (inference.py:21, :337-340).  Honoured by
+                               bf_gsf_ekf_f32 (emissions with a constant H_r); the sampling kernels need 0 / 1. */
 } bf_model;
 
 /* Legacy-class semantics (gaussfiltax/gaussfilt.py, gausssumfilt.py), honoured by bf_gsf_ekf_f32: */

@@ -293,3 +293,41 @@ def test_structured_lorenz96_instances(n, lanes, lmode):
     for k in FIELDS + ("weights",):
         full = getattr(res[1, -1], k).cpu().numpy()
         assert np.array_equal(np.concatenate([getattr(p1, k).cpu().numpy(), getattr(p2, k).cpu().numpy()], axis=2), full), k
+
+
+def test_time_varying_covariances():
+    """(T, d, d) noise covariances are selected per step exactly like _get_params(x, 2, t)
+    (inference.py:21, :337-340): linear model with K = 3 and the bearings-only model (nonlinear h,
+    non-identity F_q) against the oracle; both store paths; the sampling kernels refuse them."""
+    bfa, nl = _nl()
+    rng = np.random.default_rng(77)
+    T, B, K = 24, 4, 4
+    a = cm.cv_model_arrays()
+    scale_q = (0.5 + rng.uniform(size=T)).astype(F32)
+    scale_r = (0.5 + rng.uniform(size=T)).astype(F32)
+    Qt = (a["Q"][None] * scale_q[:, None, None]).astype(F32)
+    Rt = (a["R"][None] * scale_r[:, None, None]).astype(F32)
+    po, pp = cm.oracle_params(a), cm.product_params(a)
+    po_tv = po._replace(dynamics_noise_covariance=Qt, emission_noise_covariance=Rt)
+    pp_tv = pp._replace(dynamics_noise_covariance=Qt, emission_noise_covariance=Rt)
+    ys = np.stack([go.sample_ssm(po, otf.PRNGKey(b), T)[1] for b in range(B)])
+    init = rng.normal(size=(B, K, 4)).astype(F32)
+    ref = _oracle_batch(po_tv, ys, K, init)
+    for mode in (-1, 0):
+        _mode(mode)
+        try:
+            post = bfa.gaussian_sum_filter(pp_tv, ys, K, 1, initial_means=init)
+        finally:
+            _mode(-1)
+        _check(post, ref, tol=3e-5)
+    # only Q varies / only R varies
+    for kw in ({"dynamics_noise_covariance": Qt}, {"emission_noise_covariance": Rt}):
+        ref1 = _oracle_batch(po._replace(**kw), ys, K, init)
+        _check(bfa.gaussian_sum_filter(pp._replace(**kw), ys, K, 1, initial_means=init), ref1, tol=3e-5)
+    # wrong number of steps
+    with pytest.raises(bfa.BayesFiltError):
+        bfa.gaussian_sum_filter(pp._replace(dynamics_noise_covariance=Qt[:5]), ys, K, 1, initial_means=init)
+    # the particle filter takes constant covariances only
+    bp = bfa.ParamsBPF(*pp_tv, nl.gaussian_log_prob(pp.emission_function, a["R"]))
+    with pytest.raises(bfa.BayesFiltError):
+        bfa.bootstrap_particle_filter(bp, ys[0], 64, bfa.PRNGKey(0))
