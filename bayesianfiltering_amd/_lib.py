@@ -30,7 +30,7 @@ class bf_cstream(C.Structure):
 
 class bf_out_desc(C.Structure):
     _fields_ = [("weights", bf_stream), ("means", bf_stream), ("covs", bf_stream), ("pred_means", bf_stream),
-                ("pred_covs", bf_stream), ("loglik", bf_stream)]
+                ("pred_covs", bf_stream), ("loglik", bf_stream), ("coll_mean", bf_stream), ("coll_cov", bf_stream)]
 
 
 class bf_carry(C.Structure):

@@ -97,11 +97,16 @@ int64_t bf_bytes_per_step(int32_t n, int32_t m, int32_t K, const bf_out_desc* ou
     if (out->pred_covs.ptr) per += (int64_t)n * n;
     if (out->loglik.ptr) per += 1;
   }
-  return 4 * (int64_t)m + 4 * (int64_t)K * per;
+  int64_t once = 0;  // collapsed streams: one Gaussian per step whatever K is
+  if (out && out->coll_mean.ptr) once += n;
+  if (out && out->coll_cov.ptr) once += (int64_t)n * n;
+  return 4 * (int64_t)m + 4 * (int64_t)K * per + 4 * once;
 }
 
 int bf_kalman_filter_f32(const bf_lgssm* model, const bf_cstream* y, int64_t B, int64_t T, const bf_carry* carry,
                          const bf_out_desc* out, void* stream) {
+  if (out && (out->coll_mean.ptr || out->coll_cov.ptr))
+    return bf::set_error(BF_EINVAL, "collapsed streams are produced by bf_gsf_ekf_f32 (with one component they equal means / covs)");
   if (!model || !y || !carry || !out) return bf::set_error(BF_EINVAL, "NULL argument");
   if (B <= 0 || T <= 0) return bf::set_error(BF_EINVAL, "B and T must be positive (B=%lld, T=%lld)", (long long)B, (long long)T);
   if (model->n <= 0 || model->m <= 0 || model->dq <= 0 || model->dr <= 0)

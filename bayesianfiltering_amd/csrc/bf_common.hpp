@@ -34,6 +34,7 @@ inline SView make_sview(const bf_stream& s) { return SView{s.ptr, s.sB, s.sK, s.
 
 struct OutViews {
   SView w, m, P, pm, pP, ll;
+  SView cm, cP;  // collapsed mean / covariance of the filtered mixture (Gaussian-sum kernel only)
 };
 
 struct CarryView {

@@ -62,13 +62,16 @@ struct UView {
 };
 
 enum { SPEC_GENERIC = 0, SPEC_L96_PICK = 1 };
+constexpr int GSF_HDR = 32;  // LDS floats ahead of the tiles: cross-wave reduction scratch [0..7] scalar, [8..23] per lane-in-group
 
 template <int N>
 constexpr int wrap_mod(int i) {
   return ((i % N) + N) % N;
 }
 
-template <int NS, int M, int NL, int MODE, int SPEC>
+// EXT = true adds the optional features -- COLLAPSED outputs and per-step (time-varying) noise covariances --
+// as their own instances (strided stores only), so that the plain instances keep their register budget.
+template <int NS, int M, int NL, int MODE, int SPEC, bool EXT = false>
 __global__ void __launch_bounds__(256, 2)
 gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutViews out, long long B, long long T, int K,
                 int KP, int lds_per_wave, const float* __restrict__ tv_gqg, const float* __restrict__ tv_drd) {
@@ -122,13 +125,13 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
 
   // ---- LDS: staging tiles (per wave) + reduction scratch (per workgroup)
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* red = lds;  // 8 floats: per-wave partials of max / sum
+  float* red = lds;  // per-wave partials of max / sum (GSF_HDR floats)
   constexpr int GQ = L96 ? EP : 0;  // L96: F_q Q F_q^T, read back by every lane in its own coordinates
   if constexpr (L96) {
-    if (tid == 0) BF_UNROLL for (int i = 0; i < EP; ++i) lds[8 + i] = mdl.GQG[i];
+    if (tid == 0) BF_UNROLL for (int i = 0; i < EP; ++i) lds[GSF_HDR + i] = mdl.GQG[i];
     __syncthreads();
   }
-  int q = 8 + GQ + wave_in_blk * lds_per_wave;
+  int q = GSF_HDR + GQ + wave_in_blk * lds_per_wave;
   int oP = q, opP = q, oM = q, opM = q, oW = q, oL = q;
   if constexpr (MODE == EMIT_STAGED) {
     // a covariance row completes every step when TS == 1 (n*n >= 32): the filtered and the predicted
@@ -163,6 +166,34 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
       // adjacent-pair tree over the waves of the trajectory
       if (wpt == 2) v = op(red[w0], red[w0 + 1]);
       else v = op(op(red[w0], red[w0 + 1]), op(red[w0 + 2], red[w0 + 3]));
+    }
+    return v;
+  };
+
+  // the same sum for values that differ between the NL lanes of a chain (collapsed moments): the
+  // cross-wave step keeps one partial per lane-in-group
+  auto reduce_k_lane = [&](float v) {
+    const int lim = seg < 64 ? seg : 64;
+    int off = NL;
+    if (seg >= 16) {  // a row of 16 lanes lies inside one trajectory: DPP row rotations (one fused add each)
+      if constexpr (NL <= 1) v += dpp_mov<0x121>(v);  // row_ror:1
+      if constexpr (NL <= 2) v += dpp_mov<0x122>(v);  // row_ror:2
+      if constexpr (NL <= 4) v += dpp_mov<0x124>(v);  // row_ror:4
+      v += dpp_mov<0x128>(v);                         // row_ror:8
+      off = 16;
+    }
+    for (; off < lim && off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
+    auto add = [](float a, float b2) { return a + b2; };
+    if (lim > 16) v = xor16_combine(v, add);
+    if (lim > 32) v = xor32_combine(v, add);
+    if (seg > 64) {
+      __syncthreads();
+      if (lane < NL) red[8 + wave_in_blk * 4 + lane] = v;
+      __syncthreads();
+      const int wpt = seg / 64;
+      const int w0 = (wave_in_blk / wpt) * wpt;
+      if (wpt == 2) v = red[8 + w0 * 4 + jl] + red[8 + (w0 + 1) * 4 + jl];
+      else v = (red[8 + w0 * 4 + jl] + red[8 + (w0 + 1) * 4 + jl]) + (red[8 + (w0 + 2) * 4 + jl] + red[8 + (w0 + 3) * 4 + jl]);
     }
     return v;
   };
@@ -215,7 +246,7 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
         constexpr int i = decltype(I)::value;
         float gq[CPL];
         {
-          const int o = 8 + rowabs(i) * NS + base;
+          const int o = GSF_HDR + rowabs(i) * NS + base;
           BF_UNROLL for (int cc = 0; cc < CPL; ++cc) gq[cc] = lds[o + cc];
         }
         static_for<0, CPL>([&](auto C) {
@@ -230,10 +261,13 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
       BF_UNROLL for (int cc = 0; cc < CPL; ++cc) {
         const float ax = xr[wrapn(cc - 1)];
         const float bx = mp ? (xr[wrapn(cc + 1)] - xr[wrapn(cc - 2)]) : 0.f;
-        // x + dt (alpha ax bx - beta x + gamma), spelled out so that every copy of the loop body the
-        // compiler makes (peeled, versioned) contracts it the same way: chunked scans stay bit-identical
-        const float drift = fmaf(-beta, xr[cc], alpha * (ax * bx)) + gamma;
-        mj[cc] = fmaf(dt, drift, xr[cc]) + pick<NL>(mdl.Gq0, NS, jl, CPL, cc);
+        // x + dt (alpha ax bx - beta x + gamma) without fused multiply-adds (as NumPy evaluates it), so that
+        // every copy of the loop body the compiler makes (peeled, versioned) rounds it the same way:
+        // chunked scans stay bit-identical
+        {
+#pragma clang fp contract(off)
+          mj[cc] = xr[cc] + dt * (alpha * (ax * bx) - beta * xr[cc] + gamma) + pick<NL>(mdl.Gq0, NS, jl, CPL, cc);
+        }
       }
       return;
     }
@@ -261,7 +295,7 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
       });
       BF_UNROLL for (int cc = 0; cc < CPL; ++cc)
           Pc[cc][i] = acc[cc] + (mdl.cov_quirk ? Pc0[cc][i]
-                                     : tv_gqg   ? tv_gqg[tq * EP + i * NS + jl * CPL + cc]
+                                     : (EXT && tv_gqg) ? tv_gqg[tq * EP + i * NS + jl * CPL + cc]
                                                 : pick<NL>(mdl.GQG, NS * NS, jl, CPL, i * NS + cc));
     }
     BF_UNROLL for (int cc = 0; cc < CPL; ++cc) mj[cc] = pick<NL>(fx, NS, jl, CPL, cc);
@@ -301,7 +335,7 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
       float xf[NS], H[M * NS], hx[M], HrRHr[M * M];
       gather(mj, xf);
       emi_linearize<NS, M>(mdl, xf, u0, H, hx, HrRHr);
-      if (tv_drd) BF_UNROLL for (int i = 0; i < M * M; ++i) HrRHr[i] = tv_drd[t * (M * M) + i];
+      if constexpr (EXT) if (tv_drd) BF_UNROLL for (int i = 0; i < M * M; ++i) HrRHr[i] = tv_drd[t * (M * M) + i];
       float Hcol[CPL][M];
       BF_UNROLL for (int cc = 0; cc < CPL; ++cc) BF_UNROLL for (int a = 0; a < M; ++a)
           Hcol[cc][a] = pick<NL>(H, M * NS, jl, CPL, a * NS + cc);
@@ -353,6 +387,32 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
       const float e = comp_ok ? expf(ll - mx) * w : 0.f;
       const float tot = reduce_k(e, [](float a, float b2) { return a + b2; });
       w = comp_ok ? e / tot : 0.f;
+    }
+
+    // ================= COLLAPSED mode: moment-matched Gaussian of the filtered mixture (utils.py:10-18):
+    //   mu = sum_k w_k m_k,  Sigma = sum_k w_k (P_k + (m_k - mu)(m_k - mu)^T)   (sums in the reweight's tree order)
+    if constexpr (EXT) if (out.cm.p || out.cP.p) {
+      float mu[CPL], dj[CPL];
+      BF_UNROLL for (int cc = 0; cc < CPL; ++cc) {
+        mu[cc] = reduce_k_lane(w * mj[cc]);
+        dj[cc] = mj[cc] - mu[cc];
+      }
+      const bool writer = traj_ok && k == 0;
+      if (out.cm.p && writer) BF_UNROLL for (int cc = 0; cc < CPL; ++cc)
+          out.cm.p[b * out.cm.sB + t * out.cm.sT + (jl * CPL + cc) * out.cm.sE] = mu[cc];
+      if (out.cP.p) {
+        static_for<0, NS>([&](auto I) {
+          constexpr int i = decltype(I)::value;
+          // deviation of the row held in slot i (relative coordinates in the Lorenz-96 instance)
+          float di;
+          if constexpr (L96) di = group_rot<NL, i / CPL>(dj[i % CPL]);
+          else di = group_bcast<NL, i / CPL>(dj[i % CPL]);
+          BF_UNROLL for (int cc = 0; cc < CPL; ++cc) {
+            const float s = reduce_k_lane(w * fmaf(di, dj[cc], Pc[cc][i]));
+            if (writer) out.cP.p[b * out.cP.sB + t * out.cP.sT + (rowabs(i) * NS + jl * CPL + cc) * out.cP.sE] = s;
+          }
+        });
+      }
     }
 
     // ---- emit filtered streams
@@ -625,7 +685,8 @@ static inline int launch_gsf(const bf_model* p, const bf_cstream* y, const bf_cs
   UView uv{u && u->ptr ? u->ptr : nullptr, u ? u->sB : 0, u ? u->sT : 0};
   CarryView cv{carry->w_in, carry->m_in, carry->P_in, carry->w_out, carry->m_out, carry->P_out};
   OutViews ov{make_sview(out->weights), make_sview(out->means), make_sview(out->covs),
-              make_sview(out->pred_means), make_sview(out->pred_covs), make_sview(out->loglik)};
+              make_sview(out->pred_means), make_sview(out->pred_covs), make_sview(out->loglik),
+              make_sview(out->coll_mean), make_sview(out->coll_cov)};
   const bool ref_layout = gsf_stream_is_reference(out->weights, 1, T, K) && gsf_stream_is_reference(out->loglik, 1, T, K) &&
                           gsf_stream_is_reference(out->means, N, T, K) && gsf_stream_is_reference(out->pred_means, N, T, K) &&
                           gsf_stream_is_reference(out->covs, N * N, T, K) && gsf_stream_is_reference(out->pred_covs, N * N, T, K);
@@ -637,10 +698,12 @@ static inline int launch_gsf(const bf_model* p, const bf_cstream* y, const bf_cs
   // staged stores need every wave to hold CPW valid, consecutive chains of the [B][K] order
   const bool staged_ok = Cfg::STAGED_OK && ref_layout && rows_aligned && off32_ok && (K == KP) && (B % tpb == 0) &&
                          ((B * K) % Cfg::CPW == 0);
-  int mode = staged_ok ? EMIT_STAGED : EMIT_SCALAR;
+  const bool ext = out->coll_mean.ptr || out->coll_cov.ptr || !tvq.empty() || !tvr.empty();
+  int mode = (staged_ok && !ext) ? EMIT_STAGED : EMIT_SCALAR;
   if (force_mode == EMIT_SCALAR || force_mode == 1) mode = EMIT_SCALAR;
-  if (force_mode == EMIT_STAGED && !staged_ok)
-    return set_error(BF_EINVAL, "staged emitter needs the contiguous reference layout, K a power of two and whole waves");
+  if (force_mode == EMIT_STAGED && (!staged_ok || ext))
+    return set_error(BF_EINVAL, "staged emitter needs the contiguous reference layout, K a power of two, whole waves, constant "
+                                "covariances and no collapsed streams");
 
   const int nP = (out->covs.ptr ? 1 : 0) + (out->pred_covs.ptr ? 1 : 0);
   const int nM = (out->means.ptr ? 1 : 0) + (out->pred_means.ptr ? 1 : 0);
@@ -650,7 +713,7 @@ static inline int launch_gsf(const bf_model* p, const bf_cstream* y, const bf_cs
     if (mode == EMIT_STAGED)
       lds_per_wave = ((Cfg::TP::TS == 1 && nP == 2) ? 1 : nP) * Cfg::TP::FLOATS + nM * Cfg::TM::FLOATS + nW * Cfg::TW::FLOATS;
   lds_per_wave = (lds_per_wave + 3) & ~3;
-  const size_t lds_bytes = sizeof(float) * (8 + (SPEC == SPEC_L96_PICK ? N * N : 0) + (size_t)lds_per_wave * 4);
+  const size_t lds_bytes = sizeof(float) * (GSF_HDR + (SPEC == SPEC_L96_PICK ? N * N : 0) + (size_t)lds_per_wave * 4);
   if (lds_bytes > 160 * 1024) return set_error(BF_EUNSUPPORTED, "staging tiles exceed the 160 KiB LDS");
   // per-step covariance products: device copies for the duration of the launch
   float* d_tv = nullptr;
@@ -671,7 +734,10 @@ static inline int launch_gsf(const bf_model* p, const bf_cstream* y, const bf_cs
   }
   dim3 block(256);
   dim3 grid((unsigned)((B + tpb - 1) / tpb));
-  if (mode == EMIT_SCALAR) {
+  if (ext) {
+    hipLaunchKernelGGL((gsf_scan_kernel<N, M, NL, EMIT_SCALAR, SPEC, true>), grid, block, lds_bytes, stream, e, yv, uv, cv, ov, B,
+                       T, K, KP, lds_per_wave, d_tvq, d_tvr);
+  } else if (mode == EMIT_SCALAR) {
     hipLaunchKernelGGL((gsf_scan_kernel<N, M, NL, EMIT_SCALAR, SPEC>), grid, block, lds_bytes, stream, e, yv, uv, cv, ov, B, T, K,
                        KP, lds_per_wave, d_tvq, d_tvr);
   } else {

@@ -54,6 +54,23 @@ __device__ __forceinline__ float group_rot(float v) {
   }
 }
 
+// op(v, value of lane ^ 16) / op(v, value of lane ^ 32) in every lane through the gfx950 row / half
+// swaps (v_permlane16_swap, v_permlane32_swap: VALU, no LDS crossbar trip like ds_bpermute).  The
+// swap of (v, v) leaves {even-row copy, odd-row copy} in the two results, so op must be symmetric.
+template <class Op>
+__device__ __forceinline__ float xor16_combine(float v, Op op) {
+  float a = v, b = v;  // the instruction rewrites both operands in place: two registers
+  // explicit wait states on both sides (VALU write -> swap read, swap write -> VALU read)
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return op(a, b);
+}
+template <class Op>
+__device__ __forceinline__ float xor32_combine(float v, Op op) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return op(a, b);
+}
+
 // sum over the NL lanes of the group, result in every lane (xor butterfly: 1, 2, 4, ...)
 template <int NL>
 __device__ __forceinline__ float group_sum(float v) {

@@ -304,7 +304,8 @@ def _alloc_outputs(B, K, T, n, fields, layout, out, return_loglik, device):
 def gaussian_sum_filter(params, emissions, num_components: int = 1, num_iter: int = 1, inputs=None, *,
                         initial_means=None, initial_covariances=None, carry=None,
                         fields: Sequence[str] = FULL5, layout: str = "reference", out=None,
-                        return_loglik: bool = False, return_carry: bool = False, device="cuda"):
+                        return_loglik: bool = False, return_carry: bool = False, return_collapsed: bool = False,
+                        device="cuda"):
     """Gaussian-sum filter (bank of K extended Kalman filters + weight update),
     gaussfiltax/inference.py:303-377, on the HIP engine.
 
@@ -314,6 +315,10 @@ def gaussian_sum_filter(params, emissions, num_components: int = 1, num_iter: in
     or (B, T, d); the registry functions use ``u[0]``.  ``initial_means`` (K, n) / (B, K, n)
     overrides the reference's fixed ``MVN(m0, P0).sample(K, PRNGKey(0))`` draw (:367).
     ``carry`` / ``return_carry`` continue a scan in chunks (the carry of :334,356).
+    ``return_collapsed`` appends ``(mean (T, n), covariance (T, n, n))`` of the moment-matched single
+    Gaussian of the filtered mixture at every step (utils.collapse, utils.py:10-18; the point estimate of
+    BOT_Experiment_script.py:101), formed inside the scan: with ``fields=()`` a K-component run then
+    returns 4(n + n^2) bytes per step instead of the K-fold streams (COLLAPSED mode).
     """
     torch = _torch()
     lib = _lib.require_gpu()
@@ -350,6 +355,12 @@ def gaussian_sum_filter(params, emissions, num_components: int = 1, num_iter: in
         raise ValueError("initial means / covariances do not match (B, K, n) / (B, K, n, n)")
 
     bufs, ll, od = _alloc_outputs(B, K, T, n, fields, layout, out, return_loglik, y.device)
+    coll = None
+    if return_collapsed:
+        coll = (torch.empty((B, T, n), dtype=torch.float32, device=y.device),
+                torch.empty((B, T, n, n), dtype=torch.float32, device=y.device))
+        od.coll_mean.ptr, od.coll_mean.sB, od.coll_mean.sK, od.coll_mean.sT, od.coll_mean.sE = coll[0].data_ptr(), T * n, 0, n, 1
+        od.coll_cov.ptr, od.coll_cov.sB, od.coll_cov.sK, od.coll_cov.sT, od.coll_cov.sE = coll[1].data_ptr(), T * n * n, 0, n * n, 1
 
     yd = _lib.bf_cstream()
     yd.ptr, yd.sB, yd.sK, yd.sT, yd.sE = y.data_ptr(), y.stride(0), 0, y.stride(1), y.stride(2)
@@ -385,6 +396,8 @@ def gaussian_sum_filter(params, emissions, num_components: int = 1, num_iter: in
         extras.append(ll[0] if squeeze else ll)
     if return_carry:
         extras.append(c_out)
+    if return_collapsed:
+        extras.append(tuple(v[0] for v in coll) if squeeze else coll)
     return (post, *extras) if extras else post
 
 

@@ -70,6 +70,12 @@ typedef struct bf_out_desc {
   bf_stream pred_means; /* E = n    */
   bf_stream pred_covs;  /* E = n*n  */
   bf_stream loglik;     /* E = 1    */
+  /* COLLAPSED mode (bf_gsf_ekf_f32 only; sK unused): the moment-matched single Gaussian of the
+   * filtered mixture at every step -- utils.collapse (utils.py:10-18) and the point estimate
+   * sum_k w_k m_k of BOT_Experiment_script.py:101 -- formed inside the scan, so a K-component run
+   * can return 4(n + n*n) bytes per step instead of the K-fold streams above. */
+  bf_stream coll_mean;  /* E = n    */
+  bf_stream coll_cov;   /* E = n*n  */
 } bf_out_desc;
 
 /* Scan carry (weights, pred_means, pred_covs) of inference.py:334,356: the state the filter

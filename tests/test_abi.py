@@ -42,7 +42,7 @@ def test_struct_layouts_match_header():
     import ctypes as C
     from bayesianfiltering_amd import _lib
     assert C.sizeof(_lib.bf_stream) == 40 and C.sizeof(_lib.bf_cstream) == 40
-    assert C.sizeof(_lib.bf_out_desc) == 240 and C.sizeof(_lib.bf_carry) == 48
+    assert C.sizeof(_lib.bf_out_desc) == 320 and C.sizeof(_lib.bf_carry) == 48
     assert C.sizeof(_lib.bf_lgssm) == 16 + 8 * 8 + 8
 
 

@@ -331,3 +331,47 @@ def test_time_varying_covariances():
     bp = bfa.ParamsBPF(*pp_tv, nl.gaussian_log_prob(pp.emission_function, a["R"]))
     with pytest.raises(bfa.BayesFiltError):
         bfa.bootstrap_particle_filter(bp, ys[0], 64, bfa.PRNGKey(0))
+
+
+@pytest.mark.parametrize("case", ["l96_structured", "l96_dense_lanes4", "cv_k100_two_waves", "bot_k3"])
+def test_collapsed_mode_matches_collapse_of_the_streams(case):
+    """COLLAPSED mode: the in-scan moment matching equals utils.collapse (utils.py:10-18) applied to the
+    oracle's per-step mixture, for chains inside one wave, across waves (K = 100) and padded K."""
+    bfa, nl = _nl()
+    rng = np.random.default_rng(len(case))
+    inputs = None
+    if case.startswith("l96"):
+        n, K, T, B = 8, 8, 12, 4
+        po = go.ParamsNLSSM(np.zeros(8, F32), np.eye(8, dtype=F32), om.Lorenz96(8), np.zeros(8, F32),
+                            1e-2 * np.eye(8, dtype=F32), om.PickEven(8), np.zeros(4, F32), 1e-1 * np.eye(4, dtype=F32))
+        pp = bfa.ParamsNLSSM(np.zeros(8, F32), np.eye(8, dtype=F32), nl.lorenz96(8), np.zeros(8, F32),
+                             1e-2 * np.eye(8, dtype=F32), nl.pick_even(8), np.zeros(4, F32), 1e-1 * np.eye(4, dtype=F32))
+    else:
+        n, T, B = 4, 10, 3
+        K = 100 if case == "cv_k100_two_waves" else 3
+        a = cm.cv_model_arrays()
+        po, pp = cm.oracle_params(a), cm.product_params(a)
+    ys = np.stack([go.sample_ssm(po, otf.PRNGKey(b), T)[1] for b in range(B)])
+    init = rng.normal(size=(B, K, n)).astype(F32)
+    ref = _oracle_batch(po, ys, K, init)
+    if case == "l96_dense_lanes4":
+        _opt(b"gsf_structured", 0)
+        _opt(b"kf_lanes", 4)
+    try:
+        post, (cmean, ccov) = bfa.gaussian_sum_filter(pp, ys, K, 1, initial_means=init, return_collapsed=True)
+        only = bfa.gaussian_sum_filter(pp, ys, K, 1, initial_means=init, fields=(), return_collapsed=True)
+    finally:
+        _opt(b"gsf_structured", 1)
+        _opt(b"kf_lanes", 0)
+    _check(post, ref, tol=3e-5)
+    assert tuple(cmean.shape) == (B, T, n) and tuple(ccov.shape) == (B, T, n, n)
+    for b in range(B):
+        for t in range(T):
+            mu, Sg = go.collapse(ref["means"][b, :, t].astype(np.float64), ref["covariances"][b, :, t].astype(np.float64),
+                                 ref["weights"][b, :, t].astype(np.float64))
+            assert cm.rel_err(cmean[b, t].cpu().numpy(), mu) < 3e-5
+            assert cm.rel_err(ccov[b, t].cpu().numpy(), Sg) < 3e-5
+    # with no per-component streams requested the same numbers come back
+    assert all(getattr(only[0], k) is None for k in FIELDS + ("weights",))
+    assert np.array_equal(only[1][0].cpu().numpy(), cmean.cpu().numpy())
+    assert np.array_equal(only[1][1].cpu().numpy(), ccov.cpu().numpy())
