@@ -3,13 +3,14 @@ bootstrap particle filters) behind the call surface of the reference package ``g
 (kostastsa/BayesianFiltering).  See DESIGN.md for the hot path and its boundary."""
 from .models import ParamsNLSSM, ParamsBPF, NonlinearSSM
 from .containers import GaussianComponent, GaussianSum
-from .inference import (PosteriorGaussianSumFiltered, gaussian_sum_filter, kalman_filter, FilterCarry,
+from .inference import (PosteriorGaussianSumFiltered, gaussian_sum_filter, unscented_gaussian_sum_filter, ParamsUKF,
+                        kalman_filter, FilterCarry,
                         FULL5, FILTERED, PRNGKey, sample_initial_component_means,
                         bootstrap_particle_filter, ParticleCarry, resample_indices)
 from ._lib import BayesFiltError
 from . import nonlinearities, utils
 
 __all__ = ["ParamsNLSSM", "ParamsBPF", "NonlinearSSM", "GaussianComponent", "GaussianSum", "PosteriorGaussianSumFiltered",
-           "gaussian_sum_filter", "kalman_filter", "FilterCarry", "FULL5", "FILTERED", "PRNGKey",
+           "gaussian_sum_filter", "unscented_gaussian_sum_filter", "ParamsUKF", "kalman_filter", "FilterCarry", "FULL5", "FILTERED", "PRNGKey",
            "sample_initial_component_means", "bootstrap_particle_filter", "ParticleCarry", "resample_indices",
            "nonlinearities", "utils", "BayesFiltError"]

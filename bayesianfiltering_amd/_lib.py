@@ -57,6 +57,10 @@ class bf_model(C.Structure):
 BF_MODEL_PREDICT_FIRST, BF_MODEL_NO_JITTER, BF_MODEL_LEGACY_GSF_COV = 1, 2, 4
 
 
+class bf_ukf_params(C.Structure):
+    _fields_ = [("alpha", C.c_float), ("beta", C.c_float), ("kappa", C.c_float)]
+
+
 class bf_bpf_model(C.Structure):
     _fields_ = [("ssm", bf_model), ("m0", _FP), ("P0", _FP), ("lp_cov", _FP), ("r_eval", _FP)]
 
@@ -82,6 +86,8 @@ SYMBOLS = {
     "bf_bytes_per_step": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(bf_out_desc)]),
     "bf_gsf_ekf_f32": (C.c_int, [C.POINTER(bf_model), C.POINTER(bf_cstream), C.POINTER(bf_cstream), C.c_int64, C.c_int64,
                                  C.c_int32, C.POINTER(bf_carry), C.POINTER(bf_out_desc), C.c_void_p]),
+    "bf_ugsf_ukf_f32": (C.c_int, [C.POINTER(bf_model), C.POINTER(bf_ukf_params), C.POINTER(bf_cstream), C.POINTER(bf_cstream),
+                                  C.c_int64, C.c_int64, C.c_int32, C.POINTER(bf_carry), C.POINTER(bf_out_desc), C.c_void_p]),
     "bf_collapse_f32": (C.c_int, [C.POINTER(bf_stream), C.POINTER(bf_stream), C.POINTER(bf_stream), C.c_int64, C.c_int64,
                                   C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bf_bpf_f32": (C.c_int, [C.POINTER(bf_bpf_model), C.POINTER(bf_cstream), C.POINTER(bf_cstream), C.c_int64, C.c_int64,

@@ -29,6 +29,8 @@ int launch_collapse(const bf_stream* w, const bf_stream* m, const bf_stream* P, 
 int launch_gsf_ekf(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int K,
                    const bf_carry* carry, const bf_out_desc* out, hipStream_t stream, int force_mode, int lanes);
 
+int launch_ugsf_ukf(const bf_model* p, const bf_ukf_params* up, const bf_cstream* y, const bf_cstream* u, long long B,
+                    long long T, int K, const bf_carry* carry, const bf_out_desc* out, hipStream_t stream);
 int launch_bpf(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP,
                float ess, int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o,
                hipStream_t stream);
@@ -134,6 +136,19 @@ int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream*
   if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
   return bf::launch_gsf_ekf(model, y, u, B, T, K, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode,
                             bf::g_kf_lanes);
+}
+
+int bf_ugsf_ukf_f32(const bf_model* model, const bf_ukf_params* uparams, const bf_cstream* y, const bf_cstream* u,
+                    int64_t B, int64_t T, int32_t K, const bf_carry* carry, const bf_out_desc* out, void* stream) {
+  if (!model || !uparams || !y || !carry || !out) return bf::set_error(BF_EINVAL, "NULL argument");
+  if (B <= 0 || T <= 0 || K <= 0) return bf::set_error(BF_EINVAL, "B, T and K must be positive");
+  if (model->n <= 0 || model->m <= 0 || model->dq <= 0 || model->dr <= 0)
+    return bf::set_error(BF_EINVAL, "non-positive model dimension");
+  if (!model->Q || !model->R) return bf::set_error(BF_EINVAL, "Q and R are required");
+  if (!y->ptr) return bf::set_error(BF_EINVAL, "observations pointer is NULL");
+  if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
+  if (!(uparams->alpha > 0.f)) return bf::set_error(BF_EINVAL, "ParamsUKF.alpha must be positive");
+  return bf::launch_ugsf_ukf(model, uparams, y, u, B, T, K, carry, out, static_cast<hipStream_t>(stream));
 }
 
 int bf_collapse_f32(const bf_stream* weights, const bf_stream* means, const bf_stream* covs, int64_t B, int64_t T,

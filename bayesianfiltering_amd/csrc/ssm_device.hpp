@@ -26,9 +26,10 @@ struct BpfModel {
   float L0[N * N];    // chol(P0), lower
 };
 
-// value of f(x, q, u) for the registry dynamics (additive noise through F_q)
-template <int N, int DQ, int M>
-__device__ __forceinline__ void dyn_value(const BpfModel<N, DQ, M>& p, const float* x, const float* q, float u0, float* out) {
+// value of f(x, q, u) for the registry dynamics (additive noise through F_q); MDL is any model struct
+// with the fields dyn_id, dth, A, Gm, g_identity
+template <int N, int DQ, class MDL>
+__device__ __forceinline__ void dyn_value_t(const MDL& p, const float* x, const float* q, float u0, float* out) {
   switch (p.dyn_id) {
     case DYN_LINEAR: mv<N, N>(p.A, x, out); break;
     case DYN_LORENZ96: {
@@ -82,9 +83,15 @@ __device__ __forceinline__ void dyn_value(const BpfModel<N, DQ, M>& p, const flo
   }
 }
 
-// mean of the emission density: h(x, r_eval, u) for the registry emissions with constant H_r
 template <int N, int DQ, int M>
-__device__ __forceinline__ void emi_value(const BpfModel<N, DQ, M>& p, const float* x, float u0, float* hx) {
+__device__ __forceinline__ void dyn_value(const BpfModel<N, DQ, M>& p, const float* x, const float* q, float u0, float* out) {
+  dyn_value_t<N, DQ>(p, x, q, u0, out);
+}
+
+// noise-free part g(x, u) of the registry emissions h(x, r, u) = g(x, u) + H_r r (constant H_r); MDL is any
+// model struct with the fields emi_id, eth, Hm
+template <int N, int M, class MDL>
+__device__ __forceinline__ void emi_mean_t(const MDL& p, const float* x, float u0, float* hx) {
   switch (p.emi_id) {
     case EMI_LINEAR: mv<M, N>(p.Hm, x, hx); break;
     case EMI_BEARING_RANGE:
@@ -102,6 +109,12 @@ __device__ __forceinline__ void emi_value(const BpfModel<N, DQ, M>& p, const flo
       break;
     default: BF_UNROLL for (int a = 0; a < M; ++a) hx[a] = 0.f; break;
   }
+}
+
+// mean of the emission density: h(x, r_eval, u) for the registry emissions with constant H_r
+template <int N, int DQ, int M>
+__device__ __forceinline__ void emi_value(const BpfModel<N, DQ, M>& p, const float* x, float u0, float* hx) {
+  emi_mean_t<N, M>(p, x, u0, hx);
   BF_UNROLL for (int a = 0; a < M; ++a) hx[a] += p.hb[a];
 }
 

@@ -126,6 +126,13 @@ class _Lgssm:
         self.c = c
 
 
+class ParamsUKF(NamedTuple):
+    """Hyper-parameters of the unscented transform, gaussfiltax/inference.py:41-49 (same defaults)."""
+    alpha: float = 1e-3
+    beta: float = 2
+    kappa: float = 0
+
+
 class FilterCarry(NamedTuple):
     """The scan carry (weights, pred_means, pred_covs) of inference.py:334,356 at the end of a
     chunk; feed it back through ``carry=`` to continue the same trajectories."""
@@ -305,7 +312,7 @@ def gaussian_sum_filter(params, emissions, num_components: int = 1, num_iter: in
                         initial_means=None, initial_covariances=None, carry=None,
                         fields: Sequence[str] = FULL5, layout: str = "reference", out=None,
                         return_loglik: bool = False, return_carry: bool = False, return_collapsed: bool = False,
-                        device="cuda"):
+                        device="cuda", _uparams=None):
     """Gaussian-sum filter (bank of K extended Kalman filters + weight update),
     gaussfiltax/inference.py:303-377, on the HIP engine.
 
@@ -387,8 +394,13 @@ def gaussian_sum_filter(params, emissions, num_components: int = 1, num_iter: in
         cr.w_out, cr.m_out, cr.P_out = (t.data_ptr() for t in c_out)
 
     stream = torch.cuda.current_stream(y.device).cuda_stream
-    _lib.check(lib.bf_gsf_ekf_f32(C.byref(mdl.c), C.byref(yd), C.byref(ud), B, T, K, C.byref(cr), C.byref(od),
-                                  C.c_void_p(stream)))
+    if _uparams is None:
+        _lib.check(lib.bf_gsf_ekf_f32(C.byref(mdl.c), C.byref(yd), C.byref(ud), B, T, K, C.byref(cr), C.byref(od),
+                                      C.c_void_p(stream)))
+    else:  # the unscented bank: same carry / streams, sigma-point moment matching instead of Jacobians
+        up = _lib.bf_ukf_params(float(_uparams.alpha), float(_uparams.beta), float(_uparams.kappa))
+        _lib.check(lib.bf_ugsf_ukf_f32(C.byref(mdl.c), C.byref(up), C.byref(yd), C.byref(ud), B, T, K, C.byref(cr),
+                                       C.byref(od), C.c_void_p(stream)))
 
     post = PosteriorGaussianSumFiltered(**{k: (v[0] if (squeeze and v is not None) else v) for k, v in bufs.items()})
     extras = []
@@ -399,6 +411,25 @@ def gaussian_sum_filter(params, emissions, num_components: int = 1, num_iter: in
     if return_collapsed:
         extras.append(tuple(v[0] for v in coll) if squeeze else coll)
     return (post, *extras) if extras else post
+
+
+def unscented_gaussian_sum_filter(params, uparams, emissions, num_components: int = 1, num_iter: int = 1, inputs=None, *,
+                                  initial_means=None, initial_covariances=None, carry=None,
+                                  fields: Sequence[str] = FULL5, layout: str = "reference", out=None,
+                                  return_loglik: bool = False, return_carry: bool = False, device="cuda"):
+    """Unscented Gaussian-sum filter (bank of K unscented Kalman filters with non-additive noise +
+    weight update), gaussfiltax/inference.py:379-456, on the HIP engine.
+
+    Same positional signature as the reference (``uparams``: :class:`ParamsUKF`; ``num_iter`` ignored as
+    there).  Sigma points follow ``utils._get_sigma_points`` (utils.py:247-254): the symmetric square root
+    of blockdiag(P, noise covariance), recomputed on the device twice per step.  Shapes, ``initial_means``,
+    ``carry`` / ``return_carry``, ``fields`` and ``return_loglik`` as in :func:`gaussian_sum_filter`.
+    """
+    if not isinstance(uparams, ParamsUKF):
+        uparams = ParamsUKF(*uparams)
+    return gaussian_sum_filter(params, emissions, num_components, num_iter, inputs, initial_means=initial_means,
+                               initial_covariances=initial_covariances, carry=carry, fields=fields, layout=layout, out=out,
+                               return_loglik=return_loglik, return_carry=return_carry, device=device, _uparams=uparams)
 
 
 class ParticleCarry(NamedTuple):

@@ -145,6 +145,12 @@ typedef struct bf_model {
                                bf_gsf_ekf_f32 (emissions with a constant H_r); the sampling kernels need 0 / 1. */
 } bf_model;
 
+/* Hyper-parameters of the unscented transform -- ParamsUKF (inference.py:41-49): lambda =
+ * alpha^2 (L + kappa) - L with L = state_dim + noise_dim of the augmented state. */
+typedef struct bf_ukf_params {
+  float alpha, beta, kappa;
+} bf_ukf_params;
+
 /* Legacy-class semantics (gaussfiltax/gaussfilt.py, gausssumfilt.py), honoured by bf_gsf_ekf_f32: */
 #define BF_MODEL_PREDICT_FIRST 1  /* step order predict -> update (gaussfilt.py:113-121); carry = filtered state   */
 #define BF_MODEL_NO_JITTER 2      /* gain from S itself, no 1e-6 (gaussfilt.py:118 `Cxy @ inv(Sy)`)                 */
@@ -159,6 +165,15 @@ typedef struct bf_model {
  * times the lanes per chain must not exceed 256. */
 int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream* u, int64_t B, int64_t T, int32_t K,
                    const bf_carry* carry, const bf_out_desc* out, void* stream);
+
+/* Batched unscented Gaussian-sum filter: K unscented Kalman filters with non-additive noise
+ * (augmented sigma points) per trajectory plus the weight update.  Replaces the lax.scan of
+ * unscented_gaussian_sum_filter (inference.py:379-456) with _ukf_condition_on_nonadditive
+ * (:198-224), the reweight (:424-427) and _ukf_predict_nonadditive (:146-174); sigma points as
+ * utils._get_sigma_points (utils.py:247-254) with the symmetric matrix square root computed on the
+ * device.  Arguments as bf_gsf_ekf_f32; constant covariances, out->coll_* unsupported. */
+int bf_ugsf_ukf_f32(const bf_model* model, const bf_ukf_params* uparams, const bf_cstream* y, const bf_cstream* u,
+                    int64_t B, int64_t T, int32_t K, const bf_carry* carry, const bf_out_desc* out, void* stream);
 
 /* Moment-matching collapse of the mixture posterior per (trajectory, step): gaussfiltax/utils.py:10-18
  * and the point estimate sum_k w_k m_k (docs/experiments/BOT_Experiment_script.py:101).  weights /

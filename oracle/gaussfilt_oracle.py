@@ -11,6 +11,9 @@ Follows, line by line (paths relative to /root/reference):
   psd_solve, _resample, collapse   gaussfiltax/utils.py:256-259, 207-214, 10-18
   ParamsNLSSM / ParamsBPF   gaussfiltax/models.py:26-84
   NonlinearSSM.sample       gaussfiltax/models.py:240-289
+  ParamsUKF, _ukf_predict_nonadditive, _ukf_condition_on_nonadditive, unscented_gaussian_sum_filter
+                            gaussfiltax/inference.py:41-49, 146-174, 198-224, 379-456
+  _get_sigma_points         gaussfiltax/utils.py:247-254
 
 Quirks reproduced on purpose: update->reweight->predict order; psd_solve adds
 1e-6 to EVERY entry of S and uses LU (sgesv); posterior covariance P - K S K^T with the
@@ -247,6 +250,122 @@ def gaussian_sum_filter(params, emissions, num_components=1, num_iter=1, inputs=
         predicted_means=out_pm.swapaxes(0, 1).copy(),
         predicted_covariances=out_pP.swapaxes(0, 1).copy(),
     )
+    if return_ll:
+        return post, out_ll.swapaxes(0, 1).copy()
+    return post
+
+
+# --------------------------------------------------------------------------- unscented variants
+class ParamsUKF(NamedTuple):
+    """gaussfiltax/inference.py:41-49."""
+    alpha: float = 1e-3
+    beta: float = 2
+    kappa: float = 0
+
+
+def sym_sqrtm(P):
+    """``jnp.real(scipy.linalg.sqrtm(P))`` of utils.py:250 for a symmetric matrix: the principal square
+    root V diag(sqrt(lambda)) V^T; eigenvalues below zero (rounding) have a purely imaginary root whose
+    real part is 0.  Evaluated in float64 and rounded to float32 (jax runs a float32 Schur iteration;
+    the two agree to float32 resolution for the well-conditioned covariances of the parity tests)."""
+    lam, V = np.linalg.eigh(np.asarray(P, dtype=np.float64))
+    return ((V * np.sqrt(np.maximum(lam, 0.0))) @ V.T).astype(F32)
+
+
+def _get_sigma_points(m, P, ulambda):
+    """utils.py:247-254: the 2 dx rows m +- sqrt(dx + lambda) * sqrtm(P)^T."""
+    dx = m.shape[0]
+    L = sym_sqrtm(P)
+    c = np.sqrt(F32(dx) + F32(ulambda)).astype(F32)
+    plus = (np.stack([m] * dx, axis=0) + c * L.T).astype(F32)
+    minus = (np.stack([m] * dx, axis=0) - c * L.T).astype(F32)
+    return np.concatenate([plus, minus], axis=0)
+
+
+def _ulambda(uparams, L):
+    return F32(F32(uparams.alpha) ** 2 * F32(L + uparams.kappa) - F32(L))
+
+
+def _ukf_predict_nonadditive(m, P, f, u, Q, uparams, q0):
+    """inference.py:146-174."""
+    n, d = m.shape[0], Q.shape[0]
+    lam = _ulambda(uparams, n + d)
+    mA = np.concatenate((m, q0)).astype(F32)
+    PA = np.zeros((n + d, n + d), F32)
+    PA[:n, :n], PA[n:, n:] = P, Q
+    sp = _get_sigma_points(mA, PA, lam)
+    new = np.stack([f(x[:n], x[n:], u) for x in sp]).astype(F32)
+    f0 = f(m, q0, u).astype(F32)
+    den = F32(2) * (lam + F32(n + d))
+    mu = (np.sum(new, axis=0, dtype=F32) / den + f0 * (lam / (lam + F32(n + d)))).astype(F32)
+    dev = (new - mu).astype(F32)
+    wc = F32(lam / (lam + F32(n + d)) + F32(1) - F32(uparams.alpha) ** 2 + F32(uparams.beta))
+    Sigma = (_mm(dev.T, dev) / den + wc * np.outer(f0 - mu, f0 - mu).astype(F32)).astype(F32)
+    return mu, Sigma
+
+
+def _ukf_condition_on_nonadditive(m, P, h, R, u, y, uparams, r0):
+    """inference.py:198-224."""
+    n, d = m.shape[0], r0.shape[0]
+    lam = _ulambda(uparams, n + d)
+    mA = np.concatenate((m, r0)).astype(F32)
+    PA = np.zeros((n + d, n + d), F32)
+    PA[:n, :n], PA[n:, n:] = P, R
+    sp = _get_sigma_points(mA, PA, lam)
+    new = np.stack([h(x[:n], x[n:], u) for x in sp]).astype(F32)
+    h0 = h(m, r0, u).astype(F32)
+    den = F32(2) * (lam + F32(n + d))
+    mu = (np.sum(new, axis=0, dtype=F32) / den + h0 * (lam / (lam + F32(n + d)))).astype(F32)
+    dev = (new - mu).astype(F32)
+    wc = F32(lam / (lam + F32(n + d)) + F32(1) - F32(uparams.alpha) ** 2 + F32(uparams.beta))
+    S = (_mm(dev.T, dev) / den + wc * np.outer(h0 - mu, h0 - mu).astype(F32)).astype(F32)
+    C = (_mm(dev.T, (sp[:, :n] - m).astype(F32)) / den).astype(F32)
+    K = psd_solve(S, C).T
+    posterior_cov = (P - _mm(_mm(K, S), K.T)).astype(F32)
+    posterior_mean = (m + _mm(K, (y - mu).astype(F32))).astype(F32)
+    ll = mvn_log_prob(mu, S, y)
+    return ll, posterior_mean, posterior_cov
+
+
+def unscented_gaussian_sum_filter(params, uparams, emissions, num_components=1, num_iter=1, inputs=None,
+                                  initial_means=None, return_ll=False):
+    """inference.py:379-456.  ``initial_means`` (K,n) overrides the PRNGKey(0) draw of :445."""
+    emissions = np.asarray(emissions, dtype=F32)
+    T = len(emissions)
+    K = num_components
+    fn, hn = params.dynamics_function, params.emission_function
+    inputs = _process_input(inputs, T)
+    n = np.asarray(params.initial_mean).size
+    if initial_means is None:
+        initial_means = initial_component_means(params, K)
+    pred_means = np.array(initial_means, dtype=F32).reshape(K, n)
+    pred_covs = np.stack([np.asarray(params.initial_covariance, dtype=F32)] * K)
+    weights = (np.ones(K, dtype=F32) / F32(K)).astype(F32)
+    out_w = np.empty((T, K), F32)
+    out_m = np.empty((T, K, n), F32)
+    out_P = np.empty((T, K, n, n), F32)
+    out_pm = np.empty((T, K, n), F32)
+    out_pP = np.empty((T, K, n, n), F32)
+    out_ll = np.empty((T, K), F32)
+    for t in range(T):
+        Q = np.asarray(_get_params(params.dynamics_noise_covariance, 2, t), dtype=F32)
+        q0 = np.asarray(_get_params(params.dynamics_noise_bias, 2, t), dtype=F32)
+        R = np.asarray(_get_params(params.emission_noise_covariance, 2, t), dtype=F32)
+        r0 = np.asarray(_get_params(params.emission_noise_bias, 2, t), dtype=F32)
+        u, y = inputs[t], emissions[t]
+        lls = np.empty(K, F32)
+        fm = np.empty((K, n), F32)
+        fP = np.empty((K, n, n), F32)
+        for k in range(K):
+            lls[k], fm[k], fP[k] = _ukf_condition_on_nonadditive(pred_means[k], pred_covs[k], hn, R, u, y, uparams, r0)
+        out_ll[t] = lls
+        weights = reweight(lls, weights)
+        for k in range(K):
+            pred_means[k], pred_covs[k] = _ukf_predict_nonadditive(fm[k], fP[k], fn, u, Q, uparams, q0)
+        out_w[t], out_m[t], out_P[t], out_pm[t], out_pP[t] = weights, fm, fP, pred_means, pred_covs
+    post = PosteriorGaussianSumFiltered(
+        weights=out_w.swapaxes(0, 1).copy(), means=out_m.swapaxes(0, 1).copy(), covariances=out_P.swapaxes(0, 1).copy(),
+        predicted_means=out_pm.swapaxes(0, 1).copy(), predicted_covariances=out_pP.swapaxes(0, 1).copy())
     if return_ll:
         return post, out_ll.swapaxes(0, 1).copy()
     return post

@@ -81,3 +81,22 @@ def test_registry_functions_match_oracle_models():
     for f, g, n, nw, u in pairs:
         x = rng.normal(size=n).astype(np.float32); w = (0.1 * rng.normal(size=nw)).astype(np.float32)
         assert np.allclose(f(x, w, np.float32([u])), g.value(x, w, np.float32([u])), rtol=1e-5, atol=1e-6), f.name
+
+
+def test_struct_sizes_agree_with_a_c_compiler(tmp_path):
+    """Every struct of include/bayesfilt.h, as laid out by gcc, against its ctypes mirror in _lib.py."""
+    import ctypes as C
+    import subprocess
+    from bayesianfiltering_amd import _lib
+    names = ["bf_stream", "bf_cstream", "bf_out_desc", "bf_carry", "bf_lgssm", "bf_model", "bf_ukf_params", "bf_bpf_model",
+             "bf_bpf_carry", "bf_bpf_out"]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "bayesfilt.h"\nint main(void) {\n'
+                   + "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in names) + "  return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    sizes = dict(line.split() for line in out.strip().splitlines())
+    for n in names:
+        assert int(sizes[n]) == C.sizeof(getattr(_lib, n)), (n, sizes[n], C.sizeof(getattr(_lib, n)))

@@ -134,3 +134,25 @@ def test_gsf_single_component_equals_kalman_quirks():
     # default initial means are a PRNGKey(0) draw (:367), not m0
     pd = go.gaussian_sum_filter(p, ys, 1)
     assert not np.array_equal(pd.means[0, 0], p1.means[0, 0])
+
+
+def test_unscented_filter_is_exact_on_linear_models():
+    """The unscented transform reproduces linear maps exactly: on a linear-Gaussian model the oracle's
+    unscented Gaussian-sum filter (inference.py:379-456) must agree with its extended one, for any
+    ParamsUKF, and with the float64 textbook Kalman filter."""
+    a = cm.cv_model_arrays()
+    po = cm.oracle_params(a)
+    ys = go.sample_ssm(po, otf.PRNGKey(0), 25)[1]
+    init = np.zeros((1, 4), np.float32)
+    ekf = go.gaussian_sum_filter(po, ys, 1, initial_means=init)
+    for up in ((1.0, 0.0, 0.0), (0.5, 2.0, 1.0), (1.0, 2.0, 0.0)):
+        ukf = go.unscented_gaussian_sum_filter(po, go.ParamsUKF(*up), ys, 1, initial_means=init)
+        for k in ("means", "covariances", "predicted_means", "predicted_covariances"):
+            assert cm.rel_err(getattr(ukf, k), getattr(ekf, k)) < 2e-5, (up, k)
+    # sigma points: 2 L rows, symmetric about the mean, spread sqrt(L + lambda) * sqrtm(P)
+    P = np.array([[2.0, 0.3], [0.3, 1.0]], np.float32)
+    m = np.array([1.0, -1.0], np.float32)
+    sp = go._get_sigma_points(m, P, 1.0)
+    assert sp.shape == (4, 2) and np.allclose(sp[:2] + sp[2:], 2 * m, atol=1e-6)
+    L = (sp[:2] - m) / np.sqrt(3.0)
+    assert np.allclose(L @ L, P, atol=1e-5) and np.allclose(L, L.T, atol=1e-6)
