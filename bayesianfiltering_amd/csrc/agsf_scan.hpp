@@ -1,0 +1,245 @@
+// agsf_scan: batched "speedy" augmented Gaussian-sum filter.
+//
+// Replaces the lax.scan body of speedy_augmented_gaussian_sum_filter (gaussfiltax/inference.py:621-812).
+// Per step every carried component i0 (N0 of them) is branched into N1 z-samples drawn from
+// N(m, P - Delta), Delta = opt_args[0] P (:665-688); each is pushed through the extended-Kalman _predict
+// with covariance Delta (:695-698); every prediction is branched into N2 s-samples from
+// N(m-, P- - Lambda), Lambda = opt_args[1] P- (:711-726); each is updated by _condition_on with covariance
+// Lambda (:735-737); the N0 N1 N2 leaves are weighted (:738-743) and N0 of them are drawn with
+// jr.choice under the fixed key PRNGKey(0) (:760) to become the next carry with weights 1 / N0.
+// rng_key is never advanced by the reference, so the two arrays of normals are the same at every step
+// (:672, :716): each leaf draws its two n-vectors once, before the time loop.
+//
+// Mapping (gfx950).  One lane per leaf (i0, i1, i2); the MP = next_pow2(N0 N1 N2) <= 64 lanes of a
+// trajectory are consecutive lanes of one wave, 256 / MP trajectories per workgroup.  A lane redoes its
+// parents' work (the Cholesky factor of (1 - a0) P, the prediction of its (i0, i1) node) instead of
+// communicating: the tree is shallow and the algebra is n^3 with n <= 8.  Cross-lane steps: max / sum of
+// the leaf weights (xor butterfly, adjacent-pair tree), the cumulative sum for jr.choice in
+// lax.associative_scan order (segmented Brent-Kung with __shfl_up), the inverse-CDF search and the
+// gather of the drawn leaves through LDS.
+#pragma once
+#include <cstring>
+#include "bf_common.hpp"
+#include "kf_math.hpp"
+#include "bf_rng.hpp"
+#include "models.hpp"
+#include "gsf_scan.hpp"  // fill_model: EkfModel from the C-ABI struct
+
+namespace bf {
+
+// lower Cholesky factor of a symmetric matrix (jnp.linalg.cholesky; NaN when not positive definite)
+template <int N>
+__device__ __forceinline__ void chol_lower(const float* A, float* L) {
+  BF_UNROLL for (int i = 0; i < N * N; ++i) L[i] = 0.f;
+  BF_UNROLL for (int j = 0; j < N; ++j) {
+    float d = A[j * N + j];
+    BF_UNROLL for (int k = 0; k < j; ++k) d = fmaf(-L[j * N + k], L[j * N + k], d);
+    d = sqrtf(d);
+    L[j * N + j] = d;
+    const float inv = 1.0f / d;
+    BF_UNROLL for (int i = j + 1; i < N; ++i) {
+      float s = A[i * N + j];
+      BF_UNROLL for (int k = 0; k < j; ++k) s = fmaf(-L[i * N + k], L[j * N + k], s);
+      L[i * N + j] = s * inv;
+    }
+  }
+}
+
+struct AgsfOut {
+  SView w, m, P;
+  int* anc;  // [B][T][N0] index of the leaf each carried component was drawn from (NULL = not emitted)
+};
+
+template <int N, int M>
+__global__ void __launch_bounds__(256)
+agsf_scan_kernel(EkfModel<N, M> mdl, CView y, UView uin, CarryView carry, AgsfOut out, long long B, long long T, int N0, int N1,
+                 int N2, int MP, float a0, float a1, uint32_t key0, uint32_t key1) {
+  constexpr int EP = N * N;
+  constexpr int REC = N + EP;  // one component record in LDS: mean, covariance
+  const int tid = threadIdx.x;
+  const int tpb = 256 / MP;
+  const int slot = tid / MP;       // trajectory slot in the workgroup
+  const int l = tid % MP;          // leaf index
+  const int Mleaf = N0 * N1 * N2;
+  const bool leaf_ok = l < Mleaf;
+  const int lc = leaf_ok ? l : 0;  // padding lanes shadow leaf 0 (weight 0, never drawn)
+  const int i0 = lc / (N1 * N2), i1 = (lc / N2) % N1, i2 = lc % N2;
+  const long long b_raw = (long long)blockIdx.x * tpb + slot;
+  const bool traj_ok = b_raw < B;
+  const long long b = traj_ok ? b_raw : B - 1;
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* leafbuf = lds;                          // [256][REC]   updated mean / covariance of every leaf
+  float* carrybuf = lds + 256 * REC;             // [256][REC]   carried components, slot-major: [slot * MP + i0]
+  float* cdfbuf = carrybuf + 256 * REC;          // [256]        cumulative leaf weights
+
+  // ---- the two standard-normal vectors of this leaf (same at every step: the reference's key is never advanced)
+  float ez[N], es[N];
+  {
+    const U32x2 kz = threefry_split(key0, key1, 0u, 2u);   // key, subkey = jr.split(rng_key)          :672
+    const U32x2 ks = threefry_split(kz.x, kz.y, 0u, 2u);   // key, _ = jr.split(key)                    :716
+    const uint32_t cz = (uint32_t)(N0 * N * N1), cs = (uint32_t)(N0 * N1 * N * N2);
+    BF_UNROLL for (int d = 0; d < N; ++d) {
+      ez[d] = bits_to_normal(threefry_bits(kz.x, kz.y, (uint32_t)((i0 * N + d) * N1 + i1), cz));            // (N0, n, N1)
+      es[d] = bits_to_normal(threefry_bits(ks.x, ks.y, (uint32_t)(((i0 * N1 + i1) * N + d) * N2 + i2), cs));  // (N0 N1, n, N2)
+    }
+  }
+  // uniform of the resampling draw this lane performs (lanes l < N0): uniform(PRNGKey(0), (N0,))[l]     :760
+  const float udraw = bits_to_unit(threefry_bits(0u, 0u, (uint32_t)(l < N0 ? l : 0), (uint32_t)N0));
+
+  // ---- carry -> LDS
+  if (l < N0) {
+    float* rec = carrybuf + (slot * MP + l) * REC;
+    BF_UNROLL for (int i = 0; i < N; ++i) rec[i] = carry.m_in[(b * N0 + l) * N + i];
+    BF_UNROLL for (int i = 0; i < EP; ++i) rec[N + i] = carry.P_in[(b * N0 + l) * EP + i];
+  }
+  float wpar = carry.w_in ? carry.w_in[b * N0 + i0] : 1.0f / (float)N0;  // weight of the parent component
+  __syncthreads();
+
+  auto seg_reduce = [&](float v, auto op) {  // over the MP lanes of the trajectory, adjacent-pair tree
+    for (int off = 1; off < MP; off <<= 1) v = op(v, __shfl_xor(v, off, 64));
+    return v;
+  };
+
+  for (long long t = 0; t < T; ++t) {
+    float yv[M];
+    BF_UNROLL for (int a = 0; a < M; ++a) yv[a] = y.p[b * y.sB + t * y.sT + a * y.sE];
+    const float u0 = uin.p ? uin.p[b * uin.sB + t * uin.sT] : 0.f;
+
+    // ---- z-sample of the (i0, i1) node and its prediction (:675-698)
+    float mz[N], P[EP];
+    {
+      const float* rec = carrybuf + (slot * MP + i0) * REC;
+      float Pk[EP], Lz[EP];
+      BF_UNROLL for (int i = 0; i < EP; ++i) Pk[i] = rec[N + i];
+      float Dl[EP], Az[EP];
+      BF_UNROLL for (int i = 0; i < EP; ++i) {
+        Dl[i] = a0 * Pk[i];       // Delta = opt_args[0] * P                                       :665
+        Az[i] = Pk[i] - Dl[i];    // filtered_covs - Deltas                                        :675
+      }
+      chol_lower<N>(Az, Lz);
+      BF_UNROLL for (int i = 0; i < N; ++i) {
+        float s = 0.f;
+        BF_UNROLL for (int c = 0; c <= i; ++c) s = fmaf(Lz[i * N + c], ez[c], s);
+        mz[i] = rec[i] + s;       // z = m + chol(P - Delta) eps
+      }
+      float F[EP], fx[N];
+      dyn_linearize<N, M>(mdl, mz, u0, F, fx);
+      predict_cov<N>(F, mdl.GQG, Dl);  // F Delta F^T + F_q Q F_q^T
+      BF_UNROLL for (int i = 0; i < N; ++i) mz[i] = fx[i];
+      BF_UNROLL for (int i = 0; i < EP; ++i) P[i] = Dl[i];
+    }
+    // ---- s-sample of the leaf and its update (:711-737)
+    float ll;
+    {
+      float Lam[EP], As[EP], Ls[EP];
+      BF_UNROLL for (int i = 0; i < EP; ++i) {
+        Lam[i] = a1 * P[i];       // Lambda = opt_args[1] * P-                                     :711
+        As[i] = P[i] - Lam[i];
+      }
+      chol_lower<N>(As, Ls);
+      float ms[N];
+      BF_UNROLL for (int i = 0; i < N; ++i) {
+        float s = 0.f;
+        BF_UNROLL for (int c = 0; c <= i; ++c) s = fmaf(Ls[i * N + c], es[c], s);
+        ms[i] = mz[i] + s;
+      }
+      float H[M * N], hx[M], HrRHr[M * M], v[M];
+      emi_linearize<N, M>(mdl, ms, u0, H, hx, HrRHr);
+      BF_UNROLL for (int a = 0; a < M; ++a) v[a] = yv[a] - hx[a];
+      ll = condition_on<N, M>(H, HrRHr, v, ms, Lam);
+      BF_UNROLL for (int i = 0; i < N; ++i) mz[i] = ms[i];
+      BF_UNROLL for (int i = 0; i < EP; ++i) P[i] = Lam[i];
+    }
+    // ---- leaf weights (:738-743): carried weight / N1 / N2, times exp(ll - max), normalised
+    const float wleaf = (wpar / (float)N1) / (float)N2;
+    const float llm = leaf_ok ? ll : -__builtin_inff();
+    const float mx = seg_reduce(llm, [](float a, float c) { return (a != a || c != c) ? __builtin_nanf("") : fmaxf(a, c); });
+    const float e = leaf_ok ? expf(ll - mx) * wleaf : 0.f;
+    const float tot = seg_reduce(e, [](float a, float c) { return a + c; });
+    const float w = leaf_ok ? e / tot : 0.f;
+
+    // ---- jr.choice(PRNGKey(0), arange(M), (N0,), p = w) (:760): cumsum in associative_scan order, inverse-CDF search
+    float c = w;
+    for (int d = 0; (1 << d) < MP; ++d) {        // up-sweep
+      const float o = __shfl_up(c, 1 << d, 64);
+      if (((l + 1) & ((2 << d) - 1)) == 0) c += o;
+    }
+    for (int d = 5; d >= 1; --d) {               // down-sweep
+      if ((1 << d) < MP || (1 << d) == MP) {
+        const float o = __shfl_up(c, 1 << (d - 1), 64);
+        if (l >= (1 << d) && ((l + 1) & ((1 << d) - 1)) == (1 << (d - 1))) c += o;
+      }
+    }
+    __syncthreads();  // previous step's readers of leafbuf / cdfbuf are done
+    cdfbuf[tid] = c;
+    {
+      float* rec = leafbuf + tid * REC;
+      BF_UNROLL for (int i = 0; i < N; ++i) rec[i] = mz[i];
+      BF_UNROLL for (int i = 0; i < EP; ++i) rec[N + i] = P[i];
+    }
+    __syncthreads();
+    if (l < N0) {
+      const float* cd = cdfbuf + slot * MP;
+      const float r = cd[Mleaf - 1] * (1.0f - udraw);
+      int lo = 0, hi = Mleaf;  // first index with cdf[idx] >= r (searchsorted side='left')
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cd[mid] < r) lo = mid + 1; else hi = mid;
+      }
+      const int idx = lo < Mleaf - 1 ? lo : Mleaf - 1;
+      const float* src = leafbuf + (slot * MP + idx) * REC;
+      float* dst = carrybuf + (slot * MP + l) * REC;
+      // drawn leaf -> component l of the next carry, and out
+      BF_UNROLL for (int i = 0; i < REC; ++i) dst[i] = src[i];
+      if (traj_ok) {
+        if (out.m.p) BF_UNROLL for (int i = 0; i < N; ++i) out.m.p[b * out.m.sB + l * out.m.sK + t * out.m.sT + i * out.m.sE] = src[i];
+        if (out.P.p) BF_UNROLL for (int i = 0; i < EP; ++i) out.P.p[b * out.P.sB + l * out.P.sK + t * out.P.sT + i * out.P.sE] = src[N + i];
+        if (out.w.p) out.w.p[b * out.w.sB + l * out.w.sK + t * out.w.sT] = 1.0f / (float)N0;
+        if (out.anc) out.anc[(b * T + t) * N0 + l] = idx;
+      }
+    }
+    wpar = 1.0f / (float)N0;  // weights = ones / N0                                                :765
+    __syncthreads();
+  }
+
+  if (traj_ok && l < N0) {
+    const float* rec = carrybuf + (slot * MP + l) * REC;
+    if (carry.m_out) BF_UNROLL for (int i = 0; i < N; ++i) carry.m_out[(b * N0 + l) * N + i] = rec[i];
+    if (carry.P_out) BF_UNROLL for (int i = 0; i < EP; ++i) carry.P_out[(b * N0 + l) * EP + i] = rec[N + i];
+    if (carry.w_out) carry.w_out[b * N0 + l] = 1.0f / (float)N0;
+  }
+}
+
+template <int N, int M>
+static inline int launch_agsf(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
+                              const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry,
+                              const bf_out_desc* out, int* d_leaf_idx, hipStream_t stream) {
+  EkfModel<N, M> e;
+  int rc = fill_model<N, M>(p, e);
+  if (rc != BF_OK) return rc;
+  if (p->flags != 0) return set_error(BF_EUNSUPPORTED, "legacy-class flags do not apply to the augmented filter");
+  const int Mleaf = nc[0] * nc[1] * nc[2];
+  int MP = 1;
+  while (MP < Mleaf) MP <<= 1;
+  if (MP > 64) return set_error(BF_EUNSUPPORTED, "augmented Gaussian-sum filter: %d leaves per trajectory exceed one wave (64)", Mleaf);
+  if (out->pred_means.ptr || out->pred_covs.ptr || out->coll_mean.ptr || out->coll_cov.ptr || out->loglik.ptr)
+    return set_error(BF_EINVAL, "the augmented filter emits weights, means and covariances only (inference.py:771-775)");
+  constexpr int REC = N + N * N;
+  const size_t lds_bytes = sizeof(float) * (size_t)(2 * 256 * REC + 256);
+  if (lds_bytes > 160 * 1024) return set_error(BF_EUNSUPPORTED, "component records exceed the 160 KiB LDS");
+  CView yv{y->ptr, y->sB, y->sT, y->sE};
+  UView uv{u && u->ptr ? u->ptr : nullptr, u ? u->sB : 0, u ? u->sT : 0};
+  CarryView cv{carry->w_in, carry->m_in, carry->P_in, carry->w_out, carry->m_out, carry->P_out};
+  AgsfOut ov{make_sview(out->weights), make_sview(out->means), make_sview(out->covs), d_leaf_idx};
+  auto kern = agsf_scan_kernel<N, M>;
+  if (lds_bytes > 64 * 1024)
+    BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  const int tpb = 256 / MP;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((B + tpb - 1) / tpb)), dim3(256), lds_bytes, stream, e, yv, uv, cv, ov, B, T, nc[0],
+                     nc[1], nc[2], MP, opt[0], opt[1], key[0], key[1]);
+  BF_HIP_CHECK(hipGetLastError());
+  return BF_OK;
+}
+
+}  // namespace bf

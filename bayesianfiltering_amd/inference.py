@@ -432,6 +432,94 @@ def unscented_gaussian_sum_filter(params, uparams, emissions, num_components: in
                                return_loglik=return_loglik, return_carry=return_carry, device=device, _uparams=uparams)
 
 
+def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_key=None, num_iter: int = 1,
+                                         opt_args=(0.1, 0.1), inputs=None, *, initial_means=None,
+                                         initial_covariances=None, carry=None, return_carry: bool = False,
+                                         return_leaf_indices: bool = False, device="cuda"):
+    """"Speedy" augmented Gaussian-sum filter, gaussfiltax/inference.py:621-812, on the HIP engine.
+
+    Same positional signature as the reference: ``num_components = (N0, N1, N2)``, ``rng_key`` defaults to
+    ``PRNGKey(0)`` (the reference never advances it: the same normals at every step), ``num_iter`` is
+    ignored as there, ``opt_args = (a0, a1)`` scale the sample covariances Delta = a0 P and Lambda = a1 P-.
+    Returns ``(PosteriorGaussianSumFiltered(weights, means, covariances), aux)`` with arrays shaped
+    (N0, T, ...) for ``emissions`` (T, m) -- or with a leading batch axis for (B, T, m); ``aux`` is a dict
+    that holds ``'leaf_indices'`` (T, N0) when ``return_leaf_indices`` (the reference's per-step debugging
+    outputs -- Deltas, Lambdas, Jacobians, gains -- are not materialised) and ``'carry'`` when
+    ``return_carry``.  ``initial_means`` (N0, n) overrides the fixed ``MVN(m0, P0).sample(N0, PRNGKey(0))``
+    draw (:799).  N0 * N1 * N2 <= 64.
+    """
+    torch = _torch()
+    lib = _lib.require_gpu()
+    nc = np.ascontiguousarray(np.asarray(num_components, dtype=np.int32).reshape(-1))
+    if nc.size != 3 or np.any(nc < 1):
+        raise ValueError("num_components must hold three positive counts (N0, N1, N2)")
+    N0 = int(nc[0])
+    mdl = _Model(params)
+    n, m = mdl.n, mdl.m
+    y = _dev_f32(emissions, device)
+    squeeze = y.dim() == 2
+    if squeeze:
+        y = y.unsqueeze(0)
+    if y.dim() != 3 or y.shape[2] != m:
+        raise ValueError(f"emissions must be (T,{m}) or (B,T,{m}); got {tuple(y.shape)}")
+    B, T = int(y.shape[0]), int(y.shape[1])
+    if T == 0 or B == 0:
+        raise ValueError("empty emissions")
+    if carry is not None:
+        w_in, m_in, P_in = (_dev_f32(v, device).contiguous() for v in carry)
+    else:
+        w_in = None
+        im = sample_initial_component_means(params, N0) if initial_means is None else initial_means
+        m_in = _dev_f32(im, device).reshape(-1, N0, n)
+        m_in = m_in.expand(B, N0, n).contiguous() if m_in.shape[0] == 1 else m_in.contiguous()
+        P0 = params.initial_covariance if initial_covariances is None else initial_covariances
+        P_in = _dev_f32(P0, device)
+        if P_in.dim() == 2:
+            P_in = P_in.reshape(1, 1, n, n).expand(B, N0, n, n).contiguous()
+        else:
+            P_in = P_in.reshape(-1, N0, n, n)
+            P_in = P_in.expand(B, N0, n, n).contiguous() if P_in.shape[0] == 1 else P_in.contiguous()
+    if tuple(m_in.shape) != (B, N0, n) or tuple(P_in.shape) != (B, N0, n, n):
+        raise ValueError("initial means / covariances do not match (B, N0, n) / (B, N0, n, n)")
+    bufs, _, od = _alloc_outputs(B, N0, T, n, ("weights", "means", "covariances"), "reference", None, False, y.device)
+    yd = _lib.bf_cstream()
+    yd.ptr, yd.sB, yd.sK, yd.sT, yd.sE = y.data_ptr(), y.stride(0), 0, y.stride(1), y.stride(2)
+    ud = _lib.bf_cstream()
+    u_keep = None
+    if inputs is not None:
+        u_keep = _dev_f32(inputs, device)
+        if u_keep.dim() == 1:
+            u_keep = u_keep.reshape(1, T, 1)
+        elif u_keep.dim() == 2:
+            u_keep = u_keep.reshape(1, T, -1)
+        if u_keep.shape[1] != T or u_keep.shape[0] not in (1, B):
+            raise ValueError(f"inputs must be (T,), (T,d) or (B,T,d); got {tuple(u_keep.shape)}")
+        ud.ptr, ud.sB, ud.sT, ud.sE = u_keep.data_ptr(), (u_keep.stride(0) if u_keep.shape[0] == B else 0), u_keep.stride(1), 1
+    cr = _lib.bf_carry()
+    cr.w_in = w_in.data_ptr() if w_in is not None else None
+    cr.m_in, cr.P_in = m_in.data_ptr(), P_in.data_ptr()
+    c_out = None
+    if return_carry:
+        c_out = FilterCarry(torch.empty((B, N0), dtype=torch.float32, device=y.device),
+                            torch.empty((B, N0, n), dtype=torch.float32, device=y.device),
+                            torch.empty((B, N0, n, n), dtype=torch.float32, device=y.device))
+        cr.w_out, cr.m_out, cr.P_out = (t.data_ptr() for t in c_out)
+    key = np.ascontiguousarray(np.asarray(PRNGKey(0) if rng_key is None else rng_key, dtype=np.uint32).reshape(2))
+    opt = np.ascontiguousarray(np.asarray(opt_args, dtype=F32).reshape(2))
+    leaf = torch.empty((B, T, N0), dtype=torch.int32, device=y.device) if return_leaf_indices else None
+    stream = torch.cuda.current_stream(y.device).cuda_stream
+    _lib.check(lib.bf_agsf_ekf_f32(C.byref(mdl.c), C.byref(yd), C.byref(ud), B, T, nc.ctypes.data_as(C.POINTER(C.c_int32)),
+                                   key.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(opt), C.byref(cr), C.byref(od),
+                                   C.c_void_p(leaf.data_ptr() if leaf is not None else None), C.c_void_p(stream)))
+    post = PosteriorGaussianSumFiltered(**{k: (v[0] if (squeeze and v is not None) else v) for k, v in bufs.items()})
+    aux = {}
+    if return_leaf_indices:
+        aux["leaf_indices"] = leaf[0] if squeeze else leaf
+    if return_carry:
+        aux["carry"] = c_out
+    return post, aux
+
+
 class ParticleCarry(NamedTuple):
     """The scan carry (weights, particles, key) of inference.py:1364 at the end of a chunk."""
     weights: Any

@@ -175,6 +175,18 @@ int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream*
 int bf_ugsf_ukf_f32(const bf_model* model, const bf_ukf_params* uparams, const bf_cstream* y, const bf_cstream* u,
                     int64_t B, int64_t T, int32_t K, const bf_carry* carry, const bf_out_desc* out, void* stream);
 
+/* Batched "speedy" augmented Gaussian-sum filter: replaces the lax.scan of
+ * speedy_augmented_gaussian_sum_filter (inference.py:621-812).  num_components = (N0, N1, N2): every
+ * step branches the N0 carried components into N1 z-samples each (predicted with covariance
+ * opt_args[0] * P), every prediction into N2 s-samples (updated with covariance opt_args[1] * P-), and
+ * draws N0 of the N0*N1*N2 leaves with jr.choice under PRNGKey(0).  key: the reference's rng_key (it is
+ * never advanced: the same normals at every step).  The carry holds N0 components per trajectory;
+ * out: weights / means / covs with K = N0 (the other streams must be unset).  leaf_idx: optional
+ * DEVICE int32 [B][T][N0], the leaf each carried component was drawn from.  N0*N1*N2 <= 64. */
+int bf_agsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream* u, int64_t B, int64_t T,
+                    const int32_t num_components[3], const uint32_t key[2], const float opt_args[2], const bf_carry* carry,
+                    const bf_out_desc* out, int32_t* leaf_idx, void* stream);
+
 /* Moment-matching collapse of the mixture posterior per (trajectory, step): gaussfiltax/utils.py:10-18
  * and the point estimate sum_k w_k m_k (docs/experiments/BOT_Experiment_script.py:101).  weights /
  * means / covs are the strided streams a filter emitted (covs may be NULL when cov_out is NULL);

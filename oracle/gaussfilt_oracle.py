@@ -14,6 +14,7 @@ Follows, line by line (paths relative to /root/reference):
   ParamsUKF, _ukf_predict_nonadditive, _ukf_condition_on_nonadditive, unscented_gaussian_sum_filter
                             gaussfiltax/inference.py:41-49, 146-174, 198-224, 379-456
   _get_sigma_points         gaussfiltax/utils.py:247-254
+  speedy_augmented_gaussian_sum_filter   gaussfiltax/inference.py:621-812
 
 Quirks reproduced on purpose: update->reweight->predict order; psd_solve adds
 1e-6 to EVERY entry of S and uses LU (sgesv); posterior covariance P - K S K^T with the
@@ -369,6 +370,82 @@ def unscented_gaussian_sum_filter(params, uparams, emissions, num_components=1, 
     if return_ll:
         return post, out_ll.swapaxes(0, 1).copy()
     return post
+
+
+# --------------------------------------------------------------------------- augmented GSF (speedy variant)
+def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_key=None, num_iter=1,
+                                         opt_args=(0.1, 0.1), inputs=None, initial_means=None, debug=False):
+    """inference.py:621-812.  Every step branches each of the N0 carried components into N1 z-samples
+    (drawn from N(m, P - Delta), Delta = opt_args[0] P, :675-688), predicts each with covariance Delta
+    (:695-698), branches every prediction into N2 s-samples (N(m-, P- - Lambda), Lambda = opt_args[1] P-,
+    :711-726), updates each with covariance Lambda (:735-744) and resamples N0 of the N0 N1 N2 leaves with
+    jr.choice under the FIXED key PRNGKey(0) (:760).  Quirks kept: ``rng_key`` is never advanced, so the
+    same two normal arrays are used at every step (:672, :716); the s-key is split(key)[0] of the z-key;
+    the leaf weights are the carried weights / N1 / N2 times exp(ll - max) (:699, :738-743); the emitted
+    weights are 1 / N0 (:765).  Returns (PosteriorGaussianSumFiltered(weights, means, covariances), aux)
+    with aux = {'pre_weights', 'updated_means'} (two of the reference's aux outputs) when ``debug``."""
+    emissions = np.asarray(emissions, dtype=F32)
+    T = len(emissions)
+    N0, N1, N2 = (int(v) for v in num_components)
+    fn, hn = params.dynamics_function, params.emission_function
+    inputs = _process_input(inputs, T)
+    n = np.asarray(params.initial_mean).size
+    rng_key = tf.PRNGKey(0) if rng_key is None else np.asarray(rng_key, dtype=np.uint32)
+    if initial_means is None:
+        initial_means = initial_component_means(params, N0)
+    fmeans = np.array(initial_means, dtype=F32).reshape(N0, n)
+    fcovs = np.stack([np.asarray(params.initial_covariance, dtype=F32)] * N0)
+    weights = (np.ones(N0, dtype=F32) / F32(N0)).astype(F32)
+    a0, a1 = F32(opt_args[0]), F32(opt_args[1])
+    key = tf.split(rng_key, 2)[0]                       # :672  key, subkey = jr.split(rng_key)
+    eps_z = tf.normal(key, N0 * n * N1).reshape(N0, n, N1)
+    key2 = tf.split(key, 2)[0]                          # :716  key, _ = jr.split(key)
+    eps_s = tf.normal(key2, N0 * N1 * n * N2).reshape(N0 * N1, n, N2)
+    out_w = np.empty((T, N0), F32)
+    out_m = np.empty((T, N0, n), F32)
+    out_P = np.empty((T, N0, n, n), F32)
+    aux_pre, aux_um = [], []
+    M = N0 * N1 * N2
+    for t in range(T):
+        Q = np.asarray(_get_params(params.dynamics_noise_covariance, 2, t), dtype=F32)
+        q0 = np.asarray(_get_params(params.dynamics_noise_bias, 2, t), dtype=F32)
+        R = np.asarray(_get_params(params.emission_noise_covariance, 2, t), dtype=F32)
+        r0 = np.asarray(_get_params(params.emission_noise_bias, 2, t), dtype=F32)
+        u, y = inputs[t], emissions[t]
+        pm = np.empty((N0 * N1, n), F32)
+        pP = np.empty((N0 * N1, n, n), F32)
+        for i0 in range(N0):
+            Delta = (a0 * fcovs[i0]).astype(F32)
+            Lz = np.linalg.cholesky((fcovs[i0] - Delta).astype(F32)).astype(F32)
+            zc = _mm(Lz, eps_z[i0])                      # (n, N1)
+            for i1 in range(N1):
+                z = (fmeans[i0] + zc[:, i1]).astype(F32)
+                pm[i0 * N1 + i1], pP[i0 * N1 + i1], _ = _predict(z, Delta, fn, Q, q0, u)
+        lls = np.empty(M, F32)
+        um = np.empty((M, n), F32)
+        uP = np.empty((M, n, n), F32)
+        for j in range(N0 * N1):
+            Lam = (a1 * pP[j]).astype(F32)
+            Ls = np.linalg.cholesky((pP[j] - Lam).astype(F32)).astype(F32)
+            sc = _mm(Ls, eps_s[j])                       # (n, N2)
+            for i2 in range(N2):
+                sv = (pm[j] + sc[:, i2]).astype(F32)
+                lls[j * N2 + i2], um[j * N2 + i2], uP[j * N2 + i2], _, _ = _condition_on(sv, Lam, hn, R, r0, u, y)
+        pw = (np.repeat(weights, N1) / F32(N1)).astype(F32)          # :699
+        uw = (np.repeat(pw, N2) / F32(N2)).astype(F32)               # :738
+        w = reweight(lls, uw)                                         # :740-743
+        idx = tf.choice_indices(tf.cumsum_assoc(w), tf.uniform(tf.PRNGKey(0), N0))   # :760
+        idx = np.minimum(idx, M - 1)
+        fmeans, fcovs = um[idx].copy(), uP[idx].copy()
+        weights = (np.ones(N0, dtype=F32) / F32(N0)).astype(F32)
+        out_w[t], out_m[t], out_P[t] = weights, fmeans, fcovs
+        if debug:
+            aux_pre.append(w.copy())
+            aux_um.append(um.copy())
+    post = PosteriorGaussianSumFiltered(weights=out_w.swapaxes(0, 1).copy(), means=out_m.swapaxes(0, 1).copy(),
+                                        covariances=out_P.swapaxes(0, 1).copy())
+    aux = {"pre_weights": np.stack(aux_pre), "updated_means": np.stack(aux_um)} if debug else {}
+    return post, aux
 
 
 def collapse(mean_mat, covariance_tens, weight_vec):

@@ -3,7 +3,7 @@
 
 The reference (gaussfiltax) cannot run in the build container (no jax / tensorflow_probability)
 and its own tests hold no vectors, so these fixtures are produced by oracle/gaussfilt_oracle.py
--- the fp32 restatement of gaussfiltax/inference.py:51-120,303-377,1302-1380 -- and pin the
+-- the fp32 restatement of gaussfiltax/inference.py:51-120,146-224,303-456,621-812,1302-1380 -- and pin the
 HIP kernels (tests -m gpu) and the C port against it.  Re-run:  python tests/golden/make_golden.py
 """
 import os
@@ -87,8 +87,33 @@ def rng_vectors():
                         cumsum_in=np.linspace(0.1, 1.3, 13, dtype=F32), cumsum_out=otf.cumsum_assoc(np.linspace(0.1, 1.3, 13, dtype=F32)))
 
 
+def _bot_model():
+    mu0 = np.array([2.0, 0.3, 3.0, -0.2], F32)
+    S0 = np.diag([0.1, 0.005, 0.1, 0.01]).astype(F32)
+    Q, R = 1e-3 * np.eye(2, dtype=F32), np.diag([1e-3, 1e-2]).astype(F32)
+    return go.ParamsNLSSM(mu0, S0, om.ManeuverBOT(), np.zeros(2, F32), Q, om.BearingRange(), np.zeros(2, F32), R), mu0
+
+
+def unscented_and_augmented():
+    """(f-2, f-3) unscented GSF (ParamsUKF(1, 0, 0), K = 4) and speedy augmented GSF ((3, 2, 2) components) on the
+    manoeuvring-target / bearing + range model of BOT_Experiment_script.py, T = 24 with inputs."""
+    p, mu0 = _bot_model()
+    T = 24
+    inputs = np.array([1] * 8 + [0] * 8 + [2] * 8, F32).reshape(T, 1)
+    xs, ys = go.sample_ssm(p, otf.PRNGKey(42), T, inputs)
+    im = (mu0 + 0.05 * np.random.default_rng(3).normal(size=(4, 4))).astype(F32)
+    post = go.unscented_gaussian_sum_filter(p, go.ParamsUKF(1, 0, 0), ys, 4, inputs=inputs, initial_means=im)
+    np.savez_compressed(os.path.join(OUT, "ugsf_bot_K4_T24.npz"), emissions=ys, states=xs, inputs=inputs, initial_means=im,
+                        uparams=np.array([1, 0, 0], F32), **post._asdict())
+    post, aux = go.speedy_augmented_gaussian_sum_filter(p, ys, (3, 2, 2), otf.PRNGKey(5), 1, (0.2, 0.3), inputs,
+                                                        initial_means=im[:3], debug=True)
+    np.savez_compressed(os.path.join(OUT, "agsf_bot_322_T24.npz"), emissions=ys, inputs=inputs, initial_means=im[:3],
+                        key=otf.PRNGKey(5), opt_args=np.array([0.2, 0.3], F32), weights=post.weights, means=post.means,
+                        covariances=post.covariances, pre_weights=aux["pre_weights"])
+
+
 if __name__ == "__main__":
-    kalman_cv(); kalman_random(); gsf_models(); bpf_small(); rng_vectors()
+    kalman_cv(); kalman_random(); gsf_models(); bpf_small(); rng_vectors(); unscented_and_augmented()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")

@@ -1,0 +1,107 @@
+"""GPU parity of the "speedy" augmented Gaussian-sum filter (bf_agsf_ekf_f32; gaussfiltax/inference.py:
+621-812) against the NumPy oracle: bit-exact leaf indices of the per-step jr.choice draw, means and
+covariances within 2e-5 relative."""
+import numpy as np
+import pytest
+
+from oracle import gaussfilt_oracle as go, models as om, threefry as otf
+from tests import common as cm
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def _nl():
+    import bayesianfiltering_amd as bfa
+    return bfa, bfa.nonlinearities
+
+
+def _compare(post, aux, ref, ref_idx, tol=2e-5):
+    got_idx = aux["leaf_indices"].cpu().numpy()
+    assert np.array_equal(got_idx, ref_idx), "resampled leaves differ"
+    for k in ("means", "covariances"):
+        assert cm.rel_err(getattr(post, k).cpu().numpy(), getattr(ref, k)) < tol, (k, cm.rel_err(getattr(post, k).cpu().numpy(), getattr(ref, k)))
+    assert np.allclose(post.weights.cpu().numpy(), ref.weights)
+    assert post.predicted_means is None and post.predicted_covariances is None
+
+
+def _oracle_leaf_indices(aux_pre, N0):
+    return np.stack([np.minimum(otf.choice_indices(otf.cumsum_assoc(w), otf.uniform(otf.PRNGKey(0), N0)), w.size - 1)
+                     for w in aux_pre]).astype(np.int32)
+
+
+@pytest.mark.parametrize("nc", [(2, 2, 2), (3, 2, 2), (4, 4, 4), (5, 1, 3)])
+def test_linear_model(nc):
+    bfa, nl = _nl()
+    a = cm.cv_model_arrays()
+    po, pp = cm.oracle_params(a), cm.product_params(a)
+    T = 25
+    ys = go.sample_ssm(po, otf.PRNGKey(1), T)[1]
+    init = np.random.default_rng(0).normal(size=(nc[0], 4)).astype(F32)
+    ref, raux = go.speedy_augmented_gaussian_sum_filter(po, ys, nc, initial_means=init, debug=True)
+    post, aux = bfa.speedy_augmented_gaussian_sum_filter(pp, ys, nc, initial_means=init, return_leaf_indices=True)
+    assert tuple(post.means.shape) == (nc[0], T, 4) and tuple(post.covariances.shape) == (nc[0], T, 4, 4)
+    _compare(post, aux, ref, _oracle_leaf_indices(raux["pre_weights"], nc[0]))
+
+
+def test_bearings_only_batch_keys_and_chunks():
+    """Manoeuvring target with inputs, a batch of trajectories, a non-default rng_key and opt_args;
+    two chunks through the carry reproduce the single scan."""
+    bfa, nl = _nl()
+    T, B, nc = 24, 5, (3, 2, 2)
+    mu0 = np.array([2.0, 0.3, 3.0, -0.2], F32)
+    S0 = np.diag([0.1, 0.005, 0.1, 0.01]).astype(F32)
+    Q, R = 1e-3 * np.eye(2, dtype=F32), np.diag([1e-3, 1e-2]).astype(F32)
+    inputs = np.array([1] * 8 + [0] * 8 + [2] * 8, F32)
+    po = go.ParamsNLSSM(mu0, S0, om.ManeuverBOT(), np.zeros(2, F32), Q, om.BearingRange(), np.zeros(2, F32), R)
+    pp = bfa.ParamsNLSSM(mu0, S0, nl.maneuver_bot(), np.zeros(2, F32), Q, nl.bearing_range(), np.zeros(2, F32), R)
+    ys = np.stack([go.sample_ssm(po, otf.PRNGKey(10 + b), T, inputs.reshape(T, 1))[1] for b in range(B)])
+    init = (mu0 + 0.05 * np.random.default_rng(0).normal(size=(B, nc[0], 4))).astype(F32)
+    key = otf.PRNGKey(7)
+    post, aux = bfa.speedy_augmented_gaussian_sum_filter(pp, ys, nc, key, 1, (0.2, 0.3), inputs, initial_means=init,
+                                                         return_leaf_indices=True)
+    assert tuple(post.means.shape) == (B, nc[0], T, 4)
+    for b in range(B):
+        ref, raux = go.speedy_augmented_gaussian_sum_filter(po, ys[b], nc, key, 1, (0.2, 0.3), inputs.reshape(T, 1),
+                                                            initial_means=init[b], debug=True)
+        idx = _oracle_leaf_indices(raux["pre_weights"], nc[0])
+        assert np.array_equal(aux["leaf_indices"][b].cpu().numpy(), idx), b
+        for k in ("means", "covariances"):
+            assert cm.rel_err(getattr(post, k)[b].cpu().numpy(), getattr(ref, k)) < 2e-5, (b, k)
+    p1, a1 = bfa.speedy_augmented_gaussian_sum_filter(pp, ys[:, :10], nc, key, 1, (0.2, 0.3), inputs[:10], initial_means=init,
+                                                      return_carry=True)
+    p2, _ = bfa.speedy_augmented_gaussian_sum_filter(pp, ys[:, 10:], nc, key, 1, (0.2, 0.3), inputs[10:], carry=a1["carry"])
+    for k in ("means", "covariances", "weights"):
+        cat = np.concatenate([getattr(p1, k).cpu().numpy(), getattr(p2, k).cpu().numpy()], axis=2)
+        assert np.array_equal(cat, getattr(post, k).cpu().numpy()), k
+
+
+def test_lorenz96_and_errors():
+    bfa, nl = _nl()
+    T, nc = 10, (2, 2, 2)
+    po = go.ParamsNLSSM(np.zeros(8, F32), np.eye(8, dtype=F32), om.Lorenz96(8), np.zeros(8, F32),
+                        1e-2 * np.eye(8, dtype=F32), om.PickEven(8), np.zeros(4, F32), 1e-1 * np.eye(4, dtype=F32))
+    pp = bfa.ParamsNLSSM(np.zeros(8, F32), np.eye(8, dtype=F32), nl.lorenz96(8), np.zeros(8, F32),
+                         1e-2 * np.eye(8, dtype=F32), nl.pick_even(8), np.zeros(4, F32), 1e-1 * np.eye(4, dtype=F32))
+    ys = go.sample_ssm(po, otf.PRNGKey(2), T)[1]
+    init = np.random.default_rng(1).normal(size=(2, 8)).astype(F32)
+    ref, raux = go.speedy_augmented_gaussian_sum_filter(po, ys, nc, initial_means=init, debug=True)
+    post, aux = bfa.speedy_augmented_gaussian_sum_filter(pp, ys, nc, initial_means=init, return_leaf_indices=True)
+    _compare(post, aux, ref, _oracle_leaf_indices(raux["pre_weights"], 2))
+    with pytest.raises(bfa.BayesFiltError):     # more leaves than one wave
+        bfa.speedy_augmented_gaussian_sum_filter(pp, ys, (5, 5, 5))
+    with pytest.raises(ValueError):
+        bfa.speedy_augmented_gaussian_sum_filter(pp, ys, (2, 2))
+
+
+def test_golden_bearings_only_fixture(golden_dir):
+    bfa, nl = _nl()
+    d = np.load(f"{golden_dir}/agsf_bot_322_T24.npz")
+    mu0 = np.array([2.0, 0.3, 3.0, -0.2], F32)
+    pp = bfa.ParamsNLSSM(mu0, np.diag([0.1, 0.005, 0.1, 0.01]).astype(F32), nl.maneuver_bot(), np.zeros(2, F32),
+                         1e-3 * np.eye(2, dtype=F32), nl.bearing_range(), np.zeros(2, F32), np.diag([1e-3, 1e-2]).astype(F32))
+    post, aux = bfa.speedy_augmented_gaussian_sum_filter(pp, d["emissions"], (3, 2, 2), d["key"], 1, tuple(d["opt_args"]),
+                                                         d["inputs"], initial_means=d["initial_means"], return_leaf_indices=True)
+    assert np.array_equal(aux["leaf_indices"].cpu().numpy(), _oracle_leaf_indices(d["pre_weights"], 3))
+    for k in ("means", "covariances"):
+        assert cm.rel_err(getattr(post, k).cpu().numpy(), d[k]) < 2e-5, k

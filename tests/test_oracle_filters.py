@@ -156,3 +156,27 @@ def test_unscented_filter_is_exact_on_linear_models():
     assert sp.shape == (4, 2) and np.allclose(sp[:2] + sp[2:], 2 * m, atol=1e-6)
     L = (sp[:2] - m) / np.sqrt(3.0)
     assert np.allclose(L @ L, P, atol=1e-5) and np.allclose(L, L.T, atol=1e-6)
+
+
+def _bot_oracle_params():
+    mu0 = np.array([2.0, 0.3, 3.0, -0.2], np.float32)
+    S0 = np.diag([0.1, 0.005, 0.1, 0.01]).astype(np.float32)
+    Q, R = 1e-3 * np.eye(2, dtype=np.float32), np.diag([1e-3, 1e-2]).astype(np.float32)
+    return go.ParamsNLSSM(mu0, S0, om.ManeuverBOT(), np.zeros(2, np.float32), Q, om.BearingRange(), np.zeros(2, np.float32), R)
+
+
+def test_golden_unscented_and_augmented_fixtures_reproduce(golden_dir):
+    p = _bot_oracle_params()
+    d = np.load(f"{golden_dir}/ugsf_bot_K4_T24.npz")
+    post = go.unscented_gaussian_sum_filter(p, go.ParamsUKF(*d["uparams"]), d["emissions"], 4, inputs=d["inputs"],
+                                            initial_means=d["initial_means"])
+    for k in ("weights", "means", "covariances", "predicted_means", "predicted_covariances"):
+        assert cm.rel_err(getattr(post, k), d[k]) < 1e-6, k       # float64 eigh inside: allow the last bit
+    assert post.means.shape == (4, 24, 4)
+    d = np.load(f"{golden_dir}/agsf_bot_322_T24.npz")
+    post, aux = go.speedy_augmented_gaussian_sum_filter(p, d["emissions"], (3, 2, 2), d["key"], 1, tuple(d["opt_args"]),
+                                                        d["inputs"], initial_means=d["initial_means"], debug=True)
+    assert np.array_equal(post.means, d["means"]) and np.array_equal(post.covariances, d["covariances"])
+    assert np.array_equal(aux["pre_weights"], d["pre_weights"])
+    assert post.means.shape == (3, 24, 4) and np.allclose(post.weights, 1.0 / 3.0)      # :765 weights = ones / N0
+    assert np.allclose(aux["pre_weights"].sum(axis=1), 1.0, atol=1e-6)

@@ -156,3 +156,14 @@ def test_errors():
     Qt = np.stack([a["Q"]] * 6)
     with pytest.raises(bfa.BayesFiltError):    # constant covariances only
         bfa.unscented_gaussian_sum_filter(pp._replace(dynamics_noise_covariance=Qt), bfa.ParamsUKF(1, 0, 0), ys, 2)
+
+
+def test_golden_bearings_only_fixture(golden_dir):
+    bfa, nl = _nl()
+    d = np.load(f"{golden_dir}/ugsf_bot_K4_T24.npz")
+    mu0 = np.array([2.0, 0.3, 3.0, -0.2], F32)
+    pp = bfa.ParamsNLSSM(mu0, np.diag([0.1, 0.005, 0.1, 0.01]).astype(F32), nl.maneuver_bot(), np.zeros(2, F32),
+                         1e-3 * np.eye(2, dtype=F32), nl.bearing_range(), np.zeros(2, F32), np.diag([1e-3, 1e-2]).astype(F32))
+    post = bfa.unscented_gaussian_sum_filter(pp, bfa.ParamsUKF(*d["uparams"]), d["emissions"], 4, 1, d["inputs"],
+                                             initial_means=d["initial_means"])
+    _check(post, d, tol=2e-5)
