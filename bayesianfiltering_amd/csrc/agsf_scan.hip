@@ -13,6 +13,7 @@ int launch_agsf_ekf(const bf_model* p, const bf_cstream* y, const bf_cstream* u,
   BF_CASE(2, 2);
   BF_CASE(3, 1);
   BF_CASE(3, 3);
+  BF_CASE(4, 1);
   BF_CASE(4, 2);
   BF_CASE(8, 4);
 #undef BF_CASE

@@ -14,6 +14,7 @@ int launch_bpf_group_a(const bf_bpf_model* bp, const bf_cstream* y, const bf_cst
   }
   BF_CASE(2, 2, 2);
   BF_CASE(3, 3, 1);
+  BF_CASE(4, 2, 1);
   BF_CASE(16, 16, 8);
 #undef BF_CASE
   *matched = false;

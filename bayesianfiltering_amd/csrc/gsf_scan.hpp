@@ -578,6 +578,9 @@ static inline int fill_model(const bf_model* p, EkfModel<N, M>& e, std::vector<f
     case EMI_BEARING_RANGE:
       if (N != 4 || M != 2 || dr != 2) return set_error(BF_EINVAL, "bearing_range: n = 4, m = dr = 2");
       break;
+    case EMI_BEARING:
+      if (N != 4 || M != 1 || dr != 1) return set_error(BF_EINVAL, "bearing: n = 4, m = dr = 1");
+      break;
     case EMI_QUADRATIC:
       if (M != 1 || dr != 1 || p->n_emi_theta != 1) return set_error(BF_EINVAL, "quadratic: m = dr = 1, theta = (c)");
       e.eth[0] = th[0];

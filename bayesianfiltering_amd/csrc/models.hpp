@@ -6,6 +6,7 @@
 //   Lorenz-96 (f96 / g96)      gaussfiltax/nonlinearities.py:37-50 (mode 1 = matrix powers, 0 = as written)
 //   Lorenz-63                  docs/experiments/exp_lorentz63.py:37-41
 //   manoeuvring target + bearing/range   docs/experiments/BOT_Experiment_script.py:31-44
+//   bearing only (gBOT)        docs/tests/test_inference.py:46, BOT_Experiment_script.py:43
 //   sine / quadratic / growth  docs/notebooks/Experiment_TSP_2023.ipynb cell 2 (f1, g1, f3)
 //   stochastic volatility      docs/experiments/adaptive_experiment.py:51-54 (glmsv)
 #pragma once
@@ -15,7 +16,7 @@
 namespace bf {
 
 enum { DYN_LINEAR = 0, DYN_LORENZ96 = 1, DYN_LORENZ63 = 2, DYN_MANEUVER_BOT = 3, DYN_SINE = 4, DYN_GROWTH = 5 };
-enum { EMI_LINEAR = 0, EMI_BEARING_RANGE = 1, EMI_QUADRATIC = 2, EMI_STOCH_VOL = 3 };
+enum { EMI_LINEAR = 0, EMI_BEARING_RANGE = 1, EMI_QUADRATIC = 2, EMI_STOCH_VOL = 3, EMI_BEARING = 4 };
 
 // Everything the kernels need about one model; passed by value as a kernel argument.
 template <int N, int M>
@@ -153,6 +154,13 @@ __device__ __forceinline__ void emi_linearize(const EkfModel<N, M>& p, const flo
         hx[1] = d + p.Dr0[1];
         H[0] = -x[2] / d2; H[2] = x[0] / d2;
         H[4] = x[0] / d;   H[6] = x[2] / d;
+      }
+    } break;
+    case EMI_BEARING: {
+      if constexpr (N == 4 && M == 1) {
+        const float d2 = x[0] * x[0] + x[2] * x[2];
+        hx[0] = atan2f(x[2], x[0]) + p.Dr0[0];
+        H[0] = -x[2] / d2; H[2] = x[0] / d2;
       }
     } break;
     case EMI_QUADRATIC: {

@@ -156,6 +156,7 @@ int launch_sample_ssm(const bf_bpf_model* bp, const uint32_t* d_keys, const bf_c
   BF_CASE(4, 4, 1);
   BF_CASE(4, 4, 2);
   BF_CASE(4, 2, 2);
+  BF_CASE(4, 2, 1);
   BF_CASE(6, 6, 3);
   BF_CASE(8, 8, 4);
   BF_CASE(16, 16, 8);

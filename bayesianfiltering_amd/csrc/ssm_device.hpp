@@ -100,6 +100,9 @@ __device__ __forceinline__ void emi_mean_t(const MDL& p, const float* x, float u
         hx[1] = sqrtf(x[0] * x[0] + x[2] * x[2]);
       }
       break;
+    case EMI_BEARING:
+      if constexpr (N == 4 && M == 1) hx[0] = atan2f(x[2], x[0]);
+      break;
     case EMI_QUADRATIC:
       if constexpr (M == 1) {
         float s = 0.f;
@@ -191,6 +194,9 @@ static inline int fill_bpf_model(const bf_bpf_model* bp, BpfModel<N, DQ, M>& e) 
       break;
     case EMI_BEARING_RANGE:
       if (N != 4 || M != 2 || dr != 2) return set_error(BF_EINVAL, "bearing_range: n = 4, m = dr = 2");
+      break;
+    case EMI_BEARING:
+      if (N != 4 || M != 1 || dr != 1) return set_error(BF_EINVAL, "bearing: n = 4, m = dr = 1");
       break;
     case EMI_QUADRATIC:
       if (M != 1 || dr != 1 || p->n_emi_theta != 1) return set_error(BF_EINVAL, "quadratic: m = dr = 1");

@@ -14,6 +14,7 @@ int launch_ugsf_ukf(const bf_model* p, const bf_ukf_params* up, const bf_cstream
   BF_CASE(2, 2, 2, 2);   // stochastic volatility (adaptive_experiment.py:51-54)
   BF_CASE(3, 3, 1, 1);   // Lorenz-63 + quadratic (exp_lorentz63.py)
   BF_CASE(3, 3, 3, 3);
+  BF_CASE(4, 2, 1, 1);   // manoeuvring target + bearing only (docs/tests/test_inference.py)
   BF_CASE(4, 2, 2, 2);   // manoeuvring target + bearing / range, constant-velocity models (BOT_Experiment_script.py)
   BF_CASE(4, 4, 2, 2);
   BF_CASE(8, 8, 4, 4);   // Lorenz-96 with the even-state emission (nonlinearities.py:37-50)

@@ -413,6 +413,9 @@ static inline int fill_ukf_model(const bf_model* p, const bf_ukf_params* up, Ukf
     case EMI_BEARING_RANGE:
       if (N != 4 || M != 2 || DR != 2) return set_error(BF_EINVAL, "bearing_range: n = 4, m = dr = 2");
       break;
+    case EMI_BEARING:
+      if (N != 4 || M != 1 || DR != 1) return set_error(BF_EINVAL, "bearing: n = 4, m = dr = 1");
+      break;
     case EMI_QUADRATIC:
       if (M != 1 || DR != 1 || p->n_emi_theta != 1) return set_error(BF_EINVAL, "quadratic: m = dr = 1");
       e.eth[0] = th[0];

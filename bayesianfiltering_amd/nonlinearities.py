@@ -24,7 +24,7 @@ F32 = np.float32
 
 # fn_id values shared with csrc/models.hpp
 DYN_LINEAR, DYN_LORENZ96, DYN_LORENZ63, DYN_MANEUVER_BOT, DYN_SINE, DYN_GROWTH = 0, 1, 2, 3, 4, 5
-EMI_LINEAR, EMI_BEARING_RANGE, EMI_QUADRATIC, EMI_STOCH_VOL = 0, 1, 2, 3
+EMI_LINEAR, EMI_BEARING_RANGE, EMI_QUADRATIC, EMI_STOCH_VOL, EMI_BEARING = 0, 1, 2, 3, 4
 
 
 class DeviceFunction:
@@ -126,6 +126,13 @@ def bearing_range():
     return DeviceFunction("emission", EMI_BEARING_RANGE, 4, 2, 2, [],
                           lambda x, r, u: np.array([np.arctan2(x[2], x[0]), np.sqrt(x[0] ** 2 + x[2] ** 2)], dtype=F32) + r,
                           "bearing_range")
+
+
+def bearing():
+    """gBOT of docs/experiments/BOT_Experiment_script.py:43 and docs/tests/test_inference.py:46: the bearing
+    arctan2(x[2], x[0]) + r alone (emission_dim = 1)."""
+    return DeviceFunction("emission", EMI_BEARING, 4, 1, 1, [],
+                          lambda x, r, u: np.reshape(np.arctan2(x[2], x[0]) + r, (1,)).astype(F32), "bearing")
 
 
 def sine(state_dim, w0=10.0):

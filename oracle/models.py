@@ -200,6 +200,23 @@ class BearingRange(Fn):
         return np.eye(2, dtype=F32)
 
 
+class Bearing(Fn):
+    """gBOT: atan2(x2, x0) + r  (BOT_Experiment_script.py:43, docs/tests/test_inference.py:46)."""
+
+    def __init__(self):
+        self.out_dim = self.noise_dim = 1
+
+    def value(self, x, w, u):
+        return (np.array([np.arctan2(x[2], x[0])], dtype=F32) + w).astype(F32)
+
+    def jac_x(self, x, w, u):
+        d2 = x[0] * x[0] + x[2] * x[2]
+        return np.array([[-x[2] / d2, 0, x[0] / d2, 0]], dtype=F32)
+
+    def jac_noise(self, x, w, u):
+        return np.eye(1, dtype=F32)
+
+
 class Sine(Fn):
     """f1: sin(w0 * x) + q element-wise (Experiment_TSP_2023.ipynb cell 2, w0 = 10)."""
 

@@ -74,7 +74,7 @@ def test_registry_functions_match_oracle_models():
     rng = np.random.default_rng(0)
     pairs = [(nl.lorenz96(8), om.Lorenz96(8), 8, 8, 0.0), (nl.lorenz96(8, mode="as_written"), om.Lorenz96(8, mode="as_written"), 8, 8, 0.0),
              (nl.lorenz63(), om.Lorenz63(), 3, 3, 0.0), (nl.maneuver_bot(), om.ManeuverBOT(), 4, 2, 1.0),
-             (nl.maneuver_bot(), om.ManeuverBOT(), 4, 2, 2.0), (nl.bearing_range(), om.BearingRange(), 4, 2, 0.0),
+             (nl.maneuver_bot(), om.ManeuverBOT(), 4, 2, 2.0), (nl.bearing_range(), om.BearingRange(), 4, 2, 0.0), (nl.bearing(), om.Bearing(), 4, 1, 0.0),
              (nl.sine(3), om.Sine(3), 3, 3, 0.0), (nl.quadratic(3, 0.5), om.Quadratic(3, 0.5), 3, 1, 0.0),
              (nl.growth(), om.Growth(), 1, 1, 0.3), (nl.stoch_vol(3), om.StochVol(3), 3, 3, 1.0),
              (nl.pick_even(8), om.PickEven(8), 8, 4, 0.0)]

@@ -56,7 +56,7 @@ def test_mvn_log_prob_against_scipy():
 @pytest.mark.parametrize("fn,n,nw,u", [
     (om.Lorenz96(8), 8, 8, [0]), (om.Lorenz96(8, mode="as_written"), 8, 8, [0]), (om.Lorenz63(), 3, 3, [0]),
     (om.ManeuverBOT(), 4, 2, [0]), (om.ManeuverBOT(), 4, 2, [1]), (om.ManeuverBOT(), 4, 2, [2]),
-    (om.BearingRange(), 4, 2, [0]), (om.Sine(3), 3, 3, [0]), (om.Quadratic(3, 0.5), 3, 1, [0]),
+    (om.BearingRange(), 4, 2, [0]), (om.Bearing(), 4, 1, [0]), (om.Sine(3), 3, 3, [0]), (om.Quadratic(3, 0.5), 3, 1, [0]),
     (om.Growth(), 1, 1, [0.3]), (om.StochVol(3), 3, 3, [1]), (om.StochVol(3), 3, 3, [0]), (om.PickEven(8), 8, 4, [0])])
 def test_analytic_jacobians_match_finite_differences(fn, n, nw, u):
     rng = np.random.default_rng(n + nw)
