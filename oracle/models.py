@@ -335,6 +335,8 @@ def _eval64(fn, x, w, u):
         return (c0 * fn._fcv(np.float64) + c1 * Fp + c2 * Fm) @ x + fn.G.astype(np.float64) @ w
     if isinstance(fn, BearingRange):
         return np.array([np.arctan2(x[2], x[0]), np.hypot(x[0], x[2])]) + w
+    if isinstance(fn, Bearing):
+        return np.array([np.arctan2(x[2], x[0])]) + w
     if isinstance(fn, Sine):
         return np.sin(float(fn.w0) * x) + w
     if isinstance(fn, Quadratic):
