@@ -48,8 +48,10 @@ struct GsfCfg {
   static constexpr int EP = NS * NS;
   static constexpr int WMIN = 4 * NL;
   static constexpr int WP = (EP >= 32 ? EP : 32) > WMIN ? (EP >= 32 ? EP : 32) : WMIN;
-  static constexpr int WM = (NS >= 16 ? NS : 16) > WMIN ? (NS >= 16 ? NS : 16) : WMIN;
-  static constexpr int WW = 16 > WMIN ? 16 : WMIN;
+  // 128-byte rows for the mean / weight streams as well (8 waves per CU leave the LDS for it): a 64-byte run is
+  // half a cache line and writes ~15 % slower (scripts/store_pattern_bench.hip)
+  static constexpr int WM = (NS >= 32 ? NS : 32) > WMIN ? (NS >= 32 ? NS : 32) : WMIN;
+  static constexpr int WW = 32 > WMIN ? 32 : WMIN;
   using TP = Tile<EP, WP, CPW, 4>;
   using TM = Tile<NS, WM, CPW, 4>;
   using TW = Tile<1, WW, CPW, 0>;

@@ -57,8 +57,12 @@ struct GroupCfg {
   // (and never fewer than 64 float4 chunks per wave tile, so a flush is whole store instructions)
   static constexpr int WMIN = 4 * NL;
   static constexpr int WP = (EP >= 32 ? EP : 32) > WMIN ? (EP >= 32 ? EP : 32) : WMIN;
-  static constexpr int WM = (NS >= 16 ? NS : 16) > WMIN ? (NS >= 16 ? NS : 16) : WMIN;
-  static constexpr int WW = 16 > WMIN ? 16 : WMIN;
+  // (BF_KF_ROW_FLOATS: 128-byte rows for the mean / weight streams too when the occupancy target leaves the LDS
+  // for it -- NL >= 2 runs 8 waves per CU; a 64-byte run is half a cache line and costs ~15 % of the HBM
+  // write rate in scripts/store_pattern_bench.hip)
+  static constexpr int WSM = (NL >= 2 && NS <= 4) ? 32 : 16;
+  static constexpr int WM = (NS >= WSM ? NS : WSM) > WMIN ? (NS >= WSM ? NS : WSM) : WMIN;
+  static constexpr int WW = WSM > WMIN ? WSM : WMIN;
   using TP = Tile<EP, WP, CPW, 4>;
   using TM = Tile<NS, WM, CPW, 4>;
   using TW = Tile<1, WW, CPW, (NL == 1 ? 0 : 4)>;  // NL = 1 fills the 160 KiB exactly without the pad
