@@ -60,7 +60,10 @@ struct GroupCfg {
   // (BF_KF_ROW_FLOATS: 128-byte rows for the mean / weight streams too when the occupancy target leaves the LDS
   // for it -- NL >= 2 runs 8 waves per CU; a 64-byte run is half a cache line and costs ~15 % of the HBM
   // write rate in scripts/store_pattern_bench.hip)
-  static constexpr int WSM = (NL >= 2 && NS <= 4) ? 32 : 16;
+#ifndef BF_KF_WSM
+#define BF_KF_WSM 32
+#endif
+  static constexpr int WSM = (NL >= 2 && NS <= 4) ? BF_KF_WSM : 16;
   static constexpr int WM = (NS >= WSM ? NS : WSM) > WMIN ? (NS >= WSM ? NS : WSM) : WMIN;
   static constexpr int WW = WSM > WMIN ? WSM : WMIN;
   using TP = Tile<EP, WP, CPW, 4>;
