@@ -244,11 +244,15 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
       BF_UNROLL for (int d = 0; d < N; ++d) x[p][d] = xn[d];
       // MVN(h(x), R).log_prob(y) through the Cholesky factor (tfp), forward substitution
       float hx[M], zz[M];
-      emi_value<N, DQ, M>(mdl, xn, u0, hx);
+      if (mdl.h_pick) {  // selection emission (e.g. the even states of Lorenz-96): the zero terms of H x are skipped
+        BF_UNROLL for (int a = 0; a < M; ++a) hx[a] = xn[(2 * a) % N] + mdl.hb[a];
+      } else {
+        emi_value<N, DQ, M>(mdl, xn, u0, hx);
+      }
       float quad = 0.f;
       BF_UNROLL for (int a = 0; a < M; ++a) {
         float s = yv[a] - hx[a];
-        BF_UNROLL for (int c = 0; c < a; ++c) s = fmaf(-mdl.LR[a * M + c], zz[c], s);
+        if (!mdl.lr_diag) BF_UNROLL for (int c = 0; c < a; ++c) s = fmaf(-mdl.LR[a * M + c], zz[c], s);
         zz[a] = s * mdl.rdLR[a];
         quad = fmaf(zz[a], zz[a], quad);
       }

@@ -12,6 +12,7 @@ namespace bf {
 template <int N, int DQ, int M>
 struct BpfModel {
   int dyn_id, emi_id, g_identity, lq_diag;  // lq_diag: chol(Q) is diagonal (its zero entries are skipped)
+  int lr_diag, h_pick, pad0_, pad1_;        // lr_diag: chol(R_lp) diagonal; h_pick: linear emission whose row a is e_{2a}
   float dth[8], eth[8];
   float A[N * N];     // linear dynamics
   float Gm[N * DQ];   // F_q (noise input matrix); identity when g_identity
@@ -217,6 +218,15 @@ static inline int fill_bpf_model(const bf_bpf_model* bp, BpfModel<N, DQ, M>& e) 
     for (int k = 0; k < i; ++k)
       if (e.LQ[i * DQ + k] != 0.f) e.lq_diag = 0;
   if (cholesky_lower(bp->lp_cov, M, e.LR) != 0) return set_error(BF_EINVAL, "log-prob covariance is not positive definite");
+  e.lr_diag = 1;
+  for (int i = 0; i < M; ++i)
+    for (int k = 0; k < i; ++k)
+      if (e.LR[i * M + k] != 0.f) e.lr_diag = 0;
+  e.h_pick = (p->emi_id == EMI_LINEAR && 2 * M <= N + 1) ? 1 : 0;
+  if (e.h_pick)
+    for (int a = 0; a < M; ++a)
+      for (int i = 0; i < N; ++i)
+        if (e.Hm[a * N + i] != ((i == 2 * a) ? 1.0f : 0.0f)) e.h_pick = 0;
   float logdet = 0.f;
   for (int i = 0; i < M; ++i) {
     e.rdLR[i] = 1.0f / e.LR[i * M + i];

@@ -11,7 +11,7 @@ p = bfa.ParamsBPF(8 * np.ones(16, F32), np.eye(16, dtype=F32), nl.lorenz96(16), 
                   g, np.zeros(8, F32), R, nl.gaussian_log_prob(g, R))
 y = 8.0 + torch.randn((B, T, 8), device="cuda")
 from bayesianfiltering_amd import _lib
-for rep in range(4):
+for rep in range(int(os.environ.get("PREP", 4))):
     _lib.require_gpu().bf_set_option(b"bpf_variant", rep % 2)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
