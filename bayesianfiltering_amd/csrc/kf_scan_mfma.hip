@@ -30,6 +30,7 @@
 #include "bf_common.hpp"
 #include "kf_math.hpp"
 #include "lane_group.hpp"
+#include "scan_common.hpp"
 
 namespace bf {
 
@@ -262,7 +263,7 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
       if (lane < M) sv[lane] = sy[lane] - (s + cst->Dr0[lane]);
     }
     BF_TICK(0)
-    __syncthreads();
+    lds_barrier();
     // ================= phase B: S = (H P) H^T + D R D^T (wave 3)
     if (wave == 3) {
       f32x16 acc;
@@ -271,7 +272,7 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
       BF_UNROLL for (int r = 0; r < 16; ++r) sS[c_row(r, lane) * PS + lr] = acc[r];
     }
     BF_TICK(1)
-    __syncthreads();
+    lds_barrier();
     // ================= phase C: factorizations (waves 0 and 3)
     float ll = 0.f;
     if (wave == 0) {
@@ -283,7 +284,7 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
       ll = factor_loglik((lds_f*)sS, (lds_f*)(sKS + 1024), (lds_f*)sv, lane);
     }
     BF_TICK(2)
-    __syncthreads();
+    lds_barrier();
     // ================= phase E: W = L^-1 (H P) -> sT rows 32..63 (waves 2,3; K = 32)
     if (wave >= 2) {
       f32x16 acc = {0};
@@ -292,7 +293,7 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
       BF_UNROLL for (int r = 0; r < 16; ++r) sT[(32 + c_row(r, lane)) * PP + 32 * tj + lr] = acc[r];
     }
     BF_TICK(3)
-    __syncthreads();
+    lds_barrier();
     // ================= phase F: X = L^-T W -> sT rows 0..31 (waves 2,3)
     if (wave >= 2) {
       f32x16 acc = {0};
@@ -301,7 +302,7 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
       BF_UNROLL for (int r = 0; r < 16; ++r) sT[c_row(r, lane) * PP + 32 * tj + lr] = acc[r];
     }
     BF_TICK(4)
-    __syncthreads();
+    lds_barrier();
     // ================= phase G: -(K S) = -(X^T S), row block tj (waves 2,3); m+ (wave 1)
     if (wave >= 2) {
       f32x16 acc = {0};
@@ -314,7 +315,7 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
       mnxt[lane] = s;  // filtered mean
     }
     BF_TICK(5)
-    __syncthreads();
+    lds_barrier();
     // ================= phase H: P+ = P - (K S) X (all waves; K = 32); emit filtered streams
     f32x16 Pacc;
     BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] = sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr];
@@ -331,7 +332,7 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
       if (out.ll.p) out.ll.p[b * out.ll.sB + t * out.ll.sT] = ll;
     }
     BF_TICK(6)
-    __syncthreads();
+    lds_barrier();
     // ================= phase I: A P+ -> sT (all waves; K = 64); m- = A m+ + G q0 (waves 0, 3)
     {
       f32x16 acc = {0};
@@ -345,7 +346,7 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
       if (lane < 32) mcur[32 * ti + lane] = s + cst->Gq0[32 * ti + lane];  // predicted mean
     }
     BF_TICK(7)
-    __syncthreads();
+    lds_barrier();
     // ================= phase J: P- = (A P+) A^T + G Q G^T (all waves; K = 64); emit predicted streams
     BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] = cst->GQG[(32 * ti + c_row(r, lane)) * N + 32 * tj + lr];
     BF_UNROLL for (int s = 0; s < 32; ++s) Pacc = mfma2(sT[(32 * ti + lr) * PP + 2 * s + lk], sA[(32 * tj + lr) * PP + 2 * s + lk], Pacc);
@@ -354,7 +355,7 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
         out.pP.p[b * out.pP.sB + t * out.pP.sT + ((32 * ti + c_row(r, lane)) * N + 32 * tj + lr) * out.pP.sE] = Pacc[r];
     if (wave == 2 && out.pm.p) out.pm.p[b * out.pm.sB + t * out.pm.sT + lane * out.pm.sE] = mcur[lane];
     BF_TICK(8)
-    __syncthreads();
+    lds_barrier();
   }
 
   if (carry.P_out) BF_UNROLL for (int r = 0; r < 16; ++r)

@@ -28,6 +28,15 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory, i.e. it waits
+// (s_waitcnt vmcnt(0)) until every output store the wave has in flight is acknowledged by HBM -- a microsecond
+// per barrier in kernels whose phases talk through LDS and merely stream their results out.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ unsigned lds_byte_addr(const float* p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
 }
