@@ -21,6 +21,7 @@
 #include <cstring>
 #include "bf_common.hpp"
 #include "kf_math.hpp"
+#include "scan_common.hpp"
 #include "bf_rng.hpp"
 #include "models.hpp"
 #include "gsf_scan.hpp"  // fill_model: EkfModel from the C-ABI struct
@@ -94,7 +95,7 @@ agsf_scan_kernel(EkfModel<N, M> mdl, CView y, UView uin, CarryView carry, AgsfOu
     BF_UNROLL for (int i = 0; i < EP; ++i) rec[N + i] = carry.P_in[(b * N0 + l) * EP + i];
   }
   float wpar = carry.w_in ? carry.w_in[b * N0 + i0] : 1.0f / (float)N0;  // weight of the parent component
-  __syncthreads();
+  lds_barrier();
 
   auto seg_reduce = [&](float v, auto op) {  // over the MP lanes of the trajectory, adjacent-pair tree
     for (int off = 1; off < MP; off <<= 1) v = op(v, __shfl_xor(v, off, 64));
@@ -171,14 +172,14 @@ agsf_scan_kernel(EkfModel<N, M> mdl, CView y, UView uin, CarryView carry, AgsfOu
         if (l >= (1 << d) && ((l + 1) & ((1 << d) - 1)) == (1 << (d - 1))) c += o;
       }
     }
-    __syncthreads();  // previous step's readers of leafbuf / cdfbuf are done
+    lds_barrier();  // previous step's readers of leafbuf / cdfbuf are done
     cdfbuf[tid] = c;
     {
       float* rec = leafbuf + tid * REC;
       BF_UNROLL for (int i = 0; i < N; ++i) rec[i] = mz[i];
       BF_UNROLL for (int i = 0; i < EP; ++i) rec[N + i] = P[i];
     }
-    __syncthreads();
+    lds_barrier();
     if (l < N0) {
       const float* cd = cdfbuf + slot * MP;
       const float r = cd[Mleaf - 1] * (1.0f - udraw);
@@ -200,7 +201,7 @@ agsf_scan_kernel(EkfModel<N, M> mdl, CView y, UView uin, CarryView carry, AgsfOu
       }
     }
     wpar = 1.0f / (float)N0;  // weights = ones / N0                                                :765
-    __syncthreads();
+    lds_barrier();
   }
 
   if (traj_ok && l < N0) {

@@ -27,6 +27,7 @@
 #include <cstring>
 #include "bf_common.hpp"
 #include "kf_math.hpp"
+#include "scan_common.hpp"
 #include "bf_rng.hpp"
 #include "models.hpp"
 #include "ssm_device.hpp"
@@ -75,9 +76,9 @@ __device__ __forceinline__ void resample_indices(const float* wn, const bool* va
   }
   float excl_wave = 0.f;  // inclusive scan value at the end of the previous wave
   if constexpr (NW > 1) {
-    __syncthreads();
+    lds_barrier();
     if (lane == 63) red[16 + wave] = v;
-    __syncthreads();
+    lds_barrier();
     float r = (lane < NW) ? red[16 + lane] : 0.f;
     BF_UNROLL for (int d = 0; (1 << d) < NW; ++d) {  // up-sweep over the NW wave totals
       const float o = __shfl_up(r, 1 << d, 64);
@@ -110,9 +111,9 @@ __device__ __forceinline__ void resample_indices(const float* wn, const bool* va
     const int bs = (p / (2 * s)) * (2 * s);
     c[p] = ((bs == 0) ? E : c[bs - 1]) + tsum[p];
   }
-  __syncthreads();
+  lds_barrier();
   BF_UNROLL for (int p = 0; p < PPT; ++p) cdf[tid * PPT + p] = c[p];
-  __syncthreads();
+  lds_barrier();
   const float total = cdf[NP - 1];
   float u_sys = 0.f;
   if (resampler == 1) u_sys = bits_to_unit(threefry_bits(kc.x, kc.y, 0u, 1u));
@@ -156,9 +157,9 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
   auto block_reduce = [&](float v, auto op) {  // v already reduced over the thread's own slots
     BF_UNROLL for (int off = 1; off < 64; off <<= 1) v = op(v, __shfl_xor(v, off, 64));
     if constexpr (NW > 1) {
-      __syncthreads();
+      lds_barrier();
       if (lane == 0) red[wave] = v;
-      __syncthreads();
+      lds_barrier();
       float r = (lane < NW) ? red[lane] : red[0];
       BF_UNROLL for (int off = 1; off < NW; off <<= 1) r = op(r, __shfl_xor(r, off, 64));
       v = __shfl(r, 0, 64);
@@ -284,10 +285,10 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
       resample_indices<PPT, NW>(wn, valid, NP, kc, resampler, cdf, red, anc);
       // gather through LDS, DCH dimensions per pass
       BF_UNROLL for (int d0 = 0; d0 < N; d0 += DCH) {
-        __syncthreads();
+        lds_barrier();
         BF_UNROLL for (int p = 0; p < PPT; ++p) BF_UNROLL for (int d = 0; d < DCH; ++d)
             if (d0 + d < N) tile[d * CAP + tid * PPT + p] = x[p][d0 + d];
-        __syncthreads();
+        lds_barrier();
         BF_UNROLL for (int p = 0; p < PPT; ++p) BF_UNROLL for (int d = 0; d < DCH; ++d)
             if (d0 + d < N) x[p][d0 + d] = tile[d * CAP + anc[p]];
       }
@@ -315,9 +316,9 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
         BF_UNROLL for (int off = 1; off < 64; off <<= 1) s += __shfl_xor(s, off, 64);
         part[d] = s;
       }
-      __syncthreads();
+      lds_barrier();
       if (lane == 0) BF_UNROLL for (int d = 0; d < N; ++d) tile[wave * N + d] = part[d];
-      __syncthreads();
+      lds_barrier();
       if (tid < N) {
         float s = 0.f;
         for (int wv = 0; wv < NW; ++wv) s += tile[wv * N + tid];

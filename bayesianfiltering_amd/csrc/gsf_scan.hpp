@@ -131,7 +131,7 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
   constexpr int GQ = L96 ? EP : 0;  // L96: F_q Q F_q^T, read back by every lane in its own coordinates
   if constexpr (L96) {
     if (tid == 0) BF_UNROLL for (int i = 0; i < EP; ++i) lds[GSF_HDR + i] = mdl.GQG[i];
-    __syncthreads();
+    lds_barrier();
   }
   int q = GSF_HDR + GQ + wave_in_blk * lds_per_wave;
   int oP = q, opP = q, oM = q, opM = q, oW = q, oL = q;
@@ -160,9 +160,9 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
     const int lim = seg < 64 ? seg : 64;
     for (int off = NL; off < lim; off <<= 1) v = op(v, __shfl_xor(v, off, 64));
     if (seg > 64) {  // uniform: the trajectory spans seg / 64 waves of this workgroup
-      __syncthreads();
+      lds_barrier();
       if (lane == 0) red[wave_in_blk] = v;
-      __syncthreads();
+      lds_barrier();
       const int wpt = seg / 64;
       const int w0 = (wave_in_blk / wpt) * wpt;
       // adjacent-pair tree over the waves of the trajectory
@@ -189,9 +189,9 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
     if (lim > 16) v = xor16_combine(v, add);
     if (lim > 32) v = xor32_combine(v, add);
     if (seg > 64) {
-      __syncthreads();
+      lds_barrier();
       if (lane < NL) red[8 + wave_in_blk * 4 + lane] = v;
-      __syncthreads();
+      lds_barrier();
       const int wpt = seg / 64;
       const int w0 = (wave_in_blk / wpt) * wpt;
       if (wpt == 2) v = red[8 + w0 * 4 + jl] + red[8 + (w0 + 1) * 4 + jl];

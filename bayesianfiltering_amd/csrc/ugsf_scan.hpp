@@ -26,6 +26,7 @@
 #include <vector>
 #include "bf_common.hpp"
 #include "kf_math.hpp"
+#include "scan_common.hpp"
 #include "models.hpp"
 #include "ssm_device.hpp"
 
@@ -155,9 +156,9 @@ ugsf_scan_kernel(const UkfModel<N, DQ, M, DR>* __restrict__ mdlp, CView y, const
     const int lim = KP < 64 ? KP : 64;
     for (int off = 1; off < lim; off <<= 1) v = op(v, __shfl_xor(v, off, 64));
     if (KP > 64) {
-      __syncthreads();
+      lds_barrier();
       if (lane == 0) red[wave] = v;
-      __syncthreads();
+      lds_barrier();
       const int wpt = KP / 64;
       const int w0 = (wave / wpt) * wpt;
       if (wpt == 2) v = op(red[w0], red[w0 + 1]);
