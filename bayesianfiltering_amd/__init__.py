@@ -4,7 +4,7 @@ bootstrap particle filters) behind the call surface of the reference package ``g
 from .models import ParamsNLSSM, ParamsBPF, NonlinearSSM
 from .containers import GaussianComponent, GaussianSum
 from .inference import (PosteriorGaussianSumFiltered, gaussian_sum_filter, unscented_gaussian_sum_filter, ParamsUKF,
-                        speedy_augmented_gaussian_sum_filter,
+                        speedy_augmented_gaussian_sum_filter, augmented_gaussian_sum_filter,
                         kalman_filter, FilterCarry,
                         FULL5, FILTERED, PRNGKey, sample_initial_component_means,
                         bootstrap_particle_filter, ParticleCarry, resample_indices)
@@ -12,6 +12,6 @@ from ._lib import BayesFiltError
 from . import nonlinearities, utils
 
 __all__ = ["ParamsNLSSM", "ParamsBPF", "NonlinearSSM", "GaussianComponent", "GaussianSum", "PosteriorGaussianSumFiltered",
-           "gaussian_sum_filter", "unscented_gaussian_sum_filter", "ParamsUKF", "speedy_augmented_gaussian_sum_filter", "kalman_filter", "FilterCarry", "FULL5", "FILTERED", "PRNGKey",
+           "gaussian_sum_filter", "unscented_gaussian_sum_filter", "ParamsUKF", "speedy_augmented_gaussian_sum_filter", "augmented_gaussian_sum_filter", "kalman_filter", "FilterCarry", "FULL5", "FILTERED", "PRNGKey",
            "sample_initial_component_means", "bootstrap_particle_filter", "ParticleCarry", "resample_indices",
            "nonlinearities", "utils", "BayesFiltError"]

@@ -5,9 +5,9 @@ namespace bf {
 
 int launch_agsf_ekf(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, const int32_t nc[3],
                     const uint32_t key[2], const float opt[2], const bf_carry* carry, const bf_out_desc* out, int* d_leaf_idx,
-                    hipStream_t stream) {
+                    int variant, hipStream_t stream) {
 #define BF_CASE(N_, M_) \
-  if (p->n == N_ && p->m == M_) return launch_agsf<N_, M_>(p, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, stream);
+  if (p->n == N_ && p->m == M_) return launch_agsf<N_, M_>(p, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, variant, stream);
   BF_CASE(1, 1);
   BF_CASE(2, 1);
   BF_CASE(2, 2);

@@ -54,7 +54,7 @@ struct AgsfOut {
 template <int N, int M>
 __global__ void __launch_bounds__(256)
 agsf_scan_kernel(EkfModel<N, M> mdl, CView y, UView uin, CarryView carry, AgsfOut out, long long B, long long T, int N0, int N1,
-                 int N2, int MP, float a0, float a1, uint32_t key0, uint32_t key1) {
+                 int N2, int MP, float a0, float a1, uint32_t key0, uint32_t key1, int variant) {
   constexpr int EP = N * N;
   constexpr int REC = N + EP;  // one component record in LDS: mean, covariance
   const int tid = threadIdx.x;
@@ -76,13 +76,26 @@ agsf_scan_kernel(EkfModel<N, M> mdl, CView y, UView uin, CarryView carry, AgsfOu
 
   // ---- the two standard-normal vectors of this leaf (same at every step: the reference's key is never advanced)
   float ez[N], es[N];
-  {
+  if (variant == 0) {
     const U32x2 kz = threefry_split(key0, key1, 0u, 2u);   // key, subkey = jr.split(rng_key)          :672
     const U32x2 ks = threefry_split(kz.x, kz.y, 0u, 2u);   // key, _ = jr.split(key)                    :716
     const uint32_t cz = (uint32_t)(N0 * N * N1), cs = (uint32_t)(N0 * N1 * N * N2);
     BF_UNROLL for (int d = 0; d < N; ++d) {
       ez[d] = bits_to_normal(threefry_bits(kz.x, kz.y, (uint32_t)((i0 * N + d) * N1 + i1), cz));            // (N0, n, N1)
       es[d] = bits_to_normal(threefry_bits(ks.x, ks.y, (uint32_t)(((i0 * N1 + i1) * N + d) * N2 + i2), cs));  // (N0 N1, n, N2)
+    }
+  } else {
+    // augmented_gaussian_sum_filter (inference.py:458-620): the branches come from containers._branches_from_tree1/2
+    // (containers.py:63-140): keys = split(subkey, #nodes), node j draws jr.multivariate_normal(keys[j], mean,
+    // cov - split_cov, (num,)) = mean + chol @ normal(keys[j], (num, n))
+    const U32x2 k0s = threefry_split(key0, key1, 0u, 2u);      // key, subkey = jr.split(rng_key)       :519
+    const U32x2 sub1 = threefry_split(key0, key1, 1u, 2u);
+    const U32x2 sub2 = threefry_split(k0s.x, k0s.y, 1u, 2u);   // key, subkey = jr.split(key)           :545
+    const U32x2 kn1 = threefry_split(sub1.x, sub1.y, (uint32_t)i0, (uint32_t)N0);
+    const U32x2 kn2 = threefry_split(sub2.x, sub2.y, (uint32_t)(i0 * N1 + i1), (uint32_t)(N0 * N1));
+    BF_UNROLL for (int d = 0; d < N; ++d) {
+      ez[d] = bits_to_normal(threefry_bits(kn1.x, kn1.y, (uint32_t)(i1 * N + d), (uint32_t)(N1 * N)));   // (N1, n)
+      es[d] = bits_to_normal(threefry_bits(kn2.x, kn2.y, (uint32_t)(i2 * N + d), (uint32_t)(N2 * N)));   // (N2, n)
     }
   }
   // uniform of the resampling draw this lane performs (lanes l < N0): uniform(PRNGKey(0), (N0,))[l]     :760
@@ -123,6 +136,7 @@ agsf_scan_kernel(EkfModel<N, M> mdl, CView y, UView uin, CarryView carry, AgsfOu
         float s = 0.f;
         BF_UNROLL for (int c = 0; c <= i; ++c) s = fmaf(Lz[i * N + c], ez[c], s);
         mz[i] = rec[i] + s;       // z = m + chol(P - Delta) eps
+        if (variant != 0 && mz[i] != mz[i]) mz[i] = rec[i];  // jnp.where(isnan(new_means), mean, new_means)  containers.py:84
       }
       float F[EP], fx[N];
       dyn_linearize<N, M>(mdl, mz, u0, F, fx);
@@ -144,6 +158,7 @@ agsf_scan_kernel(EkfModel<N, M> mdl, CView y, UView uin, CarryView carry, AgsfOu
         float s = 0.f;
         BF_UNROLL for (int c = 0; c <= i; ++c) s = fmaf(Ls[i * N + c], es[c], s);
         ms[i] = mz[i] + s;
+        if (variant != 0 && ms[i] != ms[i]) ms[i] = mz[i];        // containers.py:121
       }
       float H[M * N], hx[M], HrRHr[M * M], v[M];
       emi_linearize<N, M>(mdl, ms, u0, H, hx, HrRHr);
@@ -215,7 +230,7 @@ agsf_scan_kernel(EkfModel<N, M> mdl, CView y, UView uin, CarryView carry, AgsfOu
 template <int N, int M>
 static inline int launch_agsf(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
                               const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry,
-                              const bf_out_desc* out, int* d_leaf_idx, hipStream_t stream) {
+                              const bf_out_desc* out, int* d_leaf_idx, int variant, hipStream_t stream) {
   EkfModel<N, M> e;
   int rc = fill_model<N, M>(p, e);
   if (rc != BF_OK) return rc;
@@ -238,7 +253,7 @@ static inline int launch_agsf(const bf_model* p, const bf_cstream* y, const bf_c
     BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   const int tpb = 256 / MP;
   hipLaunchKernelGGL(kern, dim3((unsigned)((B + tpb - 1) / tpb)), dim3(256), lds_bytes, stream, e, yv, uv, cv, ov, B, T, nc[0],
-                     nc[1], nc[2], MP, opt[0], opt[1], key[0], key[1]);
+                     nc[1], nc[2], MP, opt[0], opt[1], key[0], key[1], variant);
   BF_HIP_CHECK(hipGetLastError());
   return BF_OK;
 }

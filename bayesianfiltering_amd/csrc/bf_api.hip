@@ -33,7 +33,7 @@ int launch_ugsf_ukf(const bf_model* p, const bf_ukf_params* up, const bf_cstream
                     long long T, int K, const bf_carry* carry, const bf_out_desc* out, hipStream_t stream);
 int launch_agsf_ekf(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, const int32_t nc[3],
                     const uint32_t key[2], const float opt[2], const bf_carry* carry, const bf_out_desc* out, int* d_leaf_idx,
-                    hipStream_t stream);
+                    int variant, hipStream_t stream);
 int launch_bpf(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP,
                float ess, int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o,
                hipStream_t stream);
@@ -156,7 +156,8 @@ int bf_ugsf_ukf_f32(const bf_model* model, const bf_ukf_params* uparams, const b
 
 int bf_agsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream* u, int64_t B, int64_t T,
                     const int32_t num_components[3], const uint32_t key[2], const float opt_args[2], const bf_carry* carry,
-                    const bf_out_desc* out, int32_t* leaf_idx, void* stream) {
+                    const bf_out_desc* out, int32_t* leaf_idx, int32_t variant, void* stream) {
+  if (variant != 0 && variant != 1) return bf::set_error(BF_EINVAL, "variant must be 0 (speedy) or 1 (container branches)");
   if (!model || !y || !carry || !out || !num_components || !key || !opt_args) return bf::set_error(BF_EINVAL, "NULL argument");
   if (B <= 0 || T <= 0) return bf::set_error(BF_EINVAL, "B and T must be positive");
   if (num_components[0] <= 0 || num_components[1] <= 0 || num_components[2] <= 0)
@@ -167,7 +168,7 @@ int bf_agsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream
   if (model->Q_steps > 1 || model->R_steps > 1) return bf::set_error(BF_EUNSUPPORTED, "time-varying Q/R are not supported by the augmented filter");
   if (!y->ptr) return bf::set_error(BF_EINVAL, "observations pointer is NULL");
   if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
-  return bf::launch_agsf_ekf(model, y, u, B, T, num_components, key, opt_args, carry, out, leaf_idx,
+  return bf::launch_agsf_ekf(model, y, u, B, T, num_components, key, opt_args, carry, out, leaf_idx, variant,
                              static_cast<hipStream_t>(stream));
 }
 

@@ -435,7 +435,7 @@ def unscented_gaussian_sum_filter(params, uparams, emissions, num_components: in
 def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_key=None, num_iter: int = 1,
                                          opt_args=(0.1, 0.1), inputs=None, *, initial_means=None,
                                          initial_covariances=None, carry=None, return_carry: bool = False,
-                                         return_leaf_indices: bool = False, device="cuda"):
+                                         return_leaf_indices: bool = False, device="cuda", _variant=0):
     """"Speedy" augmented Gaussian-sum filter, gaussfiltax/inference.py:621-812, on the HIP engine.
 
     Same positional signature as the reference: ``num_components = (N0, N1, N2)``, ``rng_key`` defaults to
@@ -510,7 +510,7 @@ def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_
     stream = torch.cuda.current_stream(y.device).cuda_stream
     _lib.check(lib.bf_agsf_ekf_f32(C.byref(mdl.c), C.byref(yd), C.byref(ud), B, T, nc.ctypes.data_as(C.POINTER(C.c_int32)),
                                    key.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(opt), C.byref(cr), C.byref(od),
-                                   C.c_void_p(leaf.data_ptr() if leaf is not None else None), C.c_void_p(stream)))
+                                   C.c_void_p(leaf.data_ptr() if leaf is not None else None), int(_variant), C.c_void_p(stream)))
     post = PosteriorGaussianSumFiltered(**{k: (v[0] if (squeeze and v is not None) else v) for k, v in bufs.items()})
     aux = {}
     if return_leaf_indices:
@@ -518,6 +518,18 @@ def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_
     if return_carry:
         aux["carry"] = c_out
     return post, aux
+
+
+def augmented_gaussian_sum_filter(params, emissions, num_components, rng_key=None, num_iter: int = 1, opt_args=(0.1, 0.1),
+                                  inputs=None, **kwargs):
+    """Augmented Gaussian-sum filter, gaussfiltax/inference.py:458-620, on the HIP engine: the same tree
+    as :func:`speedy_augmented_gaussian_sum_filter` with the branches drawn as ``containers._branches_from_tree1/2``
+    draw them (containers.py:63-140: one key per node, ``jr.multivariate_normal`` per node, NaN samples
+    replaced by the node mean).  The reference needs its module globals ``num_prt1`` / ``num_prt2``
+    (containers.py:13-14) edited by hand to match ``num_components``; here they are ``num_components[1:]``.
+    Same arguments, return value and keyword extensions as the speedy variant."""
+    return speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_key, num_iter, opt_args, inputs,
+                                                _variant=1, **kwargs)
 
 
 class ParticleCarry(NamedTuple):

@@ -182,10 +182,13 @@ int bf_ugsf_ukf_f32(const bf_model* model, const bf_ukf_params* uparams, const b
  * draws N0 of the N0*N1*N2 leaves with jr.choice under PRNGKey(0).  key: the reference's rng_key (it is
  * never advanced: the same normals at every step).  The carry holds N0 components per trajectory;
  * out: weights / means / covs with K = N0 (the other streams must be unset).  leaf_idx: optional
- * DEVICE int32 [B][T][N0], the leaf each carried component was drawn from.  N0*N1*N2 <= 64. */
+ * DEVICE int32 [B][T][N0], the leaf each carried component was drawn from.  N0*N1*N2 <= 64.
+ * variant: 0 = the speedy filter's two shared normal arrays (:672-688, :716-726); 1 = the branches of
+ * augmented_gaussian_sum_filter (inference.py:458-620) through containers._branches_from_tree1/2
+ * (containers.py:63-140): one key per node, jr.multivariate_normal per node, NaN samples replaced by the mean. */
 int bf_agsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream* u, int64_t B, int64_t T,
                     const int32_t num_components[3], const uint32_t key[2], const float opt_args[2], const bf_carry* carry,
-                    const bf_out_desc* out, int32_t* leaf_idx, void* stream);
+                    const bf_out_desc* out, int32_t* leaf_idx, int32_t variant, void* stream);
 
 /* Moment-matching collapse of the mixture posterior per (trajectory, step): gaussfiltax/utils.py:10-18
  * and the point estimate sum_k w_k m_k (docs/experiments/BOT_Experiment_script.py:101).  weights /

@@ -15,6 +15,7 @@ Follows, line by line (paths relative to /root/reference):
                             gaussfiltax/inference.py:41-49, 146-174, 198-224, 379-456
   _get_sigma_points         gaussfiltax/utils.py:247-254
   speedy_augmented_gaussian_sum_filter   gaussfiltax/inference.py:621-812
+  augmented_gaussian_sum_filter          gaussfiltax/inference.py:458-620 + containers.py:63-140
 
 Quirks reproduced on purpose: update->reweight->predict order; psd_solve adds
 1e-6 to EVERY entry of S and uses LU (sgesv); posterior covariance P - K S K^T with the
@@ -374,7 +375,7 @@ def unscented_gaussian_sum_filter(params, uparams, emissions, num_components=1, 
 
 # --------------------------------------------------------------------------- augmented GSF (speedy variant)
 def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_key=None, num_iter=1,
-                                         opt_args=(0.1, 0.1), inputs=None, initial_means=None, debug=False):
+                                         opt_args=(0.1, 0.1), inputs=None, initial_means=None, debug=False, variant=0):
     """inference.py:621-812.  Every step branches each of the N0 carried components into N1 z-samples
     (drawn from N(m, P - Delta), Delta = opt_args[0] P, :675-688), predicts each with covariance Delta
     (:695-698), branches every prediction into N2 s-samples (N(m-, P- - Lambda), Lambda = opt_args[1] P-,
@@ -398,9 +399,19 @@ def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_
     weights = (np.ones(N0, dtype=F32) / F32(N0)).astype(F32)
     a0, a1 = F32(opt_args[0]), F32(opt_args[1])
     key = tf.split(rng_key, 2)[0]                       # :672  key, subkey = jr.split(rng_key)
-    eps_z = tf.normal(key, N0 * n * N1).reshape(N0, n, N1)
-    key2 = tf.split(key, 2)[0]                          # :716  key, _ = jr.split(key)
-    eps_s = tf.normal(key2, N0 * N1 * n * N2).reshape(N0 * N1, n, N2)
+    if variant == 0:
+        eps_z = tf.normal(key, N0 * n * N1).reshape(N0, n, N1)
+        key2 = tf.split(key, 2)[0]                      # :716  key, _ = jr.split(key)
+        eps_s = tf.normal(key2, N0 * N1 * n * N2).reshape(N0 * N1, n, N2)
+    else:
+        # augmented_gaussian_sum_filter (:458-620) via containers._branches_from_tree1/2 (containers.py:63-140):
+        # keys = split(subkey, #nodes); node j: jr.multivariate_normal(keys[j], mean, cov - split_cov, (num,))
+        #   = mean + chol @ normal(keys[j], (num, n))[i]      (method='cholesky'); NaN samples -> mean
+        sub1 = tf.split(rng_key, 2)[1]                  # :519
+        sub2 = tf.split(key, 2)[1]                      # :545  key, subkey = jr.split(key)
+        k1, k2 = tf.split(sub1, N0), tf.split(sub2, N0 * N1)
+        eps_z = np.stack([tf.normal(k1[i], N1 * n).reshape(N1, n).T for i in range(N0)])          # (N0, n, N1)
+        eps_s = np.stack([tf.normal(k2[j], N2 * n).reshape(N2, n).T for j in range(N0 * N1)])     # (N0 N1, n, N2)
     out_w = np.empty((T, N0), F32)
     out_m = np.empty((T, N0, n), F32)
     out_P = np.empty((T, N0, n, n), F32)
@@ -420,6 +431,8 @@ def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_
             zc = _mm(Lz, eps_z[i0])                      # (n, N1)
             for i1 in range(N1):
                 z = (fmeans[i0] + zc[:, i1]).astype(F32)
+                if variant:
+                    z = np.where(np.isnan(z), fmeans[i0], z).astype(F32)                     # containers.py:84
                 pm[i0 * N1 + i1], pP[i0 * N1 + i1], _ = _predict(z, Delta, fn, Q, q0, u)
         lls = np.empty(M, F32)
         um = np.empty((M, n), F32)
@@ -430,6 +443,8 @@ def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_
             sc = _mm(Ls, eps_s[j])                       # (n, N2)
             for i2 in range(N2):
                 sv = (pm[j] + sc[:, i2]).astype(F32)
+                if variant:
+                    sv = np.where(np.isnan(sv), pm[j], sv).astype(F32)                        # containers.py:121
                 lls[j * N2 + i2], um[j * N2 + i2], uP[j * N2 + i2], _, _ = _condition_on(sv, Lam, hn, R, r0, u, y)
         pw = (np.repeat(weights, N1) / F32(N1)).astype(F32)          # :699
         uw = (np.repeat(pw, N2) / F32(N2)).astype(F32)               # :738
@@ -446,6 +461,13 @@ def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_
                                         covariances=out_P.swapaxes(0, 1).copy())
     aux = {"pre_weights": np.stack(aux_pre), "updated_means": np.stack(aux_um)} if debug else {}
     return post, aux
+
+
+def augmented_gaussian_sum_filter(params, emissions, num_components, rng_key=None, num_iter=1, opt_args=(0.1, 0.1),
+                                  inputs=None, initial_means=None, debug=False):
+    """inference.py:458-620: the speedy filter's tree with container-based branches (see ``variant`` above)."""
+    return speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_key, num_iter, opt_args, inputs,
+                                                initial_means, debug, variant=1)
 
 
 def collapse(mean_mat, covariance_tens, weight_vec):

@@ -105,3 +105,22 @@ def test_golden_bearings_only_fixture(golden_dir):
     assert np.array_equal(aux["leaf_indices"].cpu().numpy(), _oracle_leaf_indices(d["pre_weights"], 3))
     for k in ("means", "covariances"):
         assert cm.rel_err(getattr(post, k).cpu().numpy(), d[k]) < 2e-5, k
+
+
+@pytest.mark.parametrize("nc", [(2, 5, 5), (3, 2, 2)])
+def test_container_branch_variant(nc):
+    """augmented_gaussian_sum_filter (inference.py:458-620): per-node keys and jr.multivariate_normal draws
+    (containers.py:63-140); (2, 5, 5) is the reference's own test size (docs/tests/test_inference.py:85)."""
+    bfa, nl = _nl()
+    a = cm.cv_model_arrays()
+    po, pp = cm.oracle_params(a), cm.product_params(a)
+    T = 20
+    ys = go.sample_ssm(po, otf.PRNGKey(3), T)[1]
+    init = np.random.default_rng(1).normal(size=(nc[0], 4)).astype(F32)
+    key = otf.PRNGKey(11)
+    ref, raux = go.augmented_gaussian_sum_filter(po, ys, nc, key, initial_means=init, debug=True)
+    post, aux = bfa.augmented_gaussian_sum_filter(pp, ys, nc, key, initial_means=init, return_leaf_indices=True)
+    _compare(post, aux, ref, _oracle_leaf_indices(raux["pre_weights"], nc[0]))
+    # and it is a different stream from the speedy variant
+    sp, _ = bfa.speedy_augmented_gaussian_sum_filter(pp, ys, nc, key, initial_means=init)
+    assert not np.allclose(sp.means.cpu().numpy(), post.means.cpu().numpy())
