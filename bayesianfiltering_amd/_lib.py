@@ -91,6 +91,9 @@ SYMBOLS = {
     "bf_agsf_ekf_f32": (C.c_int, [C.POINTER(bf_model), C.POINTER(bf_cstream), C.POINTER(bf_cstream), C.c_int64, C.c_int64,
                                   C.POINTER(C.c_int32), C.POINTER(C.c_uint32), _FP, C.POINTER(bf_carry),
                                   C.POINTER(bf_out_desc), C.c_void_p, C.c_int32, C.c_void_p]),
+    "bf_agsf_ukf_f32": (C.c_int, [C.POINTER(bf_model), C.POINTER(bf_ukf_params), C.POINTER(bf_cstream), C.POINTER(bf_cstream),
+                                  C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), _FP, C.POINTER(bf_carry),
+                                  C.POINTER(bf_out_desc), C.c_void_p, C.c_int32, C.c_void_p]),
     "bf_collapse_f32": (C.c_int, [C.POINTER(bf_stream), C.POINTER(bf_stream), C.POINTER(bf_stream), C.c_int64, C.c_int64,
                                   C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bf_bpf_f32": (C.c_int, [C.POINTER(bf_bpf_model), C.POINTER(bf_cstream), C.POINTER(bf_cstream), C.c_int64, C.c_int64,

@@ -24,7 +24,8 @@
 #include "scan_common.hpp"
 #include "bf_rng.hpp"
 #include "models.hpp"
-#include "gsf_scan.hpp"  // fill_model: EkfModel from the C-ABI struct
+#include "gsf_scan.hpp"   // fill_model: EkfModel from the C-ABI struct
+#include "ugsf_scan.hpp"  // unscented node operations (speedy_unscented_agsf, unscented_agsf)
 
 namespace bf {
 
@@ -46,14 +47,41 @@ __device__ __forceinline__ void chol_lower(const float* A, float* L) {
   }
 }
 
+// What a tree node does with its Gaussian: the extended-Kalman pair _predict / _condition_on
+// (inference.py:51-105) or the unscented pair (:146-174, :198-224) of speedy_unscented_agsf (:966-1156).
+template <int N, int M>
+struct EkfNodes {
+  using Arg = EkfModel<N, M>;  // by value, in the kernel arguments
+  static __device__ __forceinline__ void predict(const Arg& mdl, float* m, float* P, float u0) {
+    float F[N * N], fx[N];
+    dyn_linearize<N, M>(mdl, m, u0, F, fx);
+    predict_cov<N>(F, mdl.GQG, P);  // F P F^T + F_q Q F_q^T
+    BF_UNROLL for (int i = 0; i < N; ++i) m[i] = fx[i];
+  }
+  static __device__ __forceinline__ float condition(const Arg& mdl, float* m, float* P, const float* yv, float u0) {
+    float H[M * N], hx[M], HrRHr[M * M], v[M];
+    emi_linearize<N, M>(mdl, m, u0, H, hx, HrRHr);
+    BF_UNROLL for (int a = 0; a < M; ++a) v[a] = yv[a] - hx[a];
+    return condition_on<N, M>(H, HrRHr, v, m, P);
+  }
+};
+template <int N, int DQ, int M, int DR>
+struct UkfNodes {
+  using Arg = const UkfModel<N, DQ, M, DR>*;  // device-resident
+  static __device__ __forceinline__ void predict(Arg mdl, float* m, float* P, float u0) { ukf_predict(*mdl, m, P, u0); }
+  static __device__ __forceinline__ float condition(Arg mdl, float* m, float* P, const float* yv, float u0) {
+    return ukf_condition_on(*mdl, m, P, yv, u0);
+  }
+};
+
 struct AgsfOut {
   SView w, m, P;
   int* anc;  // [B][T][N0] index of the leaf each carried component was drawn from (NULL = not emitted)
 };
 
-template <int N, int M>
+template <int N, int M, class NODES>
 __global__ void __launch_bounds__(256)
-agsf_scan_kernel(EkfModel<N, M> mdl, CView y, UView uin, CarryView carry, AgsfOut out, long long B, long long T, int N0, int N1,
+agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, AgsfOut out, long long B, long long T, int N0, int N1,
                  int N2, int MP, float a0, float a1, uint32_t key0, uint32_t key1, int variant) {
   constexpr int EP = N * N;
   constexpr int REC = N + EP;  // one component record in LDS: mean, covariance
@@ -138,10 +166,7 @@ agsf_scan_kernel(EkfModel<N, M> mdl, CView y, UView uin, CarryView carry, AgsfOu
         mz[i] = rec[i] + s;       // z = m + chol(P - Delta) eps
         if (variant != 0 && mz[i] != mz[i]) mz[i] = rec[i];  // jnp.where(isnan(new_means), mean, new_means)  containers.py:84
       }
-      float F[EP], fx[N];
-      dyn_linearize<N, M>(mdl, mz, u0, F, fx);
-      predict_cov<N>(F, mdl.GQG, Dl);  // F Delta F^T + F_q Q F_q^T
-      BF_UNROLL for (int i = 0; i < N; ++i) mz[i] = fx[i];
+      NODES::predict(mdl, mz, Dl, u0);  // the node (z, Delta) through the dynamics
       BF_UNROLL for (int i = 0; i < EP; ++i) P[i] = Dl[i];
     }
     // ---- s-sample of the leaf and its update (:711-737)
@@ -160,10 +185,7 @@ agsf_scan_kernel(EkfModel<N, M> mdl, CView y, UView uin, CarryView carry, AgsfOu
         ms[i] = mz[i] + s;
         if (variant != 0 && ms[i] != ms[i]) ms[i] = mz[i];        // containers.py:121
       }
-      float H[M * N], hx[M], HrRHr[M * M], v[M];
-      emi_linearize<N, M>(mdl, ms, u0, H, hx, HrRHr);
-      BF_UNROLL for (int a = 0; a < M; ++a) v[a] = yv[a] - hx[a];
-      ll = condition_on<N, M>(H, HrRHr, v, ms, Lam);
+      ll = NODES::condition(mdl, ms, Lam, yv, u0);  // the leaf (s, Lambda) conditioned on y
       BF_UNROLL for (int i = 0; i < N; ++i) mz[i] = ms[i];
       BF_UNROLL for (int i = 0; i < EP; ++i) P[i] = Lam[i];
     }
@@ -227,14 +249,10 @@ agsf_scan_kernel(EkfModel<N, M> mdl, CView y, UView uin, CarryView carry, AgsfOu
   }
 }
 
-template <int N, int M>
-static inline int launch_agsf(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
-                              const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry,
-                              const bf_out_desc* out, int* d_leaf_idx, int variant, hipStream_t stream) {
-  EkfModel<N, M> e;
-  int rc = fill_model<N, M>(p, e);
-  if (rc != BF_OK) return rc;
-  if (p->flags != 0) return set_error(BF_EUNSUPPORTED, "legacy-class flags do not apply to the augmented filter");
+template <int N, int M, class NODES>
+static inline int launch_agsf_nodes(typename NODES::Arg arg, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
+                                    const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry,
+                                    const bf_out_desc* out, int* d_leaf_idx, int variant, hipStream_t stream) {
   const int Mleaf = nc[0] * nc[1] * nc[2];
   int MP = 1;
   while (MP < Mleaf) MP <<= 1;
@@ -248,13 +266,47 @@ static inline int launch_agsf(const bf_model* p, const bf_cstream* y, const bf_c
   UView uv{u && u->ptr ? u->ptr : nullptr, u ? u->sB : 0, u ? u->sT : 0};
   CarryView cv{carry->w_in, carry->m_in, carry->P_in, carry->w_out, carry->m_out, carry->P_out};
   AgsfOut ov{make_sview(out->weights), make_sview(out->means), make_sview(out->covs), d_leaf_idx};
-  auto kern = agsf_scan_kernel<N, M>;
+  auto kern = agsf_scan_kernel<N, M, NODES>;
   if (lds_bytes > 64 * 1024)
     BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   const int tpb = 256 / MP;
-  hipLaunchKernelGGL(kern, dim3((unsigned)((B + tpb - 1) / tpb)), dim3(256), lds_bytes, stream, e, yv, uv, cv, ov, B, T, nc[0],
+  hipLaunchKernelGGL(kern, dim3((unsigned)((B + tpb - 1) / tpb)), dim3(256), lds_bytes, stream, arg, yv, uv, cv, ov, B, T, nc[0],
                      nc[1], nc[2], MP, opt[0], opt[1], key[0], key[1], variant);
   BF_HIP_CHECK(hipGetLastError());
+  return BF_OK;
+}
+
+template <int N, int M>
+static inline int launch_agsf(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
+                              const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry,
+                              const bf_out_desc* out, int* d_leaf_idx, int variant, hipStream_t stream) {
+  EkfModel<N, M> e;
+  int rc = fill_model<N, M>(p, e);
+  if (rc != BF_OK) return rc;
+  if (p->flags != 0) return set_error(BF_EUNSUPPORTED, "legacy-class flags do not apply to the augmented filter");
+  return launch_agsf_nodes<N, M, EkfNodes<N, M>>(e, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, variant, stream);
+}
+
+// unscented nodes (speedy_unscented_agsf / unscented_agsf, inference.py:966-1156 / 813-965)
+template <int N, int DQ, int M, int DR>
+static inline int launch_uagsf(const bf_model* p, const bf_ukf_params* up, const bf_cstream* y, const bf_cstream* u, long long B,
+                               long long T, const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry,
+                               const bf_out_desc* out, int* d_leaf_idx, int variant, hipStream_t stream) {
+  UkfModel<N, DQ, M, DR> h;
+  int rc = fill_ukf_model<N, DQ, M, DR>(p, up, h);
+  if (rc != BF_OK) return rc;
+  UkfModel<N, DQ, M, DR>* d_mdl = nullptr;
+  BF_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&d_mdl), sizeof(h), stream));
+  hipError_t e = hipMemcpyAsync(d_mdl, &h, sizeof(h), hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);  // h lives on this stack frame
+  if (e != hipSuccess) {
+    (void)hipFreeAsync(d_mdl, stream);
+    BF_HIP_CHECK(e);
+  }
+  rc = launch_agsf_nodes<N, M, UkfNodes<N, DQ, M, DR>>(d_mdl, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, variant, stream);
+  const hipError_t fe = hipFreeAsync(d_mdl, stream);
+  if (rc != BF_OK) return rc;
+  BF_HIP_CHECK(fe);
   return BF_OK;
 }
 

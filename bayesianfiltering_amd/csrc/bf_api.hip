@@ -34,6 +34,9 @@ int launch_ugsf_ukf(const bf_model* p, const bf_ukf_params* up, const bf_cstream
 int launch_agsf_ekf(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, const int32_t nc[3],
                     const uint32_t key[2], const float opt[2], const bf_carry* carry, const bf_out_desc* out, int* d_leaf_idx,
                     int variant, hipStream_t stream);
+int launch_agsf_ukf(const bf_model* p, const bf_ukf_params* up, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
+                    const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry, const bf_out_desc* out,
+                    int* d_leaf_idx, int variant, hipStream_t stream);
 int launch_bpf(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP,
                float ess, int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o,
                hipStream_t stream);
@@ -169,6 +172,24 @@ int bf_agsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream
   if (!y->ptr) return bf::set_error(BF_EINVAL, "observations pointer is NULL");
   if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
   return bf::launch_agsf_ekf(model, y, u, B, T, num_components, key, opt_args, carry, out, leaf_idx, variant,
+                             static_cast<hipStream_t>(stream));
+}
+
+int bf_agsf_ukf_f32(const bf_model* model, const bf_ukf_params* uparams, const bf_cstream* y, const bf_cstream* u, int64_t B,
+                    int64_t T, const int32_t num_components[3], const uint32_t key[2], const float opt_args[2],
+                    const bf_carry* carry, const bf_out_desc* out, int32_t* leaf_idx, int32_t variant, void* stream) {
+  if (variant != 0 && variant != 1) return bf::set_error(BF_EINVAL, "variant must be 0 (speedy) or 1 (container branches)");
+  if (!model || !uparams || !y || !carry || !out || !num_components || !key || !opt_args) return bf::set_error(BF_EINVAL, "NULL argument");
+  if (B <= 0 || T <= 0) return bf::set_error(BF_EINVAL, "B and T must be positive");
+  if (num_components[0] <= 0 || num_components[1] <= 0 || num_components[2] <= 0)
+    return bf::set_error(BF_EINVAL, "num_components must be three positive counts");
+  if (model->n <= 0 || model->m <= 0 || model->dq <= 0 || model->dr <= 0)
+    return bf::set_error(BF_EINVAL, "non-positive model dimension");
+  if (!model->Q || !model->R) return bf::set_error(BF_EINVAL, "Q and R are required");
+  if (!y->ptr) return bf::set_error(BF_EINVAL, "observations pointer is NULL");
+  if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
+  if (!(uparams->alpha > 0.f)) return bf::set_error(BF_EINVAL, "ParamsUKF.alpha must be positive");
+  return bf::launch_agsf_ukf(model, uparams, y, u, B, T, num_components, key, opt_args, carry, out, leaf_idx, variant,
                              static_cast<hipStream_t>(stream));
 }
 

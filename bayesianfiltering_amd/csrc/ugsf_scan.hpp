@@ -133,6 +133,123 @@ __device__ __forceinline__ void ukf_emi(const UkfModel<N, DQ, M, DR>& p, const f
   }
 }
 
+// _ukf_condition_on_nonadditive (inference.py:198-224): m, P <- posterior; returns the log-likelihood
+template <int N, int DQ, int M, int DR>
+__device__ __forceinline__ float ukf_condition_on(const UkfModel<N, DQ, M, DR>& mdl, float* m, float* P, const float* yv, float u0) {
+  constexpr int EP = N * N;
+  float ll;
+
+  float sP[EP];
+  BF_UNROLL for (int i = 0; i < EP; ++i) sP[i] = P[i];
+  sym_sqrt<N>(sP);
+  float h0[M], mu[M];
+  ukf_emi(mdl, m, mdl.r0, u0, h0);
+  // visits the 2 L sigma points in the order of utils.py:251-253: the plus rows, then the minus rows
+  auto for_points = [&](auto&& fn) __attribute__((always_inline)) {
+    BF_UNROLL for (int sg = 0; sg < 2; ++sg) {
+      const float cs = sg == 0 ? mdl.c_u : -mdl.c_u;
+      BF_UNROLL for (int j = 0; j < N; ++j) {
+        float x[N], dx[N], yy[M];
+        BF_UNROLL for (int i = 0; i < N; ++i) {
+          dx[i] = cs * sP[j * N + i];
+          x[i] = m[i] + dx[i];
+        }
+        ukf_emi(mdl, x, mdl.r0, u0, yy);
+        fn(yy, dx, true);
+      }
+      BF_UNROLL for (int j = 0; j < DR; ++j) {
+        float r[DR], dx[N], yy[M];
+        BF_UNROLL for (int i = 0; i < DR; ++i) r[i] = mdl.r0[i] + cs * mdl.sR[j * DR + i];
+        BF_UNROLL for (int i = 0; i < N; ++i) dx[i] = 0.f;
+        ukf_emi(mdl, m, r, u0, yy);
+        fn(yy, dx, false);
+      }
+    }
+  };
+  BF_UNROLL for (int a = 0; a < M; ++a) mu[a] = 0.f;
+  for_points([&](const float* yy, const float*, bool) { BF_UNROLL for (int a = 0; a < M; ++a) mu[a] += yy[a]; });
+  BF_UNROLL for (int a = 0; a < M; ++a) mu[a] = mu[a] * mdl.ws_u + h0[a] * mdl.w0_u;
+  float S[M * M], C[M * N];
+  BF_UNROLL for (int i = 0; i < M * M; ++i) S[i] = 0.f;
+  BF_UNROLL for (int i = 0; i < M * N; ++i) C[i] = 0.f;
+  for_points([&](const float* yy, const float* dx, bool moved) {
+    float dy[M];
+    BF_UNROLL for (int a = 0; a < M; ++a) dy[a] = yy[a] - mu[a];
+    BF_UNROLL for (int a = 0; a < M; ++a) BF_UNROLL for (int c2 = 0; c2 < M; ++c2) S[a * M + c2] = fmaf(dy[a], dy[c2], S[a * M + c2]);
+    if (moved) BF_UNROLL for (int a = 0; a < M; ++a) BF_UNROLL for (int i = 0; i < N; ++i) C[a * N + i] = fmaf(dy[a], dx[i], C[a * N + i]);
+  });
+  float d0[M];
+  BF_UNROLL for (int a = 0; a < M; ++a) d0[a] = h0[a] - mu[a];
+  BF_UNROLL for (int a = 0; a < M; ++a) BF_UNROLL for (int c2 = 0; c2 < M; ++c2)
+      S[a * M + c2] = S[a * M + c2] * mdl.ws_u + mdl.wc_u * (d0[a] * d0[c2]);
+  BF_UNROLL for (int i = 0; i < M * N; ++i) C[i] *= mdl.ws_u;
+  // K = psd_solve(S, C)^T;  P+ = P - K S K^T;  m+ = m + K (y - mu);  ll = MVN(mu, S).log_prob(y)
+  psd_solve<M, N>(S, C);  // C <- (S + 1e-6)^-1 C = K^T
+  float KS[N * M];
+  BF_UNROLL for (int i = 0; i < N; ++i) BF_UNROLL for (int c2 = 0; c2 < M; ++c2) {
+    float s = C[i] * S[c2];
+    BF_UNROLL for (int a = 1; a < M; ++a) s = fmaf(C[a * N + i], S[a * M + c2], s);
+    KS[i * M + c2] = s;
+  }
+  BF_UNROLL for (int i = 0; i < N; ++i) BF_UNROLL for (int j = 0; j < N; ++j) {
+    float s = KS[i * M] * C[j];
+    BF_UNROLL for (int c2 = 1; c2 < M; ++c2) s = fmaf(KS[i * M + c2], C[c2 * N + j], s);
+    P[i * N + j] -= s;
+  }
+  float v[M];
+  BF_UNROLL for (int a = 0; a < M; ++a) v[a] = yv[a] - mu[a];
+  BF_UNROLL for (int i = 0; i < N; ++i) {
+    float s = C[i] * v[0];
+    BF_UNROLL for (int a = 1; a < M; ++a) s = fmaf(C[a * N + i], v[a], s);
+    m[i] += s;
+  }
+  ll = mvn_logpdf_chol<M>(S, v);
+  return ll;
+}
+
+// _ukf_predict_nonadditive (inference.py:146-174): m, P <- predicted mean and covariance
+template <int N, int DQ, int M, int DR>
+__device__ __forceinline__ void ukf_predict(const UkfModel<N, DQ, M, DR>& mdl, float* m, float* P, float u0) {
+  constexpr int EP = N * N;
+
+  float sP[EP];
+  BF_UNROLL for (int i = 0; i < EP; ++i) sP[i] = P[i];
+  sym_sqrt<N>(sP);
+  float f0[N], mu[N];
+  ukf_dyn(mdl, m, mdl.q0, u0, f0);
+  auto for_points = [&](auto&& fn) __attribute__((always_inline)) {
+    BF_UNROLL for (int sg = 0; sg < 2; ++sg) {
+      const float cs = sg == 0 ? mdl.c_p : -mdl.c_p;
+      BF_UNROLL for (int j = 0; j < N; ++j) {
+        float x[N], xx[N];
+        BF_UNROLL for (int i = 0; i < N; ++i) x[i] = m[i] + cs * sP[j * N + i];
+        ukf_dyn(mdl, x, mdl.q0, u0, xx);
+        fn(xx);
+      }
+      BF_UNROLL for (int j = 0; j < DQ; ++j) {
+        float q[DQ], xx[N];
+        BF_UNROLL for (int i = 0; i < DQ; ++i) q[i] = mdl.q0[i] + cs * mdl.sQ[j * DQ + i];
+        ukf_dyn(mdl, m, q, u0, xx);
+        fn(xx);
+      }
+    }
+  };
+  BF_UNROLL for (int i = 0; i < N; ++i) mu[i] = 0.f;
+  for_points([&](const float* xx) { BF_UNROLL for (int i = 0; i < N; ++i) mu[i] += xx[i]; });
+  BF_UNROLL for (int i = 0; i < N; ++i) mu[i] = mu[i] * mdl.ws_p + f0[i] * mdl.w0_p;
+  BF_UNROLL for (int i = 0; i < EP; ++i) P[i] = 0.f;
+  for_points([&](const float* xx) {
+    float d[N];
+    BF_UNROLL for (int i = 0; i < N; ++i) d[i] = xx[i] - mu[i];
+    BF_UNROLL for (int i = 0; i < N; ++i) BF_UNROLL for (int j = 0; j < N; ++j) P[i * N + j] = fmaf(d[i], d[j], P[i * N + j]);
+  });
+  float d0[N];
+  BF_UNROLL for (int i = 0; i < N; ++i) d0[i] = f0[i] - mu[i];
+  BF_UNROLL for (int i = 0; i < N; ++i) BF_UNROLL for (int j = 0; j < N; ++j)
+      P[i * N + j] = P[i * N + j] * mdl.ws_p + mdl.wc_p * (d0[i] * d0[j]);
+  BF_UNROLL for (int i = 0; i < N; ++i) m[i] = mu[i];
+}
+
 template <int N, int DQ, int M, int DR>
 __global__ void __launch_bounds__(256)
 ugsf_scan_kernel(const UkfModel<N, DQ, M, DR>* __restrict__ mdlp, CView y, const float* __restrict__ uptr, long long u_sB,
@@ -179,73 +296,7 @@ ugsf_scan_kernel(const UkfModel<N, DQ, M, DR>* __restrict__ mdlp, CView y, const
     float ll;
 
     // ================= _ukf_condition_on_nonadditive (inference.py:198-224)
-    {
-      float sP[EP];
-      BF_UNROLL for (int i = 0; i < EP; ++i) sP[i] = P[i];
-      sym_sqrt<N>(sP);
-      float h0[M], mu[M];
-      ukf_emi(mdl, m, mdl.r0, u0, h0);
-      // visits the 2 L sigma points in the order of utils.py:251-253: the plus rows, then the minus rows
-      auto for_points = [&](auto&& fn) __attribute__((always_inline)) {
-        BF_UNROLL for (int sg = 0; sg < 2; ++sg) {
-          const float cs = sg == 0 ? mdl.c_u : -mdl.c_u;
-          BF_UNROLL for (int j = 0; j < N; ++j) {
-            float x[N], dx[N], yy[M];
-            BF_UNROLL for (int i = 0; i < N; ++i) {
-              dx[i] = cs * sP[j * N + i];
-              x[i] = m[i] + dx[i];
-            }
-            ukf_emi(mdl, x, mdl.r0, u0, yy);
-            fn(yy, dx, true);
-          }
-          BF_UNROLL for (int j = 0; j < DR; ++j) {
-            float r[DR], dx[N], yy[M];
-            BF_UNROLL for (int i = 0; i < DR; ++i) r[i] = mdl.r0[i] + cs * mdl.sR[j * DR + i];
-            BF_UNROLL for (int i = 0; i < N; ++i) dx[i] = 0.f;
-            ukf_emi(mdl, m, r, u0, yy);
-            fn(yy, dx, false);
-          }
-        }
-      };
-      BF_UNROLL for (int a = 0; a < M; ++a) mu[a] = 0.f;
-      for_points([&](const float* yy, const float*, bool) { BF_UNROLL for (int a = 0; a < M; ++a) mu[a] += yy[a]; });
-      BF_UNROLL for (int a = 0; a < M; ++a) mu[a] = mu[a] * mdl.ws_u + h0[a] * mdl.w0_u;
-      float S[M * M], C[M * N];
-      BF_UNROLL for (int i = 0; i < M * M; ++i) S[i] = 0.f;
-      BF_UNROLL for (int i = 0; i < M * N; ++i) C[i] = 0.f;
-      for_points([&](const float* yy, const float* dx, bool moved) {
-        float dy[M];
-        BF_UNROLL for (int a = 0; a < M; ++a) dy[a] = yy[a] - mu[a];
-        BF_UNROLL for (int a = 0; a < M; ++a) BF_UNROLL for (int c2 = 0; c2 < M; ++c2) S[a * M + c2] = fmaf(dy[a], dy[c2], S[a * M + c2]);
-        if (moved) BF_UNROLL for (int a = 0; a < M; ++a) BF_UNROLL for (int i = 0; i < N; ++i) C[a * N + i] = fmaf(dy[a], dx[i], C[a * N + i]);
-      });
-      float d0[M];
-      BF_UNROLL for (int a = 0; a < M; ++a) d0[a] = h0[a] - mu[a];
-      BF_UNROLL for (int a = 0; a < M; ++a) BF_UNROLL for (int c2 = 0; c2 < M; ++c2)
-          S[a * M + c2] = S[a * M + c2] * mdl.ws_u + mdl.wc_u * (d0[a] * d0[c2]);
-      BF_UNROLL for (int i = 0; i < M * N; ++i) C[i] *= mdl.ws_u;
-      // K = psd_solve(S, C)^T;  P+ = P - K S K^T;  m+ = m + K (y - mu);  ll = MVN(mu, S).log_prob(y)
-      psd_solve<M, N>(S, C);  // C <- (S + 1e-6)^-1 C = K^T
-      float KS[N * M];
-      BF_UNROLL for (int i = 0; i < N; ++i) BF_UNROLL for (int c2 = 0; c2 < M; ++c2) {
-        float s = C[i] * S[c2];
-        BF_UNROLL for (int a = 1; a < M; ++a) s = fmaf(C[a * N + i], S[a * M + c2], s);
-        KS[i * M + c2] = s;
-      }
-      BF_UNROLL for (int i = 0; i < N; ++i) BF_UNROLL for (int j = 0; j < N; ++j) {
-        float s = KS[i * M] * C[j];
-        BF_UNROLL for (int c2 = 1; c2 < M; ++c2) s = fmaf(KS[i * M + c2], C[c2 * N + j], s);
-        P[i * N + j] -= s;
-      }
-      float v[M];
-      BF_UNROLL for (int a = 0; a < M; ++a) v[a] = yv[a] - mu[a];
-      BF_UNROLL for (int i = 0; i < N; ++i) {
-        float s = C[i] * v[0];
-        BF_UNROLL for (int a = 1; a < M; ++a) s = fmaf(C[a * N + i], v[a], s);
-        m[i] += s;
-      }
-      ll = mvn_logpdf_chol<M>(S, v);
-    }
+    ll = ukf_condition_on(mdl, m, P, yv, u0);
 
     // ================= reweight (inference.py:424-427)
     {
@@ -263,44 +314,7 @@ ugsf_scan_kernel(const UkfModel<N, DQ, M, DR>* __restrict__ mdlp, CView y, const
     }
 
     // ================= _ukf_predict_nonadditive (inference.py:146-174)
-    {
-      float sP[EP];
-      BF_UNROLL for (int i = 0; i < EP; ++i) sP[i] = P[i];
-      sym_sqrt<N>(sP);
-      float f0[N], mu[N];
-      ukf_dyn(mdl, m, mdl.q0, u0, f0);
-      auto for_points = [&](auto&& fn) __attribute__((always_inline)) {
-        BF_UNROLL for (int sg = 0; sg < 2; ++sg) {
-          const float cs = sg == 0 ? mdl.c_p : -mdl.c_p;
-          BF_UNROLL for (int j = 0; j < N; ++j) {
-            float x[N], xx[N];
-            BF_UNROLL for (int i = 0; i < N; ++i) x[i] = m[i] + cs * sP[j * N + i];
-            ukf_dyn(mdl, x, mdl.q0, u0, xx);
-            fn(xx);
-          }
-          BF_UNROLL for (int j = 0; j < DQ; ++j) {
-            float q[DQ], xx[N];
-            BF_UNROLL for (int i = 0; i < DQ; ++i) q[i] = mdl.q0[i] + cs * mdl.sQ[j * DQ + i];
-            ukf_dyn(mdl, m, q, u0, xx);
-            fn(xx);
-          }
-        }
-      };
-      BF_UNROLL for (int i = 0; i < N; ++i) mu[i] = 0.f;
-      for_points([&](const float* xx) { BF_UNROLL for (int i = 0; i < N; ++i) mu[i] += xx[i]; });
-      BF_UNROLL for (int i = 0; i < N; ++i) mu[i] = mu[i] * mdl.ws_p + f0[i] * mdl.w0_p;
-      BF_UNROLL for (int i = 0; i < EP; ++i) P[i] = 0.f;
-      for_points([&](const float* xx) {
-        float d[N];
-        BF_UNROLL for (int i = 0; i < N; ++i) d[i] = xx[i] - mu[i];
-        BF_UNROLL for (int i = 0; i < N; ++i) BF_UNROLL for (int j = 0; j < N; ++j) P[i * N + j] = fmaf(d[i], d[j], P[i * N + j]);
-      });
-      float d0[N];
-      BF_UNROLL for (int i = 0; i < N; ++i) d0[i] = f0[i] - mu[i];
-      BF_UNROLL for (int i = 0; i < N; ++i) BF_UNROLL for (int j = 0; j < N; ++j)
-          P[i * N + j] = P[i * N + j] * mdl.ws_p + mdl.wc_p * (d0[i] * d0[j]);
-      BF_UNROLL for (int i = 0; i < N; ++i) m[i] = mu[i];
-    }
+    ukf_predict(mdl, m, P, u0);
     if (chain_ok) {
       if (out.pm.p) BF_UNROLL for (int i = 0; i < N; ++i) out.pm.p[b * out.pm.sB + k * out.pm.sK + t * out.pm.sT + i * out.pm.sE] = m[i];
       if (out.pP.p) BF_UNROLL for (int i = 0; i < EP; ++i) out.pP.p[b * out.pP.sB + k * out.pP.sK + t * out.pP.sT + i * out.pP.sE] = P[i];

@@ -435,7 +435,7 @@ def unscented_gaussian_sum_filter(params, uparams, emissions, num_components: in
 def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_key=None, num_iter: int = 1,
                                          opt_args=(0.1, 0.1), inputs=None, *, initial_means=None,
                                          initial_covariances=None, carry=None, return_carry: bool = False,
-                                         return_leaf_indices: bool = False, device="cuda", _variant=0):
+                                         return_leaf_indices: bool = False, device="cuda", _variant=0, _uparams=None):
     """"Speedy" augmented Gaussian-sum filter, gaussfiltax/inference.py:621-812, on the HIP engine.
 
     Same positional signature as the reference: ``num_components = (N0, N1, N2)``, ``rng_key`` defaults to
@@ -508,9 +508,16 @@ def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_
     opt = np.ascontiguousarray(np.asarray(opt_args, dtype=F32).reshape(2))
     leaf = torch.empty((B, T, N0), dtype=torch.int32, device=y.device) if return_leaf_indices else None
     stream = torch.cuda.current_stream(y.device).cuda_stream
-    _lib.check(lib.bf_agsf_ekf_f32(C.byref(mdl.c), C.byref(yd), C.byref(ud), B, T, nc.ctypes.data_as(C.POINTER(C.c_int32)),
-                                   key.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(opt), C.byref(cr), C.byref(od),
-                                   C.c_void_p(leaf.data_ptr() if leaf is not None else None), int(_variant), C.c_void_p(stream)))
+    leaf_ptr = C.c_void_p(leaf.data_ptr() if leaf is not None else None)
+    if _uparams is None:
+        _lib.check(lib.bf_agsf_ekf_f32(C.byref(mdl.c), C.byref(yd), C.byref(ud), B, T, nc.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       key.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(opt), C.byref(cr), C.byref(od),
+                                       leaf_ptr, int(_variant), C.c_void_p(stream)))
+    else:
+        up = _lib.bf_ukf_params(float(_uparams.alpha), float(_uparams.beta), float(_uparams.kappa))
+        _lib.check(lib.bf_agsf_ukf_f32(C.byref(mdl.c), C.byref(up), C.byref(yd), C.byref(ud), B, T,
+                                       nc.ctypes.data_as(C.POINTER(C.c_int32)), key.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                       _fp(opt), C.byref(cr), C.byref(od), leaf_ptr, int(_variant), C.c_void_p(stream)))
     post = PosteriorGaussianSumFiltered(**{k: (v[0] if (squeeze and v is not None) else v) for k, v in bufs.items()})
     aux = {}
     if return_leaf_indices:
@@ -530,6 +537,27 @@ def augmented_gaussian_sum_filter(params, emissions, num_components, rng_key=Non
     Same arguments, return value and keyword extensions as the speedy variant."""
     return speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_key, num_iter, opt_args, inputs,
                                                 _variant=1, **kwargs)
+
+
+def speedy_unscented_agsf(params, uparams, emissions, num_components, rng_key=None, num_iter: int = 1, opt_args=(0.1, 0.1),
+                          inputs=None, **kwargs):
+    """Augmented Gaussian-sum filter with unscented nodes, gaussfiltax/inference.py:966-1156, on the HIP engine:
+    :func:`speedy_augmented_gaussian_sum_filter` with ``_ukf_predict_nonadditive`` / ``_ukf_condition_on_nonadditive``
+    at the tree nodes.  Same positional signature as the reference (``uparams``: :class:`ParamsUKF`)."""
+    if not isinstance(uparams, ParamsUKF):
+        uparams = ParamsUKF(*uparams)
+    return speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_key, num_iter, opt_args, inputs,
+                                                _uparams=uparams, **kwargs)
+
+
+def unscented_agsf(params, uparams, emissions, num_components, rng_key=None, num_iter: int = 1, opt_args=(0.1, 0.1), inputs=None,
+                   **kwargs):
+    """gaussfiltax/inference.py:813-965: the unscented augmented filter with the container-based branches of
+    :func:`augmented_gaussian_sum_filter`."""
+    if not isinstance(uparams, ParamsUKF):
+        uparams = ParamsUKF(*uparams)
+    return speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_key, num_iter, opt_args, inputs,
+                                                _variant=1, _uparams=uparams, **kwargs)
 
 
 class ParticleCarry(NamedTuple):

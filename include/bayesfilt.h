@@ -190,6 +190,13 @@ int bf_agsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream
                     const int32_t num_components[3], const uint32_t key[2], const float opt_args[2], const bf_carry* carry,
                     const bf_out_desc* out, int32_t* leaf_idx, int32_t variant, void* stream);
 
+/* The augmented filter with unscented nodes: replaces the lax.scan of speedy_unscented_agsf
+ * (inference.py:966-1156; variant 0) and unscented_agsf (:813-965; variant 1) -- the tree, sampling and
+ * resampling of bf_agsf_ekf_f32 with _ukf_predict_nonadditive / _ukf_condition_on_nonadditive at the nodes. */
+int bf_agsf_ukf_f32(const bf_model* model, const bf_ukf_params* uparams, const bf_cstream* y, const bf_cstream* u, int64_t B,
+                    int64_t T, const int32_t num_components[3], const uint32_t key[2], const float opt_args[2],
+                    const bf_carry* carry, const bf_out_desc* out, int32_t* leaf_idx, int32_t variant, void* stream);
+
 /* Moment-matching collapse of the mixture posterior per (trajectory, step): gaussfiltax/utils.py:10-18
  * and the point estimate sum_k w_k m_k (docs/experiments/BOT_Experiment_script.py:101).  weights /
  * means / covs are the strided streams a filter emitted (covs may be NULL when cov_out is NULL);

@@ -16,6 +16,7 @@ Follows, line by line (paths relative to /root/reference):
   _get_sigma_points         gaussfiltax/utils.py:247-254
   speedy_augmented_gaussian_sum_filter   gaussfiltax/inference.py:621-812
   augmented_gaussian_sum_filter          gaussfiltax/inference.py:458-620 + containers.py:63-140
+  speedy_unscented_agsf / unscented_agsf gaussfiltax/inference.py:966-1156 / 813-965
 
 Quirks reproduced on purpose: update->reweight->predict order; psd_solve adds
 1e-6 to EVERY entry of S and uses LU (sgesv); posterior covariance P - K S K^T with the
@@ -375,7 +376,8 @@ def unscented_gaussian_sum_filter(params, uparams, emissions, num_components=1, 
 
 # --------------------------------------------------------------------------- augmented GSF (speedy variant)
 def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_key=None, num_iter=1,
-                                         opt_args=(0.1, 0.1), inputs=None, initial_means=None, debug=False, variant=0):
+                                         opt_args=(0.1, 0.1), inputs=None, initial_means=None, debug=False, variant=0,
+                                         uparams=None):
     """inference.py:621-812.  Every step branches each of the N0 carried components into N1 z-samples
     (drawn from N(m, P - Delta), Delta = opt_args[0] P, :675-688), predicts each with covariance Delta
     (:695-698), branches every prediction into N2 s-samples (N(m-, P- - Lambda), Lambda = opt_args[1] P-,
@@ -433,7 +435,10 @@ def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_
                 z = (fmeans[i0] + zc[:, i1]).astype(F32)
                 if variant:
                     z = np.where(np.isnan(z), fmeans[i0], z).astype(F32)                     # containers.py:84
-                pm[i0 * N1 + i1], pP[i0 * N1 + i1], _ = _predict(z, Delta, fn, Q, q0, u)
+                if uparams is None:
+                    pm[i0 * N1 + i1], pP[i0 * N1 + i1], _ = _predict(z, Delta, fn, Q, q0, u)
+                else:    # speedy_unscented_agsf :1034-1035
+                    pm[i0 * N1 + i1], pP[i0 * N1 + i1] = _ukf_predict_nonadditive(z, Delta, fn, u, Q, uparams, q0)
         lls = np.empty(M, F32)
         um = np.empty((M, n), F32)
         uP = np.empty((M, n, n), F32)
@@ -445,7 +450,10 @@ def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_
                 sv = (pm[j] + sc[:, i2]).astype(F32)
                 if variant:
                     sv = np.where(np.isnan(sv), pm[j], sv).astype(F32)                        # containers.py:121
-                lls[j * N2 + i2], um[j * N2 + i2], uP[j * N2 + i2], _, _ = _condition_on(sv, Lam, hn, R, r0, u, y)
+                if uparams is None:
+                    lls[j * N2 + i2], um[j * N2 + i2], uP[j * N2 + i2], _, _ = _condition_on(sv, Lam, hn, R, r0, u, y)
+                else:    # :1075-1076
+                    lls[j * N2 + i2], um[j * N2 + i2], uP[j * N2 + i2] = _ukf_condition_on_nonadditive(sv, Lam, hn, R, u, y, uparams, r0)
         pw = (np.repeat(weights, N1) / F32(N1)).astype(F32)          # :699
         uw = (np.repeat(pw, N2) / F32(N2)).astype(F32)               # :738
         w = reweight(lls, uw)                                         # :740-743
@@ -468,6 +476,20 @@ def augmented_gaussian_sum_filter(params, emissions, num_components, rng_key=Non
     """inference.py:458-620: the speedy filter's tree with container-based branches (see ``variant`` above)."""
     return speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_key, num_iter, opt_args, inputs,
                                                 initial_means, debug, variant=1)
+
+
+def speedy_unscented_agsf(params, uparams, emissions, num_components, rng_key=None, num_iter=1, opt_args=(0.1, 0.1),
+                          inputs=None, initial_means=None, debug=False):
+    """inference.py:966-1156: the speedy augmented filter with unscented nodes."""
+    return speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_key, num_iter, opt_args, inputs,
+                                                initial_means, debug, variant=0, uparams=uparams)
+
+
+def unscented_agsf(params, uparams, emissions, num_components, rng_key=None, num_iter=1, opt_args=(0.1, 0.1),
+                   inputs=None, initial_means=None, debug=False):
+    """inference.py:813-965: unscented nodes, container-based branches."""
+    return speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_key, num_iter, opt_args, inputs,
+                                                initial_means, debug, variant=1, uparams=uparams)
 
 
 def collapse(mean_mat, covariance_tens, weight_vec):

@@ -124,3 +124,24 @@ def test_container_branch_variant(nc):
     # and it is a different stream from the speedy variant
     sp, _ = bfa.speedy_augmented_gaussian_sum_filter(pp, ys, nc, key, initial_means=init)
     assert not np.allclose(sp.means.cpu().numpy(), post.means.cpu().numpy())
+
+
+@pytest.mark.parametrize("which", ["speedy_unscented_agsf", "unscented_agsf"])
+def test_unscented_nodes(which):
+    """speedy_unscented_agsf (inference.py:966-1156) and unscented_agsf (:813-965): the same trees with
+    _ukf_predict_nonadditive / _ukf_condition_on_nonadditive at the nodes, on the manoeuvring-target model."""
+    bfa, nl = _nl()
+    T, nc = 18, (2, 5, 5)
+    mu0 = np.array([2.0, 0.3, 3.0, -0.2], F32)
+    S0 = np.diag([0.1, 0.005, 0.1, 0.01]).astype(F32)
+    Q, R = 1e-3 * np.eye(2, dtype=F32), np.diag([1e-3, 1e-2]).astype(F32)
+    inputs = np.array([1] * 6 + [0] * 6 + [2] * 6, F32)
+    po = go.ParamsNLSSM(mu0, S0, om.ManeuverBOT(), np.zeros(2, F32), Q, om.BearingRange(), np.zeros(2, F32), R)
+    pp = bfa.ParamsNLSSM(mu0, S0, nl.maneuver_bot(), np.zeros(2, F32), Q, nl.bearing_range(), np.zeros(2, F32), R)
+    ys = go.sample_ssm(po, otf.PRNGKey(4), T, inputs.reshape(T, 1))[1]
+    init = (mu0 + 0.05 * np.random.default_rng(2).normal(size=(nc[0], 4))).astype(F32)
+    ref, raux = getattr(go, which)(po, go.ParamsUKF(1, 0, 0), ys, nc, otf.PRNGKey(3), 1, (0.1, 0.1), inputs.reshape(T, 1),
+                                   initial_means=init, debug=True)
+    post, aux = getattr(bfa, which)(pp, bfa.ParamsUKF(1, 0, 0), ys, nc, otf.PRNGKey(3), 1, (0.1, 0.1), inputs,
+                                    initial_means=init, return_leaf_indices=True)
+    _compare(post, aux, ref, _oracle_leaf_indices(raux["pre_weights"], nc[0]), tol=3e-5)

@@ -7,8 +7,8 @@ and -- the assertion the reference lacks -- agree with the NumPy oracle.  The re
 noise R = 25e-6 makes S = H P H^T + R so small that psd_solve's +1e-6 jitter dominates it and
 fp32 parity is lost within a few steps (the reference's own GSF returns NaN on this problem,
 BOTExperiment.ipynb cell 7); the parity half of each test therefore uses R = 1e-2, the shape / finiteness
-half uses the reference's value.  Not run: augmented_gaussian_sum_filter_optimal, speedy_unscented_agsf
-(not built)."""
+half uses the reference's value.  Not run: augmented_gaussian_sum_filter_optimal (optimal_resampling is
+not built)."""
 import numpy as np
 import pytest
 
@@ -107,6 +107,26 @@ def test_unscented_gaussian_sum_filter():                                # :94-9
     ref = go.unscented_gaussian_sum_filter(po, go.ParamsUKF(1, 0, 0), ys, 5, initial_means=im, inputs=INPUTS.reshape(T, 1))
     post = bfa.unscented_gaussian_sum_filter(pp, bfa.ParamsUKF(1, 0, 0), ys, 5, 1, INPUTS)
     for k in ("means", "covariances", "predicted_means", "predicted_covariances"):
+        assert cm.rel_err(getattr(post, k).cpu().numpy(), getattr(ref, k)) < 5e-5, k
+
+
+def test_unscented_agsf():                                               # :100-104
+    bfa, po, pp = _params(25e-6)
+    ys = _data(bfa, pp)
+    # ParamsUKF(alpha=1e-3, beta=2, kappa=0) as in the reference: must run and keep the shapes (see above)
+    post, aux = bfa.speedy_unscented_agsf(pp, bfa.ParamsUKF(alpha=1e-3, beta=2.0, kappa=0.0), ys, [2, 5, 5],
+                                          opt_args=(0.1, 0.1), inputs=INPUTS)
+    _finite_shapes(post, 2)
+    bfa, po, pp = _params(1e-2)
+    ys = _data(bfa, pp).cpu().numpy()
+    ref, raux = go.speedy_unscented_agsf(po, go.ParamsUKF(1, 0, 0), ys, [2, 5, 5], opt_args=(0.1, 0.1),
+                                         inputs=INPUTS.reshape(T, 1), debug=True)
+    post, aux = bfa.speedy_unscented_agsf(pp, bfa.ParamsUKF(1, 0, 0), ys, [2, 5, 5], opt_args=(0.1, 0.1), inputs=INPUTS,
+                                          return_leaf_indices=True)
+    idx = np.stack([np.minimum(otf.choice_indices(otf.cumsum_assoc(w), otf.uniform(otf.PRNGKey(0), 2)), 49)
+                    for w in raux["pre_weights"]])
+    assert np.array_equal(aux["leaf_indices"].cpu().numpy(), idx)
+    for k in ("means", "covariances"):
         assert cm.rel_err(getattr(post, k).cpu().numpy(), getattr(ref, k)) < 5e-5, k
 
 
