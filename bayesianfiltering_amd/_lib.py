@@ -94,6 +94,8 @@ SYMBOLS = {
     "bf_agsf_ukf_f32": (C.c_int, [C.POINTER(bf_model), C.POINTER(bf_ukf_params), C.POINTER(bf_cstream), C.POINTER(bf_cstream),
                                   C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), _FP, C.POINTER(bf_carry),
                                   C.POINTER(bf_out_desc), C.c_void_p, C.c_int32, C.c_void_p]),
+    "bf_optimal_resample_f32": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
     "bf_collapse_f32": (C.c_int, [C.POINTER(bf_stream), C.POINTER(bf_stream), C.POINTER(bf_stream), C.c_int64, C.c_int64,
                                   C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bf_bpf_f32": (C.c_int, [C.POINTER(bf_bpf_model), C.POINTER(bf_cstream), C.POINTER(bf_cstream), C.c_int64, C.c_int64,

@@ -20,6 +20,37 @@ int launch_agsf_ekf(const bf_model* p, const bf_cstream* y, const bf_cstream* u,
   return set_error(BF_EUNSUPPORTED, "augmented Gaussian-sum filter: (n=%d, m=%d) is not compiled in", p->n, p->m);
 }
 
+// stand-alone utils.optimal_resampling (utils.py:216-244): one trajectory per MP-lane segment
+__global__ void __launch_bounds__(256)
+optimal_resample_kernel(const float* __restrict__ w, long long B, int M, int MP, int N, uint32_t k0, uint32_t k1,
+                        int* __restrict__ idx, float* __restrict__ wout) {
+  const int tid = threadIdx.x;
+  const int l = tid % MP;
+  const long long b_raw = (long long)blockIdx.x * (256 / MP) + tid / MP;
+  const long long b = b_raw < B ? b_raw : B - 1;
+  const float wl = l < M ? w[b * M + l] : 0.f;
+  int io;
+  float wo;
+  optimal_resampling_lanes(wl, l, MP, M, N, k0, k1, io, wo);
+  if (b_raw < B && l < N) {
+    idx[b * N + l] = io;
+    wout[b * N + l] = wo;
+  }
+}
+
+int launch_optimal_resample(const float* d_w, const uint32_t key[2], long long B, int M, int N, int* d_idx, float* d_wout,
+                            hipStream_t stream) {
+  int MP = 1;
+  while (MP < M) MP <<= 1;
+  if (MP > 64) return set_error(BF_EUNSUPPORTED, "optimal resampling: %d weights exceed one wave (64)", M);
+  if (N < 1 || N > M) return set_error(BF_EINVAL, "optimal resampling: need 1 <= N <= M");
+  const int tpb = 256 / MP;
+  hipLaunchKernelGGL(optimal_resample_kernel, dim3((unsigned)((B + tpb - 1) / tpb)), dim3(256), 0, stream, d_w, B, M, MP, N, key[0],
+                     key[1], d_idx, d_wout);
+  BF_HIP_CHECK(hipGetLastError());
+  return BF_OK;
+}
+
 int launch_agsf_ukf(const bf_model* p, const bf_ukf_params* up, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
                     const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry, const bf_out_desc* out,
                     int* d_leaf_idx, int variant, hipStream_t stream) {

@@ -47,6 +47,90 @@ __device__ __forceinline__ void chol_lower(const float* A, float* L) {
   }
 }
 
+// optimal_resampling of Fearnhead & Clifford as written in gaussfiltax/utils.py:216-244, for the M <= 64 weights
+// held one per lane by the MP = next_pow2(M) lanes of a trajectory (lane l: w, 0 beyond M).  Returns, in lanes
+// j < N, the index of the particle that becomes output j and its normalised weight.
+//   sorted_weights, sorted_idx = sort / argsort(weights)            stable: bitonic network on (w, index) pairs
+//   ps[i] = cumsum(sorted_weights)[M-N+i] / (i+1), flipped; L, p     (:226-232; running sums in index order)
+//   res_idx = jr.choice(key, M, (M,), p = normalised weights below p) (:235-237; CDF in associative_scan order)
+//   final_idx / final_weights, last N entries                        (:240-243)
+__device__ __forceinline__ void optimal_resampling_lanes(float w, int l, int MP, int M, int N, uint32_t k0, uint32_t k1,
+                                                         int& idx_out, float& w_out) {
+  const int lane = threadIdx.x & 63;
+  const int seg0 = lane - l;  // first lane of the trajectory's segment
+  // ---- stable ascending sort of (w, l); padding lanes carry +inf and end up beyond M
+  float sv = l < M ? w : __builtin_inff();
+  int si = l;
+  for (int k = 2; k <= MP; k <<= 1)
+    for (int j = k >> 1; j >= 1; j >>= 1) {
+      const float ov = __shfl_xor(sv, j, 64);
+      const int oi = __shfl_xor(si, j, 64);
+      const bool up = (l & k) == 0;         // ascending block
+      const bool lower = (l & j) == 0;      // this lane keeps the smaller of the pair in an ascending block
+      const bool other_less = (ov < sv) || (ov == sv && oi < si);
+      const bool take = (lower == up) ? other_less : !other_less;
+      sv = take ? ov : sv;
+      si = take ? oi : si;
+    }
+  // ---- running sums of the sorted weights in index order: cum[s] = ((sw0 + sw1) + ...) + sw_s
+  float cum = 0.f;
+  for (int c = 0; c < M; ++c) {
+    const float vc = __shfl(sv, seg0 + c, 64);
+    cum = (c <= l) ? cum + vc : cum;
+  }
+  // ---- threshold: lane s <-> ind = M - 1 - s in [1, N - 1]; ps = cum[s] / (N - ind); bounds (sw[s], sw[s + 1])
+  const int ind = M - 1 - l;
+  const float sw_next = __shfl_down(sv, 1, 64);
+  const bool cand = ind >= 1 && ind <= N - 1 && l < M;
+  const float psv = cum / (float)(N - ind);
+  const bool pred = cand && (sv < psv) && (psv < sw_next);
+  int Lsum = pred ? ind : 0;
+  for (int off = 1; off < MP; off <<= 1) Lsum += __shfl_xor(Lsum, off, 64);
+  const int Ll = Lsum >= 1 && Lsum <= N - 1 ? Lsum : 1;
+  const float p_at = __shfl(psv, seg0 + (M - 1 - Ll), 64);
+  const float p = Lsum == 0 ? 1.0f / (float)N : p_at;
+  // ---- resample among the weights below p
+  const bool below = l < M && sv < p;
+  float rw = below ? sv : 0.f;
+  float tot = rw;
+  for (int off = 1; off < MP; off <<= 1) tot += __shfl_xor(tot, off, 64);   // adjacent-pair tree
+  rw = rw / tot;
+  float c = rw;                                                              // cumsum, lax.associative_scan order
+  for (int d = 0; (1 << d) < MP; ++d) {
+    const float o = __shfl_up(c, 1 << d, 64);
+    if (((l + 1) & ((2 << d) - 1)) == 0) c += o;
+  }
+  for (int d = 5; d >= 1; --d)
+    if ((1 << d) <= MP) {
+      const float o = __shfl_up(c, 1 << (d - 1), 64);
+      if (l >= (1 << d) && ((l + 1) & ((1 << d) - 1)) == (1 << (d - 1))) c += o;
+    }
+  const float ctot = __shfl(c, seg0 + M - 1, 64);
+  const float u = bits_to_unit(threefry_bits(k0, k1, (uint32_t)(l < M ? l : 0), (uint32_t)M));
+  const float r = ctot * (1.0f - u);
+  int lo = 0, hi = M;  // first index with cdf[idx] >= r: every lane walks the same bounded search on shuffled values
+  for (int it = 0; it < 7; ++it) {
+    const int mid = (lo + hi) >> 1;
+    const float cm = __shfl(c, seg0 + (mid < M ? mid : M - 1), 64);
+    const bool go = lo < hi;
+    if (go && cm < r) lo = mid + 1;
+    else if (go) hi = mid;
+  }
+  // (no weight below p: 0 / 0 weights, a NaN draw -- every comparison of the search fails and the clamped result
+  // is the last index)
+  const int ridx = (r != r) ? M - 1 : (lo < M - 1 ? lo : M - 1);
+  const int unsort = __shfl(si, seg0 + ridx, 64);
+  const int fidx = below ? unsort : si;
+  const float fw = below ? p : sv;
+  // ---- the last N sorted positions are the output
+  const bool top = l >= M - N && l < M;
+  float ftot = top ? fw : 0.f;
+  for (int off = 1; off < MP; off <<= 1) ftot += __shfl_xor(ftot, off, 64);
+  const int srcl = M - N + (l < N ? l : 0);
+  idx_out = __shfl(fidx, seg0 + srcl, 64);
+  w_out = __shfl(fw, seg0 + srcl, 64) / ftot;
+}
+
 // What a tree node does with its Gaussian: the extended-Kalman pair _predict / _condition_on
 // (inference.py:51-105) or the unscented pair (:146-174, :198-224) of speedy_unscented_agsf (:966-1156).
 template <int N, int M>
@@ -101,6 +185,7 @@ agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, A
   float* leafbuf = lds;                          // [256][REC]   updated mean / covariance of every leaf
   float* carrybuf = lds + 256 * REC;             // [256][REC]   carried components, slot-major: [slot * MP + i0]
   float* cdfbuf = carrybuf + 256 * REC;          // [256]        cumulative leaf weights
+  float* wbuf = cdfbuf + 256;                    // [256]        weights of the carried components (variant 2)
 
   // ---- the two standard-normal vectors of this leaf (same at every step: the reference's key is never advanced)
   float ez[N], es[N];
@@ -136,6 +221,7 @@ agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, A
     BF_UNROLL for (int i = 0; i < EP; ++i) rec[N + i] = carry.P_in[(b * N0 + l) * EP + i];
   }
   float wpar = carry.w_in ? carry.w_in[b * N0 + i0] : 1.0f / (float)N0;  // weight of the parent component
+  float wmine = (l < N0) ? (carry.w_in ? carry.w_in[b * N0 + l] : 1.0f / (float)N0) : 0.f;  // of component l (carry out)
   lds_barrier();
 
   auto seg_reduce = [&](float v, auto op) {  // over the MP lanes of the trajectory, adjacent-pair tree
@@ -217,7 +303,15 @@ agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, A
       BF_UNROLL for (int i = 0; i < EP; ++i) rec[N + i] = P[i];
     }
     lds_barrier();
-    if (l < N0) {
+    int idx = 0;
+    float wnew = 1.0f / (float)N0;  // weights = ones / N0                                          :765
+    if (variant == 2) {
+      // augmented_gaussian_sum_filter_optimal (:1157-1300): utils.optimal_resampling(weights, N0, key) with the
+      // key left by the two splits (:1203, :1229); the drawn components keep unequal weights
+      const U32x2 kz = threefry_split(key0, key1, 0u, 2u);
+      const U32x2 ko = threefry_split(kz.x, kz.y, 0u, 2u);
+      optimal_resampling_lanes(w, l, MP, Mleaf, N0, ko.x, ko.y, idx, wnew);
+    } else if (l < N0) {
       const float* cd = cdfbuf + slot * MP;
       const float r = cd[Mleaf - 1] * (1.0f - udraw);
       int lo = 0, hi = Mleaf;  // first index with cdf[idx] >= r (searchsorted side='left')
@@ -225,27 +319,31 @@ agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, A
         const int mid = (lo + hi) >> 1;
         if (cd[mid] < r) lo = mid + 1; else hi = mid;
       }
-      const int idx = lo < Mleaf - 1 ? lo : Mleaf - 1;
+      idx = lo < Mleaf - 1 ? lo : Mleaf - 1;
+    }
+    if (l < N0) {
       const float* src = leafbuf + (slot * MP + idx) * REC;
       float* dst = carrybuf + (slot * MP + l) * REC;
       // drawn leaf -> component l of the next carry, and out
       BF_UNROLL for (int i = 0; i < REC; ++i) dst[i] = src[i];
+      wbuf[slot * MP + l] = wnew;
+      wmine = wnew;
       if (traj_ok) {
         if (out.m.p) BF_UNROLL for (int i = 0; i < N; ++i) out.m.p[b * out.m.sB + l * out.m.sK + t * out.m.sT + i * out.m.sE] = src[i];
         if (out.P.p) BF_UNROLL for (int i = 0; i < EP; ++i) out.P.p[b * out.P.sB + l * out.P.sK + t * out.P.sT + i * out.P.sE] = src[N + i];
-        if (out.w.p) out.w.p[b * out.w.sB + l * out.w.sK + t * out.w.sT] = 1.0f / (float)N0;
+        if (out.w.p) out.w.p[b * out.w.sB + l * out.w.sK + t * out.w.sT] = wnew;
         if (out.anc) out.anc[(b * T + t) * N0 + l] = idx;
       }
     }
-    wpar = 1.0f / (float)N0;  // weights = ones / N0                                                :765
     lds_barrier();
+    wpar = wbuf[slot * MP + i0];
   }
 
   if (traj_ok && l < N0) {
     const float* rec = carrybuf + (slot * MP + l) * REC;
     if (carry.m_out) BF_UNROLL for (int i = 0; i < N; ++i) carry.m_out[(b * N0 + l) * N + i] = rec[i];
     if (carry.P_out) BF_UNROLL for (int i = 0; i < EP; ++i) carry.P_out[(b * N0 + l) * EP + i] = rec[N + i];
-    if (carry.w_out) carry.w_out[b * N0 + l] = 1.0f / (float)N0;
+    if (carry.w_out) carry.w_out[b * N0 + l] = wmine;
   }
 }
 
@@ -260,7 +358,7 @@ static inline int launch_agsf_nodes(typename NODES::Arg arg, const bf_cstream* y
   if (out->pred_means.ptr || out->pred_covs.ptr || out->coll_mean.ptr || out->coll_cov.ptr || out->loglik.ptr)
     return set_error(BF_EINVAL, "the augmented filter emits weights, means and covariances only (inference.py:771-775)");
   constexpr int REC = N + N * N;
-  const size_t lds_bytes = sizeof(float) * (size_t)(2 * 256 * REC + 256);
+  const size_t lds_bytes = sizeof(float) * (size_t)(2 * 256 * REC + 512);
   if (lds_bytes > 160 * 1024) return set_error(BF_EUNSUPPORTED, "component records exceed the 160 KiB LDS");
   CView yv{y->ptr, y->sB, y->sT, y->sE};
   UView uv{u && u->ptr ? u->ptr : nullptr, u ? u->sB : 0, u ? u->sT : 0};

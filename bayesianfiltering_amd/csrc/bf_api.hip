@@ -37,6 +37,8 @@ int launch_agsf_ekf(const bf_model* p, const bf_cstream* y, const bf_cstream* u,
 int launch_agsf_ukf(const bf_model* p, const bf_ukf_params* up, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
                     const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry, const bf_out_desc* out,
                     int* d_leaf_idx, int variant, hipStream_t stream);
+int launch_optimal_resample(const float* d_w, const uint32_t key[2], long long B, int M, int N, int* d_idx, float* d_wout,
+                            hipStream_t stream);
 int launch_bpf(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP,
                float ess, int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o,
                hipStream_t stream);
@@ -160,7 +162,8 @@ int bf_ugsf_ukf_f32(const bf_model* model, const bf_ukf_params* uparams, const b
 int bf_agsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream* u, int64_t B, int64_t T,
                     const int32_t num_components[3], const uint32_t key[2], const float opt_args[2], const bf_carry* carry,
                     const bf_out_desc* out, int32_t* leaf_idx, int32_t variant, void* stream) {
-  if (variant != 0 && variant != 1) return bf::set_error(BF_EINVAL, "variant must be 0 (speedy) or 1 (container branches)");
+  if (variant < 0 || variant > 2)
+    return bf::set_error(BF_EINVAL, "variant must be 0 (speedy), 1 (container branches) or 2 (container branches + optimal resampling)");
   if (!model || !y || !carry || !out || !num_components || !key || !opt_args) return bf::set_error(BF_EINVAL, "NULL argument");
   if (B <= 0 || T <= 0) return bf::set_error(BF_EINVAL, "B and T must be positive");
   if (num_components[0] <= 0 || num_components[1] <= 0 || num_components[2] <= 0)
@@ -191,6 +194,13 @@ int bf_agsf_ukf_f32(const bf_model* model, const bf_ukf_params* uparams, const b
   if (!(uparams->alpha > 0.f)) return bf::set_error(BF_EINVAL, "ParamsUKF.alpha must be positive");
   return bf::launch_agsf_ukf(model, uparams, y, u, B, T, num_components, key, opt_args, carry, out, leaf_idx, variant,
                              static_cast<hipStream_t>(stream));
+}
+
+int bf_optimal_resample_f32(const float* d_weights, const uint32_t key[2], int64_t B, int32_t M, int32_t N, int32_t* d_idx,
+                            float* d_weights_out, void* stream) {
+  if (!d_weights || !key || !d_idx || !d_weights_out) return bf::set_error(BF_EINVAL, "NULL argument");
+  if (B <= 0 || M <= 0) return bf::set_error(BF_EINVAL, "B and M must be positive");
+  return bf::launch_optimal_resample(d_weights, key, B, M, N, d_idx, d_weights_out, static_cast<hipStream_t>(stream));
 }
 
 int bf_collapse_f32(const bf_stream* weights, const bf_stream* means, const bf_stream* covs, int64_t B, int64_t T,

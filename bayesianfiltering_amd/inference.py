@@ -560,6 +560,35 @@ def unscented_agsf(params, uparams, emissions, num_components, rng_key=None, num
                                                 _variant=1, _uparams=uparams, **kwargs)
 
 
+def augmented_gaussian_sum_filter_optimal(params, emissions, num_components, rng_key=None, num_iter: int = 1,
+                                          opt_args=(0.1, 0.1), inputs=None, **kwargs):
+    """gaussfiltax/inference.py:1157-1300 on the HIP engine: :func:`augmented_gaussian_sum_filter` with
+    ``utils.optimal_resampling`` (utils.py:216-244) in place of ``jr.choice``: the N0 retained components carry
+    unequal weights (``post.weights``).  ``_autocov1`` / ``_autocov2`` reduce to Delta = a0 P, Lambda = a1 P-
+    as in the reference's active code (:300, :338)."""
+    return speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_key, num_iter, opt_args, inputs,
+                                                _variant=2, **kwargs)
+
+
+def optimal_resampling(weights, N: int, key, device="cuda"):
+    """``utils.optimal_resampling(weights, N, key)`` (utils.py:216-244) on the device: weights (M,) or (B, M) with
+    M <= 64 -> (indices (N,), weights (N,)) or batched."""
+    torch = _torch()
+    lib = _lib.require_gpu()
+    w = _dev_f32(weights, device).contiguous()
+    squeeze = w.dim() == 1
+    if squeeze:
+        w = w.unsqueeze(0)
+    B, M = int(w.shape[0]), int(w.shape[1])
+    key = np.ascontiguousarray(np.asarray(key, dtype=np.uint32).reshape(2))
+    idx = torch.empty((B, int(N)), dtype=torch.int32, device=w.device)
+    wo = torch.empty((B, int(N)), dtype=torch.float32, device=w.device)
+    stream = torch.cuda.current_stream(w.device).cuda_stream
+    _lib.check(lib.bf_optimal_resample_f32(C.c_void_p(w.data_ptr()), key.ctypes.data_as(C.POINTER(C.c_uint32)), B, M, int(N),
+                                           C.c_void_p(idx.data_ptr()), C.c_void_p(wo.data_ptr()), C.c_void_p(stream)))
+    return (idx[0], wo[0]) if squeeze else (idx, wo)
+
+
 class ParticleCarry(NamedTuple):
     """The scan carry (weights, particles, key) of inference.py:1364 at the end of a chunk."""
     weights: Any

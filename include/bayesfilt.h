@@ -185,7 +185,9 @@ int bf_ugsf_ukf_f32(const bf_model* model, const bf_ukf_params* uparams, const b
  * DEVICE int32 [B][T][N0], the leaf each carried component was drawn from.  N0*N1*N2 <= 64.
  * variant: 0 = the speedy filter's two shared normal arrays (:672-688, :716-726); 1 = the branches of
  * augmented_gaussian_sum_filter (inference.py:458-620) through containers._branches_from_tree1/2
- * (containers.py:63-140): one key per node, jr.multivariate_normal per node, NaN samples replaced by the mean. */
+ * (containers.py:63-140): one key per node, jr.multivariate_normal per node, NaN samples replaced by the mean;
+ * 2 = augmented_gaussian_sum_filter_optimal (:1157-1300): the branches of 1 and utils.optimal_resampling
+ * (utils.py:216-244) instead of jr.choice, so the carried components keep unequal weights. */
 int bf_agsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream* u, int64_t B, int64_t T,
                     const int32_t num_components[3], const uint32_t key[2], const float opt_args[2], const bf_carry* carry,
                     const bf_out_desc* out, int32_t* leaf_idx, int32_t variant, void* stream);
@@ -196,6 +198,11 @@ int bf_agsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream
 int bf_agsf_ukf_f32(const bf_model* model, const bf_ukf_params* uparams, const bf_cstream* y, const bf_cstream* u, int64_t B,
                     int64_t T, const int32_t num_components[3], const uint32_t key[2], const float opt_args[2],
                     const bf_carry* carry, const bf_out_desc* out, int32_t* leaf_idx, int32_t variant, void* stream);
+
+/* utils.optimal_resampling(weights, N, key) (utils.py:216-244, Fearnhead & Clifford) for B weight vectors of
+ * length M <= 64: d_weights [B][M] -> d_idx [B][N] (indices into the M particles), d_weights_out [B][N]. */
+int bf_optimal_resample_f32(const float* d_weights, const uint32_t key[2], int64_t B, int32_t M, int32_t N, int32_t* d_idx,
+                            float* d_weights_out, void* stream);
 
 /* Moment-matching collapse of the mixture posterior per (trajectory, step): gaussfiltax/utils.py:10-18
  * and the point estimate sum_k w_k m_k (docs/experiments/BOT_Experiment_script.py:101).  weights /

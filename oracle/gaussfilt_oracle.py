@@ -17,6 +17,7 @@ Follows, line by line (paths relative to /root/reference):
   speedy_augmented_gaussian_sum_filter   gaussfiltax/inference.py:621-812
   augmented_gaussian_sum_filter          gaussfiltax/inference.py:458-620 + containers.py:63-140
   speedy_unscented_agsf / unscented_agsf gaussfiltax/inference.py:966-1156 / 813-965
+  augmented_gaussian_sum_filter_optimal  gaussfiltax/inference.py:1157-1300; optimal_resampling utils.py:216-244
 
 Quirks reproduced on purpose: update->reweight->predict order; psd_solve adds
 1e-6 to EVERY entry of S and uses LU (sgesv); posterior covariance P - K S K^T with the
@@ -374,6 +375,42 @@ def unscented_gaussian_sum_filter(params, uparams, emissions, num_components=1, 
     return post
 
 
+def optimal_resampling(weights, N, key):
+    """utils.py:216-244 (Fearnhead & Clifford 2003 as written there).  Conventions where XLA's are unspecified:
+    stable sort / argsort; the running sums ``lower_diag[M-N:M-1] @ sorted_weights`` accumulate in index order;
+    ``.sum()`` in the adjacent-pair tree order (sum_f32); jr.choice's cumsum in associative_scan order."""
+    weights = np.asarray(weights, dtype=F32)
+    M = weights.shape[0]
+    sorted_idx = np.argsort(weights, kind="stable").astype(np.int32)
+    sw = weights[sorted_idx]
+    cum = np.empty(M, F32)
+    acc = F32(0.0)
+    for c in range(M):
+        acc = F32(acc + sw[c])
+        cum[c] = acc
+    L = 0
+    ps = np.zeros(max(N - 1, 0), F32)
+    for ind in range(1, N):
+        ps[ind - 1] = F32(cum[M - 1 - ind] / F32(N - ind))
+        if sw[M - ind - 1] < ps[ind - 1] < sw[M - ind]:
+            L += ind
+    p = F32(1.0) / F32(N) if L == 0 else ps[min(max(L, 1), N - 1) - 1]
+    below = sw < p
+    res_w = np.where(below, sw, F32(0.0)).astype(F32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        res_w = (res_w / sum_f32(res_w)).astype(F32)
+    cdf = tf.cumsum_assoc(res_w)
+    u = tf.uniform(key, M)
+    r = (cdf[-1] * (F32(1.0) - u)).astype(F32)
+    res_idx = np.array([int(np.searchsorted(cdf, rv, side="left")) if rv == rv else M - 1 for rv in r])
+    res_idx = np.minimum(res_idx, M - 1)
+    unsort = sorted_idx[res_idx]
+    final_idx = np.where(below, unsort, sorted_idx).astype(np.int32)
+    final_w = np.where(below, p, sw).astype(F32)
+    top = final_w[M - N:]
+    return final_idx[M - N:], (top / sum_f32(top)).astype(F32)
+
+
 # --------------------------------------------------------------------------- augmented GSF (speedy variant)
 def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_key=None, num_iter=1,
                                          opt_args=(0.1, 0.1), inputs=None, initial_means=None, debug=False, variant=0,
@@ -417,7 +454,7 @@ def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_
     out_w = np.empty((T, N0), F32)
     out_m = np.empty((T, N0, n), F32)
     out_P = np.empty((T, N0, n, n), F32)
-    aux_pre, aux_um = [], []
+    aux_pre, aux_um, aux_idx = [], [], []
     M = N0 * N1 * N2
     for t in range(T):
         Q = np.asarray(_get_params(params.dynamics_noise_covariance, 2, t), dtype=F32)
@@ -457,17 +494,21 @@ def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_
         pw = (np.repeat(weights, N1) / F32(N1)).astype(F32)          # :699
         uw = (np.repeat(pw, N2) / F32(N2)).astype(F32)               # :738
         w = reweight(lls, uw)                                         # :740-743
-        idx = tf.choice_indices(tf.cumsum_assoc(w), tf.uniform(tf.PRNGKey(0), N0))   # :760
-        idx = np.minimum(idx, M - 1)
+        if variant == 2:     # augmented_gaussian_sum_filter_optimal :1256
+            idx, weights = optimal_resampling(w, N0, tf.split(key, 2)[0])
+        else:
+            idx = tf.choice_indices(tf.cumsum_assoc(w), tf.uniform(tf.PRNGKey(0), N0))   # :760
+            idx = np.minimum(idx, M - 1)
+            weights = (np.ones(N0, dtype=F32) / F32(N0)).astype(F32)
         fmeans, fcovs = um[idx].copy(), uP[idx].copy()
-        weights = (np.ones(N0, dtype=F32) / F32(N0)).astype(F32)
         out_w[t], out_m[t], out_P[t] = weights, fmeans, fcovs
         if debug:
             aux_pre.append(w.copy())
+            aux_idx.append(np.asarray(idx, dtype=np.int32).copy())
             aux_um.append(um.copy())
     post = PosteriorGaussianSumFiltered(weights=out_w.swapaxes(0, 1).copy(), means=out_m.swapaxes(0, 1).copy(),
                                         covariances=out_P.swapaxes(0, 1).copy())
-    aux = {"pre_weights": np.stack(aux_pre), "updated_means": np.stack(aux_um)} if debug else {}
+    aux = {"pre_weights": np.stack(aux_pre), "updated_means": np.stack(aux_um), "leaf_indices": np.stack(aux_idx)} if debug else {}
     return post, aux
 
 
@@ -476,6 +517,13 @@ def augmented_gaussian_sum_filter(params, emissions, num_components, rng_key=Non
     """inference.py:458-620: the speedy filter's tree with container-based branches (see ``variant`` above)."""
     return speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_key, num_iter, opt_args, inputs,
                                                 initial_means, debug, variant=1)
+
+
+def augmented_gaussian_sum_filter_optimal(params, emissions, num_components, rng_key=None, num_iter=1, opt_args=(0.1, 0.1),
+                                          inputs=None, initial_means=None, debug=False):
+    """inference.py:1157-1300: container-based branches + optimal_resampling; unequal carried weights."""
+    return speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_key, num_iter, opt_args, inputs,
+                                                initial_means, debug, variant=2)
 
 
 def speedy_unscented_agsf(params, uparams, emissions, num_components, rng_key=None, num_iter=1, opt_args=(0.1, 0.1),

@@ -145,3 +145,44 @@ def test_unscented_nodes(which):
     post, aux = getattr(bfa, which)(pp, bfa.ParamsUKF(1, 0, 0), ys, nc, otf.PRNGKey(3), 1, (0.1, 0.1), inputs,
                                     initial_means=init, return_leaf_indices=True)
     _compare(post, aux, ref, _oracle_leaf_indices(raux["pre_weights"], nc[0]), tol=3e-5)
+
+
+@pytest.mark.parametrize("M,N", [(8, 3), (12, 4), (50, 2), (30, 5), (64, 8), (5, 5), (7, 1)])
+def test_optimal_resampling_matches_oracle(M, N):
+    """utils.optimal_resampling (utils.py:216-244) on the device: indices bit-exact, weights to fp32 rounding,
+    for flat, peaked and tied weight vectors."""
+    bfa, nl = _nl()
+    rng = np.random.default_rng(M * 100 + N)
+    ws = [rng.dirichlet(np.ones(M)), rng.dirichlet(0.05 * np.ones(M)), np.ones(M) / M,
+          np.r_[np.zeros(M - 2), [0.5, 0.5]] if M > 2 else np.ones(M) / M]
+    W = np.stack(ws).astype(F32)
+    key = otf.PRNGKey(M + N)
+    idx, wo = bfa.optimal_resampling(W, N, key)
+    for b in range(W.shape[0]):
+        ri, rw = go.optimal_resampling(W[b], N, key)
+        assert np.array_equal(idx[b].cpu().numpy(), ri), (b, idx[b].cpu().numpy(), ri)
+        assert np.allclose(wo[b].cpu().numpy(), rw, rtol=1e-6, atol=1e-7, equal_nan=True), b
+    i1, w1 = bfa.optimal_resampling(W[0], N, key)
+    assert tuple(i1.shape) == (N,) and np.array_equal(i1.cpu().numpy(), idx[0].cpu().numpy())
+
+
+@pytest.mark.parametrize("nc", [(2, 5, 5), (4, 2, 3)])
+def test_optimal_variant(nc):
+    """augmented_gaussian_sum_filter_optimal (inference.py:1157-1300): unequal carried weights."""
+    bfa, nl = _nl()
+    a = cm.cv_model_arrays()
+    po, pp = cm.oracle_params(a), cm.product_params(a)
+    T = 20
+    ys = go.sample_ssm(po, otf.PRNGKey(5), T)[1]
+    init = np.random.default_rng(4).normal(size=(nc[0], 4)).astype(F32)
+    key = otf.PRNGKey(13)
+    ref, raux = go.augmented_gaussian_sum_filter_optimal(po, ys, nc, key, initial_means=init, debug=True)
+    post, aux = bfa.augmented_gaussian_sum_filter_optimal(pp, ys, nc, key, initial_means=init, return_leaf_indices=True,
+                                                          return_carry=True)
+    assert np.array_equal(aux["leaf_indices"].cpu().numpy(), raux["leaf_indices"])
+    for k in ("means", "covariances"):
+        assert cm.rel_err(getattr(post, k).cpu().numpy(), getattr(ref, k)) < 2e-5, k
+    # the weights are exponentials of log-likelihood differences: a 1e-5 error in ll is a 1e-5 * |ll| error here
+    assert np.allclose(post.weights.cpu().numpy(), ref.weights, rtol=3e-4, atol=1e-7)
+    assert not np.allclose(ref.weights, 1.0 / nc[0])                    # the point of the variant
+    assert np.allclose(aux["carry"].weights.cpu().numpy()[0], ref.weights[:, -1], rtol=3e-4, atol=1e-7)

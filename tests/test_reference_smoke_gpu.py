@@ -7,8 +7,7 @@ and -- the assertion the reference lacks -- agree with the NumPy oracle.  The re
 noise R = 25e-6 makes S = H P H^T + R so small that psd_solve's +1e-6 jitter dominates it and
 fp32 parity is lost within a few steps (the reference's own GSF returns NaN on this problem,
 BOTExperiment.ipynb cell 7); the parity half of each test therefore uses R = 1e-2, the shape / finiteness
-half uses the reference's value.  Not run: augmented_gaussian_sum_filter_optimal (optimal_resampling is
-not built)."""
+half uses the reference's value."""
 import numpy as np
 import pytest
 
@@ -90,6 +89,22 @@ def test_augmented_gaussian_sum_filter():                                # :84-8
     idx = np.stack([np.minimum(otf.choice_indices(otf.cumsum_assoc(w), otf.uniform(otf.PRNGKey(0), 2)), 49)
                     for w in raux["pre_weights"]])
     assert np.array_equal(aux["leaf_indices"].cpu().numpy(), idx)
+    for k in ("means", "covariances"):
+        assert cm.rel_err(getattr(post, k).cpu().numpy(), getattr(ref, k)) < 5e-5, k
+
+
+def test_augmented_gaussian_sum_filter_optimal():                        # :89-92
+    bfa, po, pp = _params(25e-6)
+    ys = _data(bfa, pp)
+    post, aux = bfa.augmented_gaussian_sum_filter_optimal(pp, ys, [5, 2, 2], opt_args=(0.1, 0.1), inputs=INPUTS)
+    _finite_shapes(post, 5)                 # the reference's [5, 5, 5] is 125 leaves; one wave holds 64
+    bfa, po, pp = _params(1e-2)
+    ys = _data(bfa, pp).cpu().numpy()
+    ref, raux = go.augmented_gaussian_sum_filter_optimal(po, ys, [5, 2, 2], opt_args=(0.1, 0.1), inputs=INPUTS.reshape(T, 1),
+                                                         debug=True)
+    post, aux = bfa.augmented_gaussian_sum_filter_optimal(pp, ys, [5, 2, 2], opt_args=(0.1, 0.1), inputs=INPUTS,
+                                                          return_leaf_indices=True)
+    assert np.array_equal(aux["leaf_indices"].cpu().numpy(), raux["leaf_indices"])
     for k in ("means", "covariances"):
         assert cm.rel_err(getattr(post, k).cpu().numpy(), getattr(ref, k)) < 5e-5, k
 
