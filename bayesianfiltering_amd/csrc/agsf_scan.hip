@@ -51,20 +51,4 @@ int launch_optimal_resample(const float* d_w, const uint32_t key[2], long long B
   return BF_OK;
 }
 
-int launch_agsf_ukf(const bf_model* p, const bf_ukf_params* up, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
-                    const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry, const bf_out_desc* out,
-                    int* d_leaf_idx, int variant, hipStream_t stream) {
-#define BF_CASE(N_, DQ_, M_, DR_)                                     \
-  if (p->n == N_ && p->dq == DQ_ && p->m == M_ && p->dr == DR_)       \
-    return launch_uagsf<N_, DQ_, M_, DR_>(p, up, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, variant, stream);
-  BF_CASE(1, 1, 1, 1);
-  BF_CASE(3, 3, 1, 1);
-  BF_CASE(4, 2, 1, 1);
-  BF_CASE(4, 2, 2, 2);
-  BF_CASE(4, 4, 2, 2);
-#undef BF_CASE
-  return set_error(BF_EUNSUPPORTED, "unscented augmented filter: (n=%d, dq=%d, m=%d, dr=%d) is not compiled in", p->n, p->dq, p->m,
-                   p->dr);
-}
-
 }  // namespace bf

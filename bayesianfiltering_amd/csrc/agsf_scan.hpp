@@ -163,14 +163,20 @@ struct AgsfOut {
   int* anc;  // [B][T][N0] index of the leaf each carried component was drawn from (NULL = not emitted)
 };
 
-template <int N, int M, class NODES>
-__global__ void __launch_bounds__(256)
+// NW = 1: the MP <= 64 leaves of a trajectory are lanes of one wave, 256 / MP trajectories per 256-thread workgroup.
+// NW > 1: one trajectory per workgroup of 64 NW threads (MP = 64 NW leaves, e.g. the [100, 2, 2] tree of
+// BOT_Experiment_script.py:118); reductions and the cumulative sum continue across waves through LDS.
+template <int N, int M, class NODES, int NW>
+__global__ void __launch_bounds__(NW == 1 ? 256 : 64 * NW)
 agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, AgsfOut out, long long B, long long T, int N0, int N1,
-                 int N2, int MP, float a0, float a1, uint32_t key0, uint32_t key1, int variant) {
+                 int N2, int MP, float a0, float a1, uint32_t key0, uint32_t key1, int variant, int carry_records) {
   constexpr int EP = N * N;
   constexpr int REC = N + EP;  // one component record in LDS: mean, covariance
+  constexpr int NT = NW == 1 ? 256 : 64 * NW;
   const int tid = threadIdx.x;
-  const int tpb = 256 / MP;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tpb = NT / MP;
   const int slot = tid / MP;       // trajectory slot in the workgroup
   const int l = tid % MP;          // leaf index
   const int Mleaf = N0 * N1 * N2;
@@ -182,10 +188,11 @@ agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, A
   const long long b = traj_ok ? b_raw : B - 1;
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* leafbuf = lds;                          // [256][REC]   updated mean / covariance of every leaf
-  float* carrybuf = lds + 256 * REC;             // [256][REC]   carried components, slot-major: [slot * MP + i0]
-  float* cdfbuf = carrybuf + 256 * REC;          // [256]        cumulative leaf weights
-  float* wbuf = cdfbuf + 256;                    // [256]        weights of the carried components (variant 2)
+  float* leafbuf = lds;                          // [NT][REC]            updated mean / covariance of every leaf
+  float* carrybuf = lds + NT * REC;              // [carry_records][REC] carried components, slot-major: [slot * MP + i0]
+  float* cdfbuf = carrybuf + carry_records * REC;  // [NT]               cumulative leaf weights
+  float* wbuf = cdfbuf + NT;                     // [carry_records]      weights of the carried components
+  float* red = wbuf + carry_records;             // [64]                 cross-wave scratch (NW > 1)
 
   // ---- the two standard-normal vectors of this leaf (same at every step: the reference's key is never advanced)
   float ez[N], es[N];
@@ -224,8 +231,18 @@ agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, A
   float wmine = (l < N0) ? (carry.w_in ? carry.w_in[b * N0 + l] : 1.0f / (float)N0) : 0.f;  // of component l (carry out)
   lds_barrier();
 
-  auto seg_reduce = [&](float v, auto op) {  // over the MP lanes of the trajectory, adjacent-pair tree
-    for (int off = 1; off < MP; off <<= 1) v = op(v, __shfl_xor(v, off, 64));
+  auto seg_reduce = [&](float v, auto op) {  // over the MP leaves of the trajectory, adjacent-pair tree
+    if constexpr (NW == 1) {
+      for (int off = 1; off < MP; off <<= 1) v = op(v, __shfl_xor(v, off, 64));
+    } else {
+      for (int off = 1; off < 64; off <<= 1) v = op(v, __shfl_xor(v, off, 64));
+      lds_barrier();
+      if (lane == 0) red[wave] = v;
+      lds_barrier();
+      float r = red[lane < NW ? lane : 0];
+      for (int off = 1; off < NW; off <<= 1) r = op(r, __shfl_xor(r, off, 64));
+      v = __shfl(r, 0, 64);
+    }
     return v;
   };
 
@@ -285,14 +302,44 @@ agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, A
 
     // ---- jr.choice(PRNGKey(0), arange(M), (N0,), p = w) (:760): cumsum in associative_scan order, inverse-CDF search
     float c = w;
-    for (int d = 0; (1 << d) < MP; ++d) {        // up-sweep
-      const float o = __shfl_up(c, 1 << d, 64);
-      if (((l + 1) & ((2 << d) - 1)) == 0) c += o;
-    }
-    for (int d = 5; d >= 1; --d) {               // down-sweep
-      if ((1 << d) < MP || (1 << d) == MP) {
+    if constexpr (NW == 1) {
+      for (int d = 0; (1 << d) < MP; ++d) {        // up-sweep
+        const float o = __shfl_up(c, 1 << d, 64);
+        if (((l + 1) & ((2 << d) - 1)) == 0) c += o;
+      }
+      for (int d = 5; d >= 1; --d) {               // down-sweep
+        if ((1 << d) <= MP) {
+          const float o = __shfl_up(c, 1 << (d - 1), 64);
+          if (l >= (1 << d) && ((l + 1) & ((1 << d) - 1)) == (1 << (d - 1))) c += o;
+        }
+      }
+    } else {
+      // the same Brent-Kung order over 64 NW leaves: wave up-sweep, scan of the wave totals, wave down-sweep
+      BF_UNROLL for (int d = 0; d < 6; ++d) {
+        const float o = __shfl_up(c, 1 << d, 64);
+        if (((lane + 1) & ((2 << d) - 1)) == 0) c += o;
+      }
+      lds_barrier();
+      if (lane == 63) red[16 + wave] = c;
+      lds_barrier();
+      float r = (lane < NW) ? red[16 + lane] : 0.f;
+      BF_UNROLL for (int d = 0; (1 << d) < NW; ++d) {
+        const float o = __shfl_up(r, 1 << d, 64);
+        if (lane < NW && ((lane + 1) & ((2 << d) - 1)) == 0) r += o;
+      }
+      BF_UNROLL for (int d = 4; d >= 1; --d) {
+        if ((1 << d) <= NW) {
+          const float o = __shfl_up(r, 1 << (d - 1), 64);
+          if (lane < NW && lane >= (1 << d) && ((lane + 1) & ((1 << d) - 1)) == (1 << (d - 1))) r += o;
+        }
+      }
+      const float mine = __shfl(r, wave, 64);
+      const float prev = __shfl(r, wave > 0 ? wave - 1 : 0, 64);
+      const float excl_wave = wave > 0 ? prev : 0.f;
+      if (lane == 63) c = mine;
+      BF_UNROLL for (int d = 6; d >= 1; --d) {
         const float o = __shfl_up(c, 1 << (d - 1), 64);
-        if (l >= (1 << d) && ((l + 1) & ((1 << d) - 1)) == (1 << (d - 1))) c += o;
+        if (((lane + 1) & ((1 << d) - 1)) == (1 << (d - 1))) c += (lane >= (1 << (d - 1))) ? o : excl_wave;
       }
     }
     lds_barrier();  // previous step's readers of leafbuf / cdfbuf are done
@@ -305,7 +352,7 @@ agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, A
     lds_barrier();
     int idx = 0;
     float wnew = 1.0f / (float)N0;  // weights = ones / N0                                          :765
-    if (variant == 2) {
+    if (NW == 1 && variant == 2) {
       // augmented_gaussian_sum_filter_optimal (:1157-1300): utils.optimal_resampling(weights, N0, key) with the
       // key left by the two splits (:1203, :1229); the drawn components keep unequal weights
       const U32x2 kz = threefry_split(key0, key1, 0u, 2u);
@@ -347,31 +394,57 @@ agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, A
   }
 }
 
-template <int N, int M, class NODES>
-static inline int launch_agsf_nodes(typename NODES::Arg arg, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
-                                    const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry,
-                                    const bf_out_desc* out, int* d_leaf_idx, int variant, hipStream_t stream) {
-  const int Mleaf = nc[0] * nc[1] * nc[2];
-  int MP = 1;
-  while (MP < Mleaf) MP <<= 1;
-  if (MP > 64) return set_error(BF_EUNSUPPORTED, "augmented Gaussian-sum filter: %d leaves per trajectory exceed one wave (64)", Mleaf);
-  if (out->pred_means.ptr || out->pred_covs.ptr || out->coll_mean.ptr || out->coll_cov.ptr || out->loglik.ptr)
-    return set_error(BF_EINVAL, "the augmented filter emits weights, means and covariances only (inference.py:771-775)");
+template <int N, int M, class NODES, int NW>
+static inline int launch_agsf_geom(typename NODES::Arg arg, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
+                                   const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry,
+                                   const bf_out_desc* out, int* d_leaf_idx, int variant, int MP, hipStream_t stream) {
   constexpr int REC = N + N * N;
-  const size_t lds_bytes = sizeof(float) * (size_t)(2 * 256 * REC + 512);
-  if (lds_bytes > 160 * 1024) return set_error(BF_EUNSUPPORTED, "component records exceed the 160 KiB LDS");
+  constexpr int NT = NW == 1 ? 256 : 64 * NW;
+  const int carry_records = NW == 1 ? 256 : ((nc[0] + 3) & ~3);
+  const size_t lds_bytes = sizeof(float) * ((size_t)NT * REC + (size_t)carry_records * REC + NT + carry_records + 64);
+  if (lds_bytes > 160 * 1024)
+    return set_error(BF_EUNSUPPORTED, "augmented Gaussian-sum filter: %d leaves and %d components of dimension %d exceed the 160 KiB LDS",
+                     nc[0] * nc[1] * nc[2], nc[0], N);
   CView yv{y->ptr, y->sB, y->sT, y->sE};
   UView uv{u && u->ptr ? u->ptr : nullptr, u ? u->sB : 0, u ? u->sT : 0};
   CarryView cv{carry->w_in, carry->m_in, carry->P_in, carry->w_out, carry->m_out, carry->P_out};
   AgsfOut ov{make_sview(out->weights), make_sview(out->means), make_sview(out->covs), d_leaf_idx};
-  auto kern = agsf_scan_kernel<N, M, NODES>;
+  auto kern = agsf_scan_kernel<N, M, NODES, NW>;
   if (lds_bytes > 64 * 1024)
     BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  const int tpb = 256 / MP;
-  hipLaunchKernelGGL(kern, dim3((unsigned)((B + tpb - 1) / tpb)), dim3(256), lds_bytes, stream, arg, yv, uv, cv, ov, B, T, nc[0],
-                     nc[1], nc[2], MP, opt[0], opt[1], key[0], key[1], variant);
+  const int tpb = NT / MP;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((B + tpb - 1) / tpb)), dim3(NT), lds_bytes, stream, arg, yv, uv, cv, ov, B, T, nc[0],
+                     nc[1], nc[2], MP, opt[0], opt[1], key[0], key[1], variant, carry_records);
   BF_HIP_CHECK(hipGetLastError());
   return BF_OK;
+}
+
+template <int N, int M, class NODES>
+static inline int launch_agsf_nodes(typename NODES::Arg arg, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
+                                    const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry,
+                                    const bf_out_desc* out, int* d_leaf_idx, int variant, hipStream_t stream) {
+  const long long Mleaf = (long long)nc[0] * nc[1] * nc[2];
+  if (Mleaf > 1024)
+    return set_error(BF_EUNSUPPORTED, "augmented Gaussian-sum filter: %lld leaves per trajectory exceed one workgroup (1024)", Mleaf);
+  int MP = 1;
+  while (MP < Mleaf) MP <<= 1;
+  if (variant == 2 && MP > 64)
+    return set_error(BF_EUNSUPPORTED, "optimal resampling sorts inside one wave: %lld leaves exceed 64", Mleaf);
+  if (out->pred_means.ptr || out->pred_covs.ptr || out->coll_mean.ptr || out->coll_cov.ptr || out->loglik.ptr)
+    return set_error(BF_EINVAL, "the augmented filter emits weights, means and covariances only (inference.py:771-775)");
+#define BF_GEOM(NW_) return launch_agsf_geom<N, M, NODES, NW_>(arg, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, variant, MP, stream)
+  if (MP <= 64) BF_GEOM(1);
+  if constexpr (N <= 4) {  // the multi-wave geometries are built for the small state dimensions only (build time, LDS)
+    if (MP <= 256) {
+      MP = 256;
+      BF_GEOM(4);
+    }
+    MP = 1024;
+    BF_GEOM(16);
+  } else {
+    return set_error(BF_EUNSUPPORTED, "augmented Gaussian-sum filter: more than 64 leaves per trajectory need state_dim <= 4");
+  }
+#undef BF_GEOM
 }
 
 template <int N, int M>

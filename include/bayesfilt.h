@@ -182,7 +182,8 @@ int bf_ugsf_ukf_f32(const bf_model* model, const bf_ukf_params* uparams, const b
  * draws N0 of the N0*N1*N2 leaves with jr.choice under PRNGKey(0).  key: the reference's rng_key (it is
  * never advanced: the same normals at every step).  The carry holds N0 components per trajectory;
  * out: weights / means / covs with K = N0 (the other streams must be unset).  leaf_idx: optional
- * DEVICE int32 [B][T][N0], the leaf each carried component was drawn from.  N0*N1*N2 <= 64.
+ * DEVICE int32 [B][T][N0], the leaf each carried component was drawn from.  N0*N1*N2 <= 64 in general,
+ * <= 1024 for state_dim <= 4 (one workgroup per trajectory), <= 64 for variant 2.
  * variant: 0 = the speedy filter's two shared normal arrays (:672-688, :716-726); 1 = the branches of
  * augmented_gaussian_sum_filter (inference.py:458-620) through containers._branches_from_tree1/2
  * (containers.py:63-140): one key per node, jr.multivariate_normal per node, NaN samples replaced by the mean;

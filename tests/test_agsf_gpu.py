@@ -186,3 +186,37 @@ def test_optimal_variant(nc):
     assert np.allclose(post.weights.cpu().numpy(), ref.weights, rtol=3e-4, atol=1e-7)
     assert not np.allclose(ref.weights, 1.0 / nc[0])                    # the point of the variant
     assert np.allclose(aux["carry"].weights.cpu().numpy()[0], ref.weights[:, -1], rtol=3e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("nc,unscented", [((100, 2, 2), False), ((3, 5, 7), False), ((20, 3, 3), True), ((70, 1, 1), False)])
+def test_trees_wider_than_a_wave(nc, unscented):
+    """num_components = [100, 2, 2] is what BOT_Experiment_script.py:118 runs: 400 leaves = one 1024-thread workgroup
+    per trajectory (reductions and the cumulative sum continue across waves); 105 and 180 leaves use 256 threads."""
+    bfa, nl = _nl()
+    T, B = 8, 2
+    mu0 = np.array([2.0, 0.3, 3.0, -0.2], F32)
+    S0 = np.diag([0.1, 0.005, 0.1, 0.01]).astype(F32)
+    Q, R = 1e-3 * np.eye(2, dtype=F32), np.diag([1e-3, 1e-2]).astype(F32)
+    inputs = np.array([1] * 3 + [0] * 3 + [2] * 2, F32)
+    po = go.ParamsNLSSM(mu0, S0, om.ManeuverBOT(), np.zeros(2, F32), Q, om.BearingRange(), np.zeros(2, F32), R)
+    pp = bfa.ParamsNLSSM(mu0, S0, nl.maneuver_bot(), np.zeros(2, F32), Q, nl.bearing_range(), np.zeros(2, F32), R)
+    ys = np.stack([go.sample_ssm(po, otf.PRNGKey(20 + b), T, inputs.reshape(T, 1))[1] for b in range(B)])
+    init = (mu0 + 0.05 * np.random.default_rng(7).normal(size=(B, nc[0], 4))).astype(F32)
+    key = otf.PRNGKey(9)
+    if unscented:
+        post, aux = bfa.speedy_unscented_agsf(pp, bfa.ParamsUKF(1, 0, 0), ys, nc, key, 1, (0.1, 0.1), inputs, initial_means=init,
+                                              return_leaf_indices=True)
+    else:
+        post, aux = bfa.speedy_augmented_gaussian_sum_filter(pp, ys, nc, key, 1, (0.1, 0.1), inputs, initial_means=init,
+                                                             return_leaf_indices=True)
+    assert tuple(post.means.shape) == (B, nc[0], T, 4)
+    for b in range(B):
+        if unscented:
+            ref, raux = go.speedy_unscented_agsf(po, go.ParamsUKF(1, 0, 0), ys[b], nc, key, 1, (0.1, 0.1), inputs.reshape(T, 1),
+                                                 initial_means=init[b], debug=True)
+        else:
+            ref, raux = go.speedy_augmented_gaussian_sum_filter(po, ys[b], nc, key, 1, (0.1, 0.1), inputs.reshape(T, 1),
+                                                                initial_means=init[b], debug=True)
+        assert np.array_equal(aux["leaf_indices"][b].cpu().numpy(), raux["leaf_indices"]), b
+        for k in ("means", "covariances"):
+            assert cm.rel_err(getattr(post, k)[b].cpu().numpy(), getattr(ref, k)) < 3e-5, (b, k)
