@@ -50,8 +50,12 @@ struct GsfCfg {
   static constexpr int WP = (EP >= 32 ? EP : 32) > WMIN ? (EP >= 32 ? EP : 32) : WMIN;
   // 128-byte rows for the mean / weight streams as well (8 waves per CU leave the LDS for it): a 64-byte run is
   // half a cache line and writes ~15 % slower (scripts/store_pattern_bench.hip)
-  static constexpr int WM = (NS >= 32 ? NS : 32) > WMIN ? (NS >= 32 ? NS : 32) : WMIN;
-  static constexpr int WW = 32 > WMIN ? 32 : WMIN;
+#ifndef BF_GSF_WSM
+#define BF_GSF_WSM 32
+#endif
+  static constexpr int WSM = BF_GSF_WSM;
+  static constexpr int WM = (NS >= WSM ? NS : WSM) > WMIN ? (NS >= WSM ? NS : WSM) : WMIN;
+  static constexpr int WW = WSM > WMIN ? WSM : WMIN;
   using TP = Tile<EP, WP, CPW, 4>;
   using TM = Tile<NS, WM, CPW, 4>;
   using TW = Tile<1, WW, CPW, 0>;

@@ -13,7 +13,7 @@ dev = torch.device("cuda")
 y = 8.0 + torch.randn((B, T, 4), device=dev)
 init = 8.0 + torch.randn((B, K, 8), device=dev)
 lib = _lib.require_gpu()
-for lanes in (2, 4, 8):
+for lanes in [int(v) for v in os.environ.get("PLANES", "2,4,8").split(",")]:
   lib.bf_set_option(b"kf_lanes", lanes)
   print("lanes", lanes)
   for fields, name in ((bfa.FULL5, "FULL5"), ((), "none")):
