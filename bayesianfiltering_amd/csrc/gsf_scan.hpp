@@ -80,7 +80,7 @@ constexpr int wrap_mod(int i) {
 template <int NS, int M, int NL, int MODE, int SPEC, bool EXT = false>
 __global__ void __launch_bounds__(256, 2)
 gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutViews out, long long B, long long T, int K,
-                int KP, int lds_per_wave, const float* __restrict__ tv_gqg, const float* __restrict__ tv_drd) {
+                int KP, int lds_per_wave, const float* __restrict__ tv_gqg, const float* __restrict__ tv_drd, int wscalar) {
   using Cfg = GsfCfg<NS, M, NL>;
   constexpr int CPL = Cfg::CPL, CPW = Cfg::CPW, EP = Cfg::EP;
   using TP = typename Cfg::TP;
@@ -149,8 +149,8 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
     }
     if (out.m.p) { oM = q; q += TM::FLOATS; }
     if (out.pm.p) { opM = q; q += TM::FLOATS; }
-    if (out.w.p) { oW = q; q += TW::FLOATS; }
-    if (out.ll.p) { oL = q; q += TW::FLOATS; }
+    if (out.w.p && !wscalar) { oW = q; q += TW::FLOATS; }
+    if (out.ll.p && !wscalar) { oL = q; q += TW::FLOATS; }
   }
   const unsigned offP = TP::lane_off(lane, T * EP);
   const unsigned offM = TM::lane_off(lane, T * NS);
@@ -429,8 +429,13 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
         BF_UNROLL for (int i = 0; i < NS; ++i) BF_UNROLL for (int cc = 0; cc < CPL; ++cc) lds[o + rowabs(i) * NS + cc] = Pc[cc][i];
       }
       if (jl == 0) {
-        if (out.w.p) lds[oW + putW + int(t % TW::TS)] = w;
-        if (out.ll.p) lds[oL + putW + int(t % TW::TS)] = ll;
+        if (wscalar) {  // T is not a multiple of 4: the rows of the scalar streams are not 16-byte aligned, they go out one by one
+          if (out.w.p) out.w.p[b * out.w.sB + k * out.w.sK + t * out.w.sT] = w;
+          if (out.ll.p) out.ll.p[b * out.ll.sB + k * out.ll.sK + t * out.ll.sT] = ll;
+        } else {
+          if (out.w.p) lds[oW + putW + int(t % TW::TS)] = w;
+          if (out.ll.p) lds[oL + putW + int(t % TW::TS)] = ll;
+        }
       }
       if constexpr (TP::TS == 1) {
         if (out.P.p) {
@@ -487,7 +492,7 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
         if (out.m.p) TM::write(va, lane, reinterpret_cast<char*>(out.m.p + chain0w * out.m.sK + t0 * NS), offM, out.m.sK, lim);
         if (out.pm.p) TM::write(vb, lane, reinterpret_cast<char*>(out.pm.p + chain0w * out.pm.sK + t0 * NS), offM, out.pm.sK, lim);
       }
-      if (remW == 0 || last) {
+      if (!wscalar && (remW == 0 || last)) {
         wave_lds_sync();
         const long long t0 = remW == 0 ? t1 - TW::TS : t1 - remW;
         const int lim = remW == 0 ? TW::CH : remW / 4;
@@ -700,8 +705,10 @@ static inline int launch_gsf(const bf_model* p, const bf_cstream* y, const bf_cs
                           gsf_stream_is_reference(out->means, N, T, K) && gsf_stream_is_reference(out->pred_means, N, T, K) &&
                           gsf_stream_is_reference(out->covs, N * N, T, K) && gsf_stream_is_reference(out->pred_covs, N * N, T, K);
   auto row_ok = [&](const bf_stream& st, long long E) { return st.ptr == nullptr || (T * E) % 4 == 0; };
-  const bool rows_aligned = row_ok(out->weights, 1) && row_ok(out->loglik, 1) && row_ok(out->means, N) &&
-                            row_ok(out->pred_means, N) && row_ok(out->covs, N * N) && row_ok(out->pred_covs, N * N);
+  // (the two scalar streams may fall back to dword stores on their own: T not a multiple of 4 is common)
+  const bool wscalar = !(row_ok(out->weights, 1) && row_ok(out->loglik, 1));
+  const bool rows_aligned = row_ok(out->means, N) && row_ok(out->pred_means, N) && row_ok(out->covs, N * N) &&
+                            row_ok(out->pred_covs, N * N);
   const bool off32_ok = (double)T * N * N * 4.0 * (Cfg::CPW + 1) < 4.0e9;
   const int tpb = 256 / (KP * NL);
   // staged stores need every wave to hold CPW valid, consecutive chains of the [B][K] order
@@ -716,7 +723,7 @@ static inline int launch_gsf(const bf_model* p, const bf_cstream* y, const bf_cs
 
   const int nP = (out->covs.ptr ? 1 : 0) + (out->pred_covs.ptr ? 1 : 0);
   const int nM = (out->means.ptr ? 1 : 0) + (out->pred_means.ptr ? 1 : 0);
-  const int nW = (out->weights.ptr ? 1 : 0) + (out->loglik.ptr ? 1 : 0);
+  const int nW = wscalar ? 0 : (out->weights.ptr ? 1 : 0) + (out->loglik.ptr ? 1 : 0);
   int lds_per_wave = 0;
   if constexpr (Cfg::STAGED_OK)
     if (mode == EMIT_STAGED)
@@ -745,14 +752,14 @@ static inline int launch_gsf(const bf_model* p, const bf_cstream* y, const bf_cs
   dim3 grid((unsigned)((B + tpb - 1) / tpb));
   if (ext) {
     hipLaunchKernelGGL((gsf_scan_kernel<N, M, NL, EMIT_SCALAR, SPEC, true>), grid, block, lds_bytes, stream, e, yv, uv, cv, ov, B,
-                       T, K, KP, lds_per_wave, d_tvq, d_tvr);
+                       T, K, KP, lds_per_wave, d_tvq, d_tvr, (int)wscalar);
   } else if (mode == EMIT_SCALAR) {
     hipLaunchKernelGGL((gsf_scan_kernel<N, M, NL, EMIT_SCALAR, SPEC>), grid, block, lds_bytes, stream, e, yv, uv, cv, ov, B, T, K,
-                       KP, lds_per_wave, d_tvq, d_tvr);
+                       KP, lds_per_wave, d_tvq, d_tvr, (int)wscalar);
   } else {
     if constexpr (Cfg::STAGED_OK)
       hipLaunchKernelGGL((gsf_scan_kernel<N, M, NL, EMIT_STAGED, SPEC>), grid, block, lds_bytes, stream, e, yv, uv, cv, ov, B, T, K,
-                         KP, lds_per_wave, d_tvq, d_tvr);
+                         KP, lds_per_wave, d_tvq, d_tvr, (int)wscalar);
   }
   const hipError_t le = hipGetLastError();
   if (d_tv) (void)hipFreeAsync(d_tv, stream);

@@ -81,7 +81,7 @@ struct GroupCfg {
 template <int NS, int M, int NL, int MODE, bool TV>
 __global__ void __launch_bounds__(256, (NL >= 4 ? 4 : NL))
 kf_scan_group_kernel(KFConst<NS, M> c, const float* __restrict__ gqg_t, const float* __restrict__ drd_t, CView y,
-                     CarryView carry, OutViews out, long long B, long long T, int lds_per_wave, int vm_younger) {
+                     CarryView carry, OutViews out, long long B, long long T, int lds_per_wave, int vm_younger, int wscalar) {
   using Cfg = GroupCfg<NS, M, NL>;
   constexpr int CPL = Cfg::CPL, CPW = Cfg::CPW, EP = Cfg::EP, YS = Cfg::YS;
   using TP = typename Cfg::TP;
@@ -134,8 +134,8 @@ kf_scan_group_kernel(KFConst<NS, M> c, const float* __restrict__ gqg_t, const fl
     if (out.pP.p) { opP = q; q += TP::FLOATS; }
     if (out.m.p) { oM = q; q += TM::FLOATS; }
     if (out.pm.p) { opM = q; q += TM::FLOATS; }
-    if (out.w.p) { oW = q; q += TW::FLOATS; }
-    if (out.ll.p) { oL = q; q += TW::FLOATS; }
+    if (out.w.p && !wscalar) { oW = q; q += TW::FLOATS; }
+    if (out.ll.p && !wscalar) { oL = q; q += TW::FLOATS; }
   }
   const unsigned offP = TP::lane_off(lane, T * EP);
   const unsigned offM = TM::lane_off(lane, T * NS);
@@ -247,8 +247,13 @@ kf_scan_group_kernel(KFConst<NS, M> c, const float* __restrict__ gqg_t, const fl
         BF_UNROLL for (int i = 0; i < NS; ++i) BF_UNROLL for (int cc = 0; cc < CPL; ++cc) lds[o + i * NS + cc] = Pc[cc][i];
       }
       if (jl == 0) {
-        if (out.w.p) lds[oW + putW + int(t % TW::TS)] = w;
-        if (out.ll.p) lds[oL + putW + int(t % TW::TS)] = ll;
+        if (wscalar) {  // T is not a multiple of 4: the rows of the scalar streams are not 16-byte aligned, they go out one by one
+          if (out.w.p) out.w.p[b * out.w.sB + t * out.w.sT] = w;
+          if (out.ll.p) out.ll.p[b * out.ll.sB + t * out.ll.sT] = ll;
+        } else {
+          if (out.w.p) lds[oW + putW + int(t % TW::TS)] = w;
+          if (out.ll.p) lds[oL + putW + int(t % TW::TS)] = ll;
+        }
       }
     } else if (chain_ok) {
       BF_UNROLL for (int cc = 0; cc < CPL; ++cc) if (col_ok[cc]) {
@@ -339,7 +344,7 @@ kf_scan_group_kernel(KFConst<NS, M> c, const float* __restrict__ gqg_t, const fl
         if (out.m.p) TM::write(va, lane, reinterpret_cast<char*>(out.m.p + b0w * out.m.sB + t0 * NS), offM, out.m.sB, lim);
         if (out.pm.p) TM::write(vb, lane, reinterpret_cast<char*>(out.pm.p + b0w * out.pm.sB + t0 * NS), offM, out.pm.sB, lim);
       }
-      if (remW == 0 || last) {
+      if (!wscalar && (remW == 0 || last)) {
         wave_lds_sync();
         const long long t0 = remW == 0 ? t1 - TW::TS : t1 - remW;
         const int lim = remW == 0 ? TW::CH : remW / 4;
@@ -454,8 +459,10 @@ static inline int launch_nml(const bf_lgssm* p, const bf_cstream* y, long long B
                           stream_is_reference(out->covs, N * N, T) && stream_is_reference(out->pred_covs, N * N, T);
   // float4 stores need every enabled stream's rows (T*E floats apart) to stay 16-byte aligned
   auto row_ok = [&](const bf_stream& st, long long E) { return st.ptr == nullptr || (T * E) % 4 == 0; };
-  const bool rows_aligned = row_ok(out->weights, 1) && row_ok(out->loglik, 1) && row_ok(out->means, N) &&
-                            row_ok(out->pred_means, N) && row_ok(out->covs, N * N) && row_ok(out->pred_covs, N * N);
+  // (the two scalar streams may fall back to dword stores on their own: T not a multiple of 4 is common)
+  const bool wscalar = !(row_ok(out->weights, 1) && row_ok(out->loglik, 1));
+  const bool rows_aligned = row_ok(out->means, N) && row_ok(out->pred_means, N) && row_ok(out->covs, N * N) &&
+                            row_ok(out->pred_covs, N * N);
   // the flush addresses the rows of one wave through 32-bit byte offsets from a uniform base
   const bool off32_ok = (double)T * N * N * 4.0 * (Cfg::CPW + 1) < 4.0e9;
   const bool staged_ok = Cfg::STAGED_OK && ref_layout && rows_aligned && off32_ok;
@@ -464,7 +471,7 @@ static inline int launch_nml(const bf_lgssm* p, const bf_cstream* y, long long B
   if constexpr (Cfg::STAGED_OK) {
     const int nP = (out->covs.ptr ? 1 : 0) + (out->pred_covs.ptr ? 1 : 0);
     const int nM = (out->means.ptr ? 1 : 0) + (out->pred_means.ptr ? 1 : 0);
-    const int nW = (out->weights.ptr ? 1 : 0) + (out->loglik.ptr ? 1 : 0);
+    const int nW = wscalar ? 0 : (out->weights.ptr ? 1 : 0) + (out->loglik.ptr ? 1 : 0);
     const size_t per_wave = 2 * Cfg::YBUF + nP * Cfg::TP::FLOATS + nM * Cfg::TM::FLOATS + nW * Cfg::TW::FLOATS;
     lds_ok = per_wave * 4 * sizeof(float) <= 160 * 1024;
   }
@@ -520,9 +527,10 @@ static inline int launch_nml(const bf_lgssm* p, const bf_cstream* y, long long B
     // bound the counted vmcnt of the kernel relies on
     int vm_younger;
     if (mode_ == EMIT_STAGED) {
-      lds_per_wave += nP * Cfg::TP::FLOATS + nM * Cfg::TM::FLOATS + nW * Cfg::TW::FLOATS;
+      const int nWs = wscalar ? 0 : nW;  // scalar streams staged only when their rows are 16-byte aligned
+      lds_per_wave += nP * Cfg::TP::FLOATS + nM * Cfg::TM::FLOATS + nWs * Cfg::TW::FLOATS;
       vm_younger = (Cfg::YS / Cfg::TP::TS) * nP * Cfg::TP::ITER + (Cfg::YS / Cfg::TM::TS) * nM * Cfg::TM::ITER +
-                   (Cfg::YS / Cfg::TW::TS) * nW * Cfg::TW::ITER;
+                   (Cfg::YS / Cfg::TW::TS) * nWs * Cfg::TW::ITER;
     } else {
       vm_younger = Cfg::YS * (nM * Cfg::CPL + nP * N * Cfg::CPL + nW);
     }
@@ -539,7 +547,7 @@ static inline int launch_nml(const bf_lgssm* p, const bf_cstream* y, long long B
     dim3 grid((unsigned)((waves + 3) / 4));
 #define BF_LAUNCH(MODE_, TV_)                                                                                  \
   hipLaunchKernelGGL((kf_scan_group_kernel<N, M, NL, MODE_, TV_>), grid, block, lds_bytes, stream, c, d_gqg,   \
-                     d_drd, yv2, cv2, ov2, b_count, T, lds_per_wave, vm_younger)
+                     d_drd, yv2, cv2, ov2, b_count, T, lds_per_wave, vm_younger, (int)wscalar)
     if (tv) {
       if (mode_ == EMIT_SCALAR) BF_LAUNCH(EMIT_SCALAR, true);
       else if constexpr (Cfg::STAGED_OK) BF_LAUNCH(EMIT_STAGED, true);

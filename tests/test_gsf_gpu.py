@@ -375,3 +375,26 @@ def test_collapsed_mode_matches_collapse_of_the_streams(case):
     assert all(getattr(only[0], k) is None for k in FIELDS + ("weights",))
     assert np.array_equal(only[1][0].cpu().numpy(), cmean.cpu().numpy())
     assert np.array_equal(only[1][1].cpu().numpy(), ccov.cpu().numpy())
+
+
+def test_staged_path_when_T_is_not_a_multiple_of_four():
+    """K = 4, T = 50: the weight rows are misaligned and fall back to dword stores on their own; the forced
+    staged emitter must accept the launch and agree bit for bit with the strided path."""
+    bfa, nl = _nl()
+    a = cm.cv_model_arrays()
+    po, pp = cm.oracle_params(a), cm.product_params(a)
+    T, B, K = 50, 32, 4
+    ys = np.stack([go.sample_ssm(po, otf.PRNGKey(b), T)[1] for b in range(B)])
+    init = np.random.default_rng(6).normal(size=(B, K, 4)).astype(F32)
+    res = {}
+    for mode in (2, 0):
+        _mode(mode)
+        try:
+            res[mode] = bfa.gaussian_sum_filter(pp, ys, K, 1, initial_means=init, return_loglik=True)
+        finally:
+            _mode(-1)
+    ref = _oracle_batch(po, ys[:2], K, init[:2])
+    for k in FIELDS + ("weights",):
+        assert np.array_equal(getattr(res[2][0], k).cpu().numpy(), getattr(res[0][0], k).cpu().numpy()), k
+        assert cm.rel_err(getattr(res[2][0], k).cpu().numpy()[:2], ref[k]) < 3e-5 or k == "weights", k
+    assert np.array_equal(res[2][1].cpu().numpy(), res[0][1].cpu().numpy())

@@ -149,3 +149,27 @@ def test_golden_kalman_fixtures(golden_dir):
         for k in FIELDS:
             assert cm.rel_err(getattr(post, k).cpu().numpy(), d["out_" + k]) < TOL, (name, k)
         assert cm.rel_err(ll.cpu().numpy(), d["out_loglik"]) < 2e-5
+
+
+@pytest.mark.parametrize("T", [50, 73 * 2, 21 * 4 + 2])
+def test_staged_path_with_rows_of_the_scalar_streams_unaligned(T):
+    """T not a multiple of 4: the weight / log-likelihood rows are not 16-byte aligned and go out as dword
+    stores while means and covariances keep the LDS-staged path (forcing the staged emitter must succeed)."""
+    import bayesianfiltering_amd as bfa
+    from bayesianfiltering_amd import _lib
+    a = cm.cv_model_arrays()
+    p = cm.product_params(a)
+    B = 64
+    ys = cm.simulate_batch(a, B, T, seed=T)
+    init = np.tile(a["m0"], (B, 1)).astype(np.float32)
+    ref = cm.oracle_kalman_batch(a, ys, init)
+    lib = _lib.require_gpu()
+    _lib.check(lib.bf_set_option(b"kf_emit_mode", 2))
+    try:
+        post, ll = bfa.kalman_filter(p, ys, initial_means=init, return_loglik=True)
+    finally:
+        _lib.check(lib.bf_set_option(b"kf_emit_mode", -1))
+    for k in ("means", "covariances", "predicted_means", "predicted_covariances"):
+        assert cm.rel_err(getattr(post, k).cpu().numpy(), ref[k]) < 1e-5, k
+    assert np.allclose(post.weights.cpu().numpy(), 1.0)
+    assert cm.rel_err(ll.cpu().numpy(), ref["loglik"]) < 3e-5
