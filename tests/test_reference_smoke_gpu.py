@@ -156,3 +156,16 @@ def test_bootstrap_particle_filter_on_the_same_model():
     assert tuple(out["weights"].shape) == (1000, T) and tuple(out["particles"].shape) == (1000, T, 4)
     w = out["weights"].cpu().numpy()
     assert np.allclose(w.sum(axis=0), 1.0, atol=1e-4)
+
+
+def test_bot_monte_carlo_example_runs():
+    """examples/bot_experiment.py (the loop of BOT_Experiment_script.py:89-180 as one batch) at a small size."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "bot_experiment.py"), "--nsim", "8", "--steps", "50",
+                          "--components", "8", "--particles", "256"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    for name in ("GSF", "U-GSF", "AGSF", "U-AGSF", "BPF"):
+        assert any(line.startswith(name) for line in out.stdout.splitlines()), out.stdout
