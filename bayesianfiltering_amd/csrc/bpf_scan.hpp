@@ -141,7 +141,7 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
                 int resampler, uint32_t key0, uint32_t key1) {
   constexpr int NT = 64 * NW;
   constexpr int CAP = NT * PPT;                 // particle slots (power of two)
-  constexpr int DCH = (N >= 8) ? 8 : N;         // state dimensions gathered per LDS pass
+  constexpr int DCH = (PPT >= 16) ? 1 : ((N >= 8) ? 8 : N);  // state dimensions gathered per LDS pass
   const BpfModel<N, DQ, M>& mdl = *mdlp;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -349,7 +349,7 @@ static inline int launch_bpf_cfg(const BpfModel<N, DQ, M>* d_mdl, const bf_cstre
                           long long T, int NP, float ess, int resampler, const uint32_t key[2], const BpfCarry& cr,
                           const BpfOut& out, hipStream_t stream) {
   constexpr int CAP = 64 * NW * PPT;
-  constexpr int DCH = (N >= 8) ? 8 : N;
+  constexpr int DCH = (PPT >= 16) ? 1 : ((N >= 8) ? 8 : N);
   const size_t lds_bytes = sizeof(float) * (size_t)(CAP + 64 + CAP * DCH);
   if (lds_bytes > 160 * 1024) return set_error(BF_EUNSUPPORTED, "particle tile exceeds the 160 KiB LDS");
   CView yv{y->ptr, y->sB, y->sT, y->sE};
@@ -390,7 +390,13 @@ static inline int launch_bpf_dims(const bf_bpf_model* bp, const bf_cstream* y, c
     if (g_bpf_variant == 1) rc = launch_bpf_cfg<N, DQ, M, 8, 8>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
     else rc = launch_bpf_cfg<N, DQ, M, 4, 16>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
   }
-  else rc = set_error(BF_EUNSUPPORTED, "bootstrap particle filter: %d particles exceed the compiled capacity of 4096 per trajectory", NP);
+  else if (NP <= 16384 && N <= 4 && DQ <= 4) {
+    // small states: 16 particles per thread still fit the registers (1024 threads x 16; the gather goes one
+    // state dimension at a time so that CDF + tile stay within the LDS)
+    if constexpr (N <= 4 && DQ <= 4) rc = launch_bpf_cfg<N, DQ, M, 16, 16>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
+  }
+  else rc = set_error(BF_EUNSUPPORTED, "bootstrap particle filter: %d particles exceed the compiled capacity per trajectory "
+                      "(4096; 16384 for state and noise dimensions <= 4)", NP);
   hipError_t fe = hipFreeAsync(d_mdl, stream);
   if (rc != BF_OK) return rc;
   BF_HIP_CHECK(fe);

@@ -125,7 +125,45 @@ def test_bpf_errors():
     p = _l63_params(bfa, nl)
     ys = np.zeros((4, 3), F32)
     with pytest.raises(_lib.BayesFiltError) as e:
-        bfa.bootstrap_particle_filter(p, ys, 5000)
+        bfa.bootstrap_particle_filter(p, ys, 20000)       # 16 384 is the largest compiled capacity (state dims <= 4)
     assert e.value.code == _lib.BF_EUNSUPPORTED
     with pytest.raises(TypeError):
         bfa.bootstrap_particle_filter(p._replace(emission_distribution_log_prob=lambda x, y, u: 0.0), ys, 64)
+
+
+def test_sixteen_thousand_particles_for_small_states():
+    """N = 10 000 (the particle count of the reference's BOTExperiment notebook) on the manoeuvring-target
+    model: 16 particles per thread; weights, particles and ancestry against the oracle."""
+    import bayesianfiltering_amd as bfa
+    nl = bfa.nonlinearities
+    T, N = 6, 10000
+    mu0 = np.array([2.0, 0.3, 3.0, -0.2], F32)
+    S0 = np.diag([0.1, 0.005, 0.1, 0.01]).astype(F32)
+    Q, R = 1e-3 * np.eye(2, dtype=F32), np.diag([1e-2, 1e-1]).astype(F32)
+    inputs = np.array([1, 1, 0, 0, 2, 2], F32)
+    po = go.ParamsBPF(mu0, S0, om.ManeuverBOT(), np.zeros(2, F32), Q, om.BearingRange(), np.zeros(2, F32), R,
+                      go.GaussianEmissionLogProb(om.BearingRange(), R))
+    pp = bfa.ParamsBPF(mu0, S0, nl.maneuver_bot(), np.zeros(2, F32), Q, nl.bearing_range(), np.zeros(2, F32), R,
+                       nl.gaussian_log_prob(nl.bearing_range(), R))
+    ys = go.sample_ssm(go.ParamsNLSSM(*po[:8]), otf.PRNGKey(8), T, inputs.reshape(T, 1))[1]
+    key = otf.PRNGKey(5)
+    ref, dbg = go.bootstrap_particle_filter(po, ys, N, key=key, inputs=inputs.reshape(T, 1), debug=True)
+    out = bfa.bootstrap_particle_filter(pp, ys, N, key, inputs, return_ancestors=True)
+    assert tuple(out["weights"].shape) == (N, T) and tuple(out["particles"].shape) == (N, T, 4)
+    anc, ranc = out["ancestors"].cpu().numpy(), np.asarray(dbg["ancestors"])
+    if ranc.shape != anc.shape:
+        ranc = ranc.T
+    # a draw within an ulp of a CDF step may pick the neighbouring index; from that step on the two particle sets
+    # differ in one member and the runs drift apart, so: (nearly) identical ancestry at the first step, and
+    # bit-level agreement of everything up to the first such event
+    assert (anc[:, 0] == ranc[:, 0]).mean() > 0.9995
+    t_ok = 0
+    while t_ok < T and np.array_equal(anc[:, t_ok], ranc[:, t_ok]):
+        t_ok += 1
+    same = anc[:, 0] == ranc[:, 0]
+    assert cm.rel_err(out["particles"].cpu().numpy()[same, 0], ref["particles"][same, 0]) < 2e-5
+    if t_ok >= 1:
+        assert cm.rel_err(out["particles"].cpu().numpy()[:, :t_ok], ref["particles"][:, :t_ok]) < 2e-5
+        assert np.max(np.abs(out["weights"].cpu().numpy()[:, :t_ok] - ref["weights"][:, :t_ok])) < 1e-6
+    with pytest.raises(bfa.BayesFiltError):
+        bfa.bootstrap_particle_filter(pp, ys, 20000, key, inputs)
