@@ -1,0 +1,90 @@
+"""Edge cases through the C-ABI: empty and minimal inputs, capacity limits, ragged batches."""
+import numpy as np
+import pytest
+
+from oracle import gaussfilt_oracle as go, models as om, threefry as otf
+from tests import common as cm
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def _bfa():
+    import bayesianfiltering_amd as bfa
+    return bfa, bfa.nonlinearities
+
+
+def test_empty_inputs_are_rejected_loudly():
+    bfa, nl = _bfa()
+    a = cm.cv_model_arrays()
+    p = cm.product_params(a)
+    for bad in (np.zeros((0, 2), F32), np.zeros((0, 5, 2), F32), np.zeros((3, 0, 2), F32)):
+        with pytest.raises(ValueError):
+            bfa.kalman_filter(p, bad) if bad.ndim == 3 else bfa.gaussian_sum_filter(p, bad, 2)
+    with pytest.raises(ValueError):
+        bfa.gaussian_sum_filter(p, np.zeros((4, 3), F32), 2)          # wrong emission dimension
+    with pytest.raises(ValueError):
+        bfa.gaussian_sum_filter(p, np.zeros((4, 2), F32), 0)          # no components
+
+
+def test_single_step_single_trajectory():
+    bfa, nl = _bfa()
+    a = cm.cv_model_arrays()
+    po, pp = cm.oracle_params(a), cm.product_params(a)
+    y = np.array([[0.3, -0.2]], F32)
+    init = np.array([[0.1, 0.0, -0.1, 0.0]], F32)
+    ref = go.gaussian_sum_filter(po, y, 1, initial_means=init)
+    post = bfa.gaussian_sum_filter(pp, y, 1, 1, initial_means=init)
+    for k in ("means", "covariances", "predicted_means", "predicted_covariances"):
+        assert tuple(getattr(post, k).shape) == getattr(ref, k).shape
+        assert cm.rel_err(getattr(post, k).cpu().numpy(), getattr(ref, k)) < 1e-5, k
+    kf = bfa.kalman_filter(pp, y[None], initial_means=init)
+    assert cm.rel_err(kf.means.cpu().numpy()[0], ref.means) < 1e-5
+
+
+@pytest.mark.parametrize("B", [1, 31, 33, 95, 257])
+def test_ragged_batches(B):
+    """Batches that do not fill the last wave / workgroup: the tail goes through the strided path."""
+    bfa, nl = _bfa()
+    a = cm.cv_model_arrays()
+    po, pp = cm.oracle_params(a), cm.product_params(a)
+    T = 12
+    ys = cm.simulate_batch(a, B, T, seed=B)
+    init = np.tile(a["m0"], (B, 1)).astype(F32)
+    post = bfa.kalman_filter(pp, ys, initial_means=init)
+    ref = cm.oracle_kalman_batch(a, ys[[0, B - 1]], init[[0, B - 1]])
+    for k in ("means", "covariances", "predicted_covariances"):
+        assert cm.rel_err(getattr(post, k).cpu().numpy()[[0, B - 1]], ref[k]) < 1e-5, k
+    gsf = bfa.gaussian_sum_filter(pp, ys, 4, 1, initial_means=np.repeat(init[:, None], 4, axis=1))
+    assert cm.rel_err(gsf.means.cpu().numpy()[:, 0], post.means.cpu().numpy()[:, 0]) < 2e-5
+
+
+def test_capacity_limits():
+    bfa, nl = _bfa()
+    # 256 components = every lane of a workgroup (scalar state: one lane per chain)
+    po = go.ParamsNLSSM(np.zeros(1, F32), np.eye(1, dtype=F32), om.Sine(1, 1.5), np.zeros(1, F32), 0.1 * np.eye(1, dtype=F32),
+                        om.Quadratic(1, 0.5), np.zeros(1, F32), 0.5 * np.eye(1, dtype=F32))
+    pp = bfa.ParamsNLSSM(np.zeros(1, F32), np.eye(1, dtype=F32), nl.sine(1, 1.5), np.zeros(1, F32), 0.1 * np.eye(1, dtype=F32),
+                         nl.quadratic(1, 0.5), np.zeros(1, F32), 0.5 * np.eye(1, dtype=F32))
+    ys = go.sample_ssm(po, otf.PRNGKey(1), 6)[1]
+    init = np.linspace(-2, 2, 256, dtype=F32).reshape(256, 1)
+    ref = go.gaussian_sum_filter(po, ys, 256, initial_means=init)
+    post = bfa.gaussian_sum_filter(pp, ys, 256, 1, initial_means=init)
+    assert cm.rel_err(post.means.cpu().numpy(), ref.means) < 1e-4
+    assert np.max(np.abs(post.weights.cpu().numpy() - ref.weights)) < 1e-5
+    with pytest.raises(bfa.BayesFiltError):
+        bfa.gaussian_sum_filter(pp, ys, 257, 1, initial_means=np.zeros((257, 1), F32))
+    # 1024 leaves = the largest augmented tree; 1025 is refused
+    a = cm.cv_model_arrays()
+    p4 = cm.product_params(a)
+    y4 = np.zeros((3, 2), F32)
+    post, _ = bfa.speedy_augmented_gaussian_sum_filter(p4, y4, (16, 8, 8))
+    assert tuple(post.means.shape) == (16, 3, 4) and bool(np.isfinite(post.means.cpu().numpy()).all())
+    with pytest.raises(bfa.BayesFiltError):
+        bfa.speedy_augmented_gaussian_sum_filter(p4, y4, (41, 5, 5))
+    # the particle capacities: 4096 in general, 16384 for small states
+    bp = bfa.ParamsBPF(*p4, nl.gaussian_log_prob(p4.emission_function, a["R"]))
+    out = bfa.bootstrap_particle_filter(bp, y4, 16384, bfa.PRNGKey(0), output="summary")
+    assert tuple(out["mean"].shape) == (3, 4) and bool(np.isfinite(out["mean"].cpu().numpy()).all())
+    with pytest.raises(bfa.BayesFiltError):
+        bfa.bootstrap_particle_filter(bp, y4, 16385, bfa.PRNGKey(0))
