@@ -446,7 +446,7 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
           wave_lds_sync();
         }
       }
-    } else if (chain_ok) {
+    } else if (MODE == EMIT_SCALAR && chain_ok) {
       BF_UNROLL for (int cc = 0; cc < CPL; ++cc) {
         const int col = jl * CPL + cc;
         if (out.m.p) out.m.p[b * out.m.sB + k * out.m.sK + t * out.m.sT + col * out.m.sE] = mj[cc];
@@ -503,7 +503,7 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
         if (out.ll.p) TW::write(vb, lane, reinterpret_cast<char*>(out.ll.p + chain0w * out.ll.sK + t0), offW, out.ll.sK, lim);
       }
       wave_lds_sync();
-    } else if (chain_ok) {
+    } else if (MODE == EMIT_SCALAR && chain_ok) {
       BF_UNROLL for (int cc = 0; cc < CPL; ++cc) {
         const int col = jl * CPL + cc;
         if (out.pm.p) out.pm.p[b * out.pm.sB + k * out.pm.sK + t * out.pm.sT + col * out.pm.sE] = mj[cc];
@@ -750,7 +750,12 @@ static inline int launch_gsf(const bf_model* p, const bf_cstream* y, const bf_cs
   }
   dim3 block(256);
   dim3 grid((unsigned)((B + tpb - 1) / tpb));
-  if (ext) {
+  const bool no_streams = !out->weights.ptr && !out->means.ptr && !out->covs.ptr && !out->pred_means.ptr && !out->pred_covs.ptr &&
+                          !out->loglik.ptr;
+  if (ext && no_streams) {  // collapsed-only: the per-component store code is not even compiled in
+    hipLaunchKernelGGL((gsf_scan_kernel<N, M, NL, EMIT_NONE, SPEC, true>), grid, block, lds_bytes, stream, e, yv, uv, cv, ov, B,
+                       T, K, KP, lds_per_wave, d_tvq, d_tvr, (int)wscalar);
+  } else if (ext) {
     hipLaunchKernelGGL((gsf_scan_kernel<N, M, NL, EMIT_SCALAR, SPEC, true>), grid, block, lds_bytes, stream, e, yv, uv, cv, ov, B,
                        T, K, KP, lds_per_wave, d_tvq, d_tvr, (int)wscalar);
   } else if (mode == EMIT_SCALAR) {

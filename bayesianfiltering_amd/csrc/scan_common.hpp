@@ -8,7 +8,7 @@
 
 namespace bf {
 
-enum { EMIT_SCALAR = 0, EMIT_STAGED = 2 };
+enum { EMIT_SCALAR = 0, EMIT_NONE = 1, EMIT_STAGED = 2 };  // EMIT_NONE: no per-component streams compiled in (collapsed-only runs)
 
 // table[idx * STRIDE + off] for a lane-dependent idx < CNT, as an unrolled select chain (the
 // table is a kernel argument: a runtime index would copy it to scratch)
