@@ -364,6 +364,12 @@ static inline int launch_bpf_cfg(const BpfModel<N, DQ, M>* d_mdl, const bf_cstre
 
 extern int g_bpf_variant;  // tuning hook (bf_set_option "bpf_variant")
 
+// bpf_big.hpp: particle counts beyond the in-register capacities (declared here, defined after the kernels there)
+template <int N, int DQ, int M>
+static inline int launch_bpf_big_dims(const BpfModel<N, DQ, M>* d_mdl, const bf_cstream* y, const bf_cstream* u, long long B,
+                                      long long T, int NP, float ess, int resampler, const uint32_t key[2], const BpfCarry& cr,
+                                      const BpfOut& out, hipStream_t stream);
+
 template <int N, int DQ, int M>
 static inline int launch_bpf_dims(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
                            int NP, float ess, int resampler, const uint32_t key[2], const BpfCarry& cr, const BpfOut& out,
@@ -395,8 +401,7 @@ static inline int launch_bpf_dims(const bf_bpf_model* bp, const bf_cstream* y, c
     // state dimension at a time so that CDF + tile stay within the LDS)
     if constexpr (N <= 4 && DQ <= 4) rc = launch_bpf_cfg<N, DQ, M, 16, 16>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
   }
-  else rc = set_error(BF_EUNSUPPORTED, "bootstrap particle filter: %d particles exceed the compiled capacity per trajectory "
-                      "(4096; 16384 for state and noise dimensions <= 4)", NP);
+  else rc = launch_bpf_big_dims<N, DQ, M>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);  // particles in HBM (bpf_big.hpp)
   hipError_t fe = hipFreeAsync(d_mdl, stream);
   if (rc != BF_OK) return rc;
   BF_HIP_CHECK(fe);

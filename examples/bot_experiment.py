@@ -8,8 +8,8 @@ simulated and filtered in one launch per filter.  Prints the RMSE table of :238-
 0 and 2, mean +- std over the runs) and the wall time per filter for the whole batch.
 
 Differences from the reference script, by necessity: the functions come from the device registry instead of
-Python lambdas; the particle filter runs 4096 particles per trajectory by default, at most 16 384 (the reference:
-50 000 -- the engine keeps a trajectory's particles in the registers of one workgroup); emission noise R = 1e-4 I instead of
+Python lambdas; the particle filter runs 4096 particles per trajectory by default (the reference: 50 000, which
+--particles 50000 reproduces through the particles-in-HBM kernel, at ~10x the time per trajectory); emission noise R = 1e-4 I instead of
 25e-6 I, where the reference's own GSF / UGSF return NaN (BOTExperiment.ipynb cell 7).
 
     python examples/bot_experiment.py [--nsim 100] [--steps 500] [--components 100]

@@ -253,8 +253,10 @@ typedef struct bf_bpf_out {
 } bf_bpf_out;
 
 /* Batched bootstrap particle filter: replaces the lax.scan of bootstrap_particle_filter
- * (inference.py:1330-1377) with _resample (utils.py:207-214).  N <= 4096 particles per
- * trajectory, one workgroup per trajectory.  key = {hi, lo} of jr.PRNGKey (used for every
+ * (inference.py:1330-1377) with _resample (utils.py:207-214).  One workgroup per
+ * trajectory: N <= 4096 particles (16 384 for state / noise dimensions <= 4) stay in the workgroup's
+ * registers; larger N up to 2^20 keep the particles in HBM scratch (stream-ordered allocation) and run
+ * the same tree orders chunk by chunk.  key = {hi, lo} of jr.PRNGKey (used for every
  * trajectory unless carry->key_in is given).  resampler: 0 = multinomial inverse-CDF (the
  * reference's jr.choice), 1 = systematic. */
 int bf_bpf_f32(const bf_bpf_model* model, const bf_cstream* y, const bf_cstream* u, int64_t B, int64_t T, int32_t N,

@@ -82,9 +82,11 @@ def test_capacity_limits():
     assert tuple(post.means.shape) == (16, 3, 4) and bool(np.isfinite(post.means.cpu().numpy()).all())
     with pytest.raises(bfa.BayesFiltError):
         bfa.speedy_augmented_gaussian_sum_filter(p4, y4, (41, 5, 5))
-    # the particle capacities: 4096 in general, 16384 for small states
+    # the in-register particle capacities: 4096 in general, 16384 for small states; beyond, the particles live in HBM
     bp = bfa.ParamsBPF(*p4, nl.gaussian_log_prob(p4.emission_function, a["R"]))
     out = bfa.bootstrap_particle_filter(bp, y4, 16384, bfa.PRNGKey(0), output="summary")
     assert tuple(out["mean"].shape) == (3, 4) and bool(np.isfinite(out["mean"].cpu().numpy()).all())
+    out = bfa.bootstrap_particle_filter(bp, y4, 16385, bfa.PRNGKey(0), output="summary")
+    assert bool(np.isfinite(out["mean"].cpu().numpy()).all())
     with pytest.raises(bfa.BayesFiltError):
-        bfa.bootstrap_particle_filter(bp, y4, 16385, bfa.PRNGKey(0))
+        bfa.bootstrap_particle_filter(bp, y4, (1 << 20) + 1, bfa.PRNGKey(0))
