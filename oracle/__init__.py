@@ -15,6 +15,8 @@ the reference's own tests hold no assertions, golden vectors or fixtures
 (docs/tests/test_inference.py:74-104 only ``return`` values).  The oracle is therefore pinned
 by what can be checked offline: textbook fp64 Kalman recursions, the discrete Riccati
 steady state (scipy), public Threefry-2x32 known-answer vectors (Random123), and
-finite-difference checks of every analytic Jacobian.  The golden fixtures under
+finite-difference checks of every analytic Jacobian.  The only reference-generated data this path
+can be checked against are the 20 PRNG keys printed in docs/notebooks/BOTExperiment.ipynb (cell 6):
+PRNGKey / split reproduce them bit for bit (tests/golden/reference_notebook_keys.json).  The golden fixtures under
 ``tests/golden`` are produced by this oracle (``tests/golden/make_golden.py``).
 """

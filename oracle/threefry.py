@@ -15,7 +15,8 @@ What is restated here is the published algorithm of those functions for the defa
   the public Random123 known-answer vectors (tests/test_oracle_rng.py).
 * ``threefry_2x32(key, counts)``: counts are split in two halves (padded with one 0 if odd),
   the halves are the two words of each block, outputs are concatenated half-after-half.
-* ``split(key, num)``: counts = iota(2*num) -> reshape (num, 2).
+* ``split(key, num)``: counts = iota(2*num) -> reshape (num, 2).  Pinned by the 20 keys the reference's own
+  notebook run printed (BOTExperiment.ipynb cell 6; tests/golden/reference_notebook_keys.json).
 * ``random_bits(key, 32, shape)``: counts = iota(size).
 * ``uniform``: mantissa trick ``(bits >> 9) | 0x3f800000`` -> [1,2) - 1, affine to [lo, hi), max(lo, .).
 * ``normal``: ``sqrt(2) * erf_inv(uniform(nextafter(-1, 0), 1))`` with XLA's f32 ``erf_inv``

@@ -59,3 +59,14 @@ def test_golden_rng_vectors(golden_dir):
     assert np.array_equal(d["bits_0_9"], tf.random_bits(k, 9))
     assert np.array_equal(d["normal_0_8"], tf.normal(k, 8))
     assert np.array_equal(d["cumsum_out"], tf.cumsum_assoc(d["cumsum_in"]))
+
+
+def test_split_chain_recorded_by_the_reference(golden_dir):
+    """The reference's own run (BOTExperiment.ipynb cell 6) printed 20 keys of a chained jr.split(next_key, 3) from
+    PRNGKey(1): the oracle's PRNGKey / split must give the same words (tests/golden/extract_reference_keys.py)."""
+    import json
+    d = json.load(open(golden_dir + "/reference_notebook_keys.json"))
+    nk = tf.PRNGKey(d["seed"])
+    for k0_ref, k_ref in zip(d["key0"], d["key"]):
+        k0, k, nk = tf.split(nk, 3)
+        assert k0.tolist() == k0_ref and k.tolist() == k_ref

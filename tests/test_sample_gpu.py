@@ -44,3 +44,16 @@ def test_sample_matches_oracle_for_registry_models():
             assert cm.rel_err(ys[b].cpu().numpy(), yr) < 2e-5, type(po.emission_function).__name__
         x1, y1 = model.sample(pp, keys[0], T, u)            # single key -> reference shapes (T, n), (T, m)
         assert tuple(x1.shape) == (T, dims[0]) and np.array_equal(x1.cpu().numpy(), xs[0].cpu().numpy())
+
+
+def test_library_split_reproduces_keys_recorded_by_the_reference(golden_dir):
+    """bf_random_split (the library's Threefry, the same function the kernels inline) against the 20 keys the
+    reference's own notebook run printed: PRNGKey(1), then key0, key, next_key = split(next_key, 3), ten times."""
+    import json
+    import bayesianfiltering_amd as bfa
+    from bayesianfiltering_amd import legacy
+    d = json.load(open(golden_dir + "/reference_notebook_keys.json"))
+    nk = bfa.PRNGKey(d["seed"])
+    for k0_ref, k_ref in zip(d["key0"], d["key"]):
+        k0, k, nk = legacy._split(nk, 3)
+        assert k0.tolist() == k0_ref and k.tolist() == k_ref
