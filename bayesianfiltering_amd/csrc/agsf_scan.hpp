@@ -29,21 +29,27 @@
 
 namespace bf {
 
-// lower Cholesky factor of a symmetric matrix (jnp.linalg.cholesky; NaN when not positive definite)
+// jnp.linalg.cholesky as the reference's CPU runs evaluate it: the input is symmetrised ((A + A^T) / 2), and a failed
+// factorisation (LAPACK potrf: a pivot <= 0 or NaN) returns an all-NaN factor
 template <int N>
 __device__ __forceinline__ void chol_lower(const float* A, float* L) {
   BF_UNROLL for (int i = 0; i < N * N; ++i) L[i] = 0.f;
+  bool bad = false;
   BF_UNROLL for (int j = 0; j < N; ++j) {
     float d = A[j * N + j];
     BF_UNROLL for (int k = 0; k < j; ++k) d = fmaf(-L[j * N + k], L[j * N + k], d);
+    bad |= !(d > 0.f);
     d = sqrtf(d);
     L[j * N + j] = d;
     const float inv = 1.0f / d;
     BF_UNROLL for (int i = j + 1; i < N; ++i) {
-      float s = A[i * N + j];
+      float s = 0.5f * (A[i * N + j] + A[j * N + i]);
       BF_UNROLL for (int k = 0; k < j; ++k) s = fmaf(-L[i * N + k], L[j * N + k], s);
       L[i * N + j] = s * inv;
     }
+  }
+  if (bad) {
+    BF_UNROLL for (int i = 0; i < N * N; ++i) L[i] = __builtin_nanf("");
   }
 }
 

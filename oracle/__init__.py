@@ -9,14 +9,18 @@ Who may import it: ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baselin
 ``bayesianfiltering_amd/`` imports, links or executes anything from here; the product path
 raises if the HIP library is missing.
 
-PARITY UNPINNED: the reference cannot be executed in this build environment (``jax``,
+PARITY PIN: the reference cannot be executed in this build environment (``jax``,
 ``tensorflow_probability`` are not installed; ordinary ModuleNotFoundError) and
-the reference's own tests hold no assertions, golden vectors or fixtures
-(docs/tests/test_inference.py:74-104 only ``return`` values).  The oracle is therefore pinned
-by what can be checked offline: textbook fp64 Kalman recursions, the discrete Riccati
-steady state (scipy), public Threefry-2x32 known-answer vectors (Random123), and
-finite-difference checks of every analytic Jacobian.  The only reference-generated data this path
-can be checked against are the 20 PRNG keys printed in docs/notebooks/BOTExperiment.ipynb (cell 6):
-PRNGKey / split reproduce them bit for bit (tests/golden/reference_notebook_keys.json).  The golden fixtures under
-``tests/golden`` are produced by this oracle (``tests/golden/make_golden.py``).
+its own tests hold no assertions, golden vectors or fixtures (docs/tests/test_inference.py:74-104
+only ``return`` values).  What pins this restatement to the real reference are the results the
+reference's author recorded in the stored cell outputs of docs/notebooks/*.ipynb
+(tests/golden/extract_reference_outputs.py): the 20 PRNG keys of BOTExperiment.ipynb (bit-exact),
+the GSF / UGSF RMSEs of Experiment_TSP_2023.ipynb (<= 3e-6 relative, NaN pattern included) and the
+GSF-NaN / 100-particle BPF RMSE / weights of test_single_run.ipynb (6e-7) --
+tests/test_reference_recorded_outputs.py, tests/test_oracle_rng.py.  PARITY UNPINNED for the
+augmented filters (their recorded RMSEs come from an older library state) and the legacy classes.
+Beyond that the oracle is checked against offline mathematics: textbook fp64 Kalman recursions, the
+discrete Riccati steady state (scipy), public Threefry-2x32 known-answer vectors (Random123), and
+finite-difference checks of every analytic Jacobian.  The golden fixtures under ``tests/golden``
+(*.npz) are produced by this oracle (``tests/golden/make_golden.py``).
 """

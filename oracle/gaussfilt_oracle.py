@@ -25,7 +25,8 @@ un-jittered S and no symmetrisation; log-likelihood from a Cholesky of the un-ji
 linear-domain weights (0/0 -> NaN allowed); num_iter ignored; inputs=None -> zeros((T,1));
 time-varying parameters only through an extra leading axis on the (d,d) covariances.
 
-All arithmetic float32.  PARITY UNPINNED against the real reference (see oracle/__init__.py).
+All arithmetic float32.  Pinned by the reference's recorded notebook outputs for the sampler, GSF, UGSF and BPF;
+PARITY UNPINNED for the augmented filters (see oracle/__init__.py).
 """
 from typing import NamedTuple, Optional, Callable
 import numpy as np
@@ -272,7 +273,10 @@ def sym_sqrtm(P):
     root V diag(sqrt(lambda)) V^T; eigenvalues below zero (rounding) have a purely imaginary root whose
     real part is 0.  Evaluated in float64 and rounded to float32 (jax runs a float32 Schur iteration;
     the two agree to float32 resolution for the well-conditioned covariances of the parity tests)."""
-    lam, V = np.linalg.eigh(np.asarray(P, dtype=np.float64))
+    P = np.asarray(P, dtype=np.float64)
+    if not np.all(np.isfinite(P)):      # NaN in, NaN out (jax propagates; LAPACK would raise)
+        return np.full(P.shape, np.nan, dtype=F32)
+    lam, V = np.linalg.eigh(P)
     return ((V * np.sqrt(np.maximum(lam, 0.0))) @ V.T).astype(F32)
 
 
@@ -411,6 +415,19 @@ def optimal_resampling(weights, N, key):
     return final_idx[M - N:], (top / sum_f32(top)).astype(F32)
 
 
+def chol_jax(A):
+    """jnp.linalg.cholesky as the reference's CPU runs evaluate it: the input is symmetrised ((A + A^T) / 2), LAPACK potrf
+    factors it, and a failed factorisation (a pivot <= 0 or NaN) returns an all-NaN matrix instead of raising."""
+    A = np.asarray(A, dtype=F32)
+    A = (F32(0.5) * (A + A.T)).astype(F32)
+    if not np.all(np.isfinite(A)):
+        return np.full(A.shape, np.nan, dtype=F32)
+    try:
+        return np.linalg.cholesky(A).astype(F32)
+    except np.linalg.LinAlgError:
+        return np.full(A.shape, np.nan, dtype=F32)
+
+
 # --------------------------------------------------------------------------- augmented GSF (speedy variant)
 def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_key=None, num_iter=1,
                                          opt_args=(0.1, 0.1), inputs=None, initial_means=None, debug=False, variant=0,
@@ -466,7 +483,7 @@ def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_
         pP = np.empty((N0 * N1, n, n), F32)
         for i0 in range(N0):
             Delta = (a0 * fcovs[i0]).astype(F32)
-            Lz = np.linalg.cholesky((fcovs[i0] - Delta).astype(F32)).astype(F32)
+            Lz = chol_jax((fcovs[i0] - Delta).astype(F32))
             zc = _mm(Lz, eps_z[i0])                      # (n, N1)
             for i1 in range(N1):
                 z = (fmeans[i0] + zc[:, i1]).astype(F32)
@@ -481,7 +498,7 @@ def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_
         uP = np.empty((M, n, n), F32)
         for j in range(N0 * N1):
             Lam = (a1 * pP[j]).astype(F32)
-            Ls = np.linalg.cholesky((pP[j] - Lam).astype(F32)).astype(F32)
+            Ls = chol_jax((pP[j] - Lam).astype(F32))
             sc = _mm(Ls, eps_s[j])                       # (n, N2)
             for i2 in range(N2):
                 sv = (pm[j] + sc[:, i2]).astype(F32)

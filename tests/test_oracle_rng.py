@@ -63,7 +63,7 @@ def test_golden_rng_vectors(golden_dir):
 
 def test_split_chain_recorded_by_the_reference(golden_dir):
     """The reference's own run (BOTExperiment.ipynb cell 6) printed 20 keys of a chained jr.split(next_key, 3) from
-    PRNGKey(1): the oracle's PRNGKey / split must give the same words (tests/golden/extract_reference_keys.py)."""
+    PRNGKey(1): the oracle's PRNGKey / split must give the same words (tests/golden/extract_reference_outputs.py)."""
     import json
     d = json.load(open(golden_dir + "/reference_notebook_keys.json"))
     nk = tf.PRNGKey(d["seed"])
