@@ -48,6 +48,7 @@ int launch_resample(const float* d_w, const uint32_t* d_keys, long long B, int N
                     hipStream_t stream);
 
 extern int g_bpf_variant;
+extern int g_bpf_hbm_mode;
 extern int g_gsf_structured;
 static int g_kf_emit_mode = -1;  // -1 = choose from the layout
 static int g_kf_lanes = 0;       // 0 = default lanes per trajectory for the (n, m) pair
@@ -90,6 +91,11 @@ int bf_set_option(const char* name, int value) {
   if (name && std::strcmp(name, "bpf_variant") == 0) {
     if (value < 0 || value > 1) return bf::set_error(BF_EINVAL, "bpf_variant must be 0 or 1");
     bf::g_bpf_variant = value;
+    return BF_OK;
+  }
+  if (name && std::strcmp(name, "bpf_hbm_mode") == 0) {
+    if (value < 0 || value > 2) return bf::set_error(BF_EINVAL, "bpf_hbm_mode must be 0, 1 or 2");
+    bf::g_bpf_hbm_mode = value;
     return BF_OK;
   }
   return bf::set_error(BF_EINVAL, "unknown option '%s'", name ? name : "(null)");

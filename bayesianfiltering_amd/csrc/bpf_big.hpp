@@ -86,6 +86,38 @@ __device__ __forceinline__ float chunk_total_bk(float v, float* red) {
   return __shfl(r, 15, 64);
 }
 
+// one particle through the dynamics with its own noise draw (inference.py:1342-1345: q = q0 + chol(Q) z from the
+// particle's key), written back in place, and its emission log-density (:1348-1349)
+template <int N, int DQ, int M>
+__device__ __forceinline__ float propagate_particle(const BpfModel<N, DQ, M>& mdl, U32x2 ki, float* xp, float u0, const float* yv) {
+  float x[N], q[DQ], xn[N];
+  BF_UNROLL for (int d = 0; d < N; ++d) x[d] = xp[d];
+  constexpr int h = (DQ + 1) / 2;
+  float zhi[h];
+  BF_UNROLL for (int d = 0; d < DQ; ++d) q[d] = 0.f;
+  BF_UNROLL for (int j = 0; j < h; ++j) {
+    const U32x2 o = threefry2x32(ki.x, ki.y, (uint32_t)j, (h + j < DQ) ? (uint32_t)(h + j) : 0u);
+    const float zj = bits_to_normal(o.x);
+    zhi[j] = (h + j < DQ) ? bits_to_normal(o.y) : 0.f;
+    BF_UNROLL for (int d = j; d < DQ; ++d) q[d] = fmaf(mdl.LQ[d * DQ + j], zj, q[d]);
+  }
+  BF_UNROLL for (int j = 0; h + j < DQ; ++j)
+    BF_UNROLL for (int d = h + j; d < DQ; ++d) q[d] = fmaf(mdl.LQ[d * DQ + h + j], zhi[j], q[d]);
+  BF_UNROLL for (int d = 0; d < DQ; ++d) q[d] = mdl.q0[d] + q[d];
+  dyn_value<N, DQ, M>(mdl, x, q, u0, xn);
+  BF_UNROLL for (int d = 0; d < N; ++d) xp[d] = xn[d];
+  float hx[M], zz[M];
+  emi_value<N, DQ, M>(mdl, xn, u0, hx);
+  float quad = 0.f;
+  BF_UNROLL for (int a = 0; a < M; ++a) {
+    float s = yv[a] - hx[a];
+    BF_UNROLL for (int cc = 0; cc < a; ++cc) s = fmaf(-mdl.LR[a * M + cc], zz[cc], s);
+    zz[a] = s * mdl.rdLR[a];
+    quad = fmaf(zz[a], zz[a], quad);
+  }
+  return -0.5f * quad + mdl.lp_const;
+}
+
 template <int N, int DQ, int M>
 __global__ void __launch_bounds__(BIG_NT)
 bpf_big_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const float* __restrict__ uptr, long long u_sB, long long u_sT,
@@ -186,32 +218,7 @@ bpf_big_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const float
       float ll = -__builtin_inff();
       if (valid) {
         const U32x2 ki = threefry_split(k0, k1, (uint32_t)i + 1u, (uint32_t)NP + 1u);
-        float x[N], q[DQ], xn[N];
-        BF_UNROLL for (int d = 0; d < N; ++d) x[d] = xa[(long long)i * N + d];
-        constexpr int h = (DQ + 1) / 2;
-        float zhi[h];
-        BF_UNROLL for (int d = 0; d < DQ; ++d) q[d] = 0.f;
-        BF_UNROLL for (int j = 0; j < h; ++j) {
-          const U32x2 o = threefry2x32(ki.x, ki.y, (uint32_t)j, (h + j < DQ) ? (uint32_t)(h + j) : 0u);
-          const float zj = bits_to_normal(o.x);
-          zhi[j] = (h + j < DQ) ? bits_to_normal(o.y) : 0.f;
-          BF_UNROLL for (int d = j; d < DQ; ++d) q[d] = fmaf(mdl.LQ[d * DQ + j], zj, q[d]);
-        }
-        BF_UNROLL for (int j = 0; h + j < DQ; ++j)
-          BF_UNROLL for (int d = h + j; d < DQ; ++d) q[d] = fmaf(mdl.LQ[d * DQ + h + j], zhi[j], q[d]);
-        BF_UNROLL for (int d = 0; d < DQ; ++d) q[d] = mdl.q0[d] + q[d];
-        dyn_value<N, DQ, M>(mdl, x, q, u0, xn);
-        BF_UNROLL for (int d = 0; d < N; ++d) xa[(long long)i * N + d] = xn[d];
-        float hx[M], zz[M];
-        emi_value<N, DQ, M>(mdl, xn, u0, hx);
-        float quad = 0.f;
-        BF_UNROLL for (int a = 0; a < M; ++a) {
-          float s = yv[a] - hx[a];
-          BF_UNROLL for (int cc = 0; cc < a; ++cc) s = fmaf(-mdl.LR[a * M + cc], zz[cc], s);
-          zz[a] = s * mdl.rdLR[a];
-          quad = fmaf(zz[a], zz[a], quad);
-        }
-        ll = -0.5f * quad + mdl.lp_const;
+        ll = propagate_particle<N, DQ, M>(mdl, ki, xa + (long long)i * N, u0, yv);
         gl[i] = ll;
       }
       const float cm = block_reduce(ll, nanmax);
@@ -225,6 +232,7 @@ bpf_big_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const float
       const int i = c * BIG_NT + tid;
       float e = 0.f;
       if (i < NP) {
+#pragma clang fp contract(off)
         e = expf(gl[i] - mx) * gw[i];
         gl[i] = e;
       }
@@ -240,6 +248,7 @@ bpf_big_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const float
       const int i = c * BIG_NT + tid;
       float w2 = 0.f;
       if (i < NP) {
+#pragma clang fp contract(off)  // the product is rounded before it enters the tree
         const float wn = gl[i] / tot;
         gl[i] = wn;
         w2 = wn * wn;

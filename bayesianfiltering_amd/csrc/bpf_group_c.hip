@@ -1,6 +1,6 @@
 // Instantiations of the bootstrap particle filter kernel (bpf_scan.hpp) for a slice of the
 // (n, dq, m) table; split over several translation units to build in parallel.
-#include "bpf_big.hpp"
+#include "bpf_wide.hpp"
 
 namespace bf {
 

@@ -362,11 +362,12 @@ static inline int launch_bpf_cfg(const BpfModel<N, DQ, M>* d_mdl, const bf_cstre
   return BF_OK;
 }
 
-extern int g_bpf_variant;  // tuning hook (bf_set_option "bpf_variant")
+extern int g_bpf_variant;   // tuning hook (bf_set_option "bpf_variant")
+extern int g_bpf_hbm_mode;  // bf_set_option "bpf_hbm_mode": 0 = choose, 1 = workgroup per trajectory, 2 = per chunk
 
-// bpf_big.hpp: particle counts beyond the in-register capacities (declared here, defined after the kernels there)
+// bpf_big.hpp / bpf_wide.hpp: particle counts beyond the in-register capacities (declared here, defined after the kernels there)
 template <int N, int DQ, int M>
-static inline int launch_bpf_big_dims(const BpfModel<N, DQ, M>* d_mdl, const bf_cstream* y, const bf_cstream* u, long long B,
+static inline int launch_bpf_hbm_dims(const BpfModel<N, DQ, M>* d_mdl, const bf_cstream* y, const bf_cstream* u, long long B,
                                       long long T, int NP, float ess, int resampler, const uint32_t key[2], const BpfCarry& cr,
                                       const BpfOut& out, hipStream_t stream);
 
@@ -401,7 +402,7 @@ static inline int launch_bpf_dims(const bf_bpf_model* bp, const bf_cstream* y, c
     // state dimension at a time so that CDF + tile stay within the LDS)
     if constexpr (N <= 4 && DQ <= 4) rc = launch_bpf_cfg<N, DQ, M, 16, 16>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
   }
-  else rc = launch_bpf_big_dims<N, DQ, M>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);  // particles in HBM (bpf_big.hpp)
+  else rc = launch_bpf_hbm_dims<N, DQ, M>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);  // particles in HBM (bpf_big.hpp, bpf_wide.hpp)
   hipError_t fe = hipFreeAsync(d_mdl, stream);
   if (rc != BF_OK) return rc;
   BF_HIP_CHECK(fe);

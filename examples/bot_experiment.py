@@ -9,7 +9,7 @@ simulated and filtered in one launch per filter.  Prints the RMSE table of :238-
 
 Differences from the reference script, by necessity: the functions come from the device registry instead of
 Python lambdas; the particle filter runs 4096 particles per trajectory by default (the reference: 50 000, which
---particles 50000 reproduces through the particles-in-HBM kernel, at ~10x the time per trajectory); emission noise R = 1e-4 I instead of
+--particles 50000 reproduces through the particles-in-HBM kernels); emission noise R = 1e-4 I instead of
 25e-6 I, where the reference's own GSF / UGSF return NaN (BOTExperiment.ipynb cell 7).
 
     python examples/bot_experiment.py [--nsim 100] [--steps 500] [--components 100]

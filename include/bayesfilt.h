@@ -117,7 +117,11 @@ int bf_device_count(void);
  *                   otherwise one of the compiled powers of two, e.g. 1, 2 or 4 at n = 4).
  *   "gsf_structured": 1 (default) lets bf_gsf_ekf_f32 use the structure-aware kernel instances
  *                   (banded Lorenz-96 Jacobian, selection emission) when the model qualifies;
- *                   0 forces the dense generic instances. */
+ *                   0 forces the dense generic instances.
+ *   "bpf_variant":  0 (default) / 1: workgroup geometry of the 4096-particle instance.
+ *   "bpf_hbm_mode": particle counts beyond the in-register capacities: 0 (default) = choose by batch
+ *                   size, 1 = one workgroup per trajectory, 2 = one workgroup per 1024-particle chunk
+ *                   (six launches per step; same results bit for bit). */
 int bf_set_option(const char* name, int value);
 
 /* Batched Kalman filter: B independent trajectories, one component each (K = 1), T steps.
@@ -256,7 +260,7 @@ typedef struct bf_bpf_out {
  * (inference.py:1330-1377) with _resample (utils.py:207-214).  One workgroup per
  * trajectory: N <= 4096 particles (16 384 for state / noise dimensions <= 4) stay in the workgroup's
  * registers; larger N up to 2^20 keep the particles in HBM scratch (stream-ordered allocation) and run
- * the same tree orders chunk by chunk.  key = {hi, lo} of jr.PRNGKey (used for every
+ * the same tree orders chunk by chunk (a workgroup per trajectory, or per chunk when B < 128).  key = {hi, lo} of jr.PRNGKey (used for every
  * trajectory unless carry->key_in is given).  resampler: 0 = multinomial inverse-CDF (the
  * reference's jr.choice), 1 = systematic. */
 int bf_bpf_f32(const bf_bpf_model* model, const bf_cstream* y, const bf_cstream* u, int64_t B, int64_t T, int32_t N,

@@ -203,3 +203,48 @@ def test_particles_in_hbm_path(N, resampler):
     assert np.max(np.abs(out["weights"].cpu().numpy()[:, 0] - ref["weights"][:, 0])) < 1e-7
     assert cm.rel_err(out["ess"].cpu().numpy()[:1], np.asarray(dbg["ess"])[:1]) < 1e-4
     assert bool(np.isfinite(out["mean"].cpu().numpy()).all())
+
+
+@pytest.mark.parametrize("N,resampler,B", [(20000, "multinomial", 1), (17000, "systematic", 3), (70000, "multinomial", 2)])
+def test_workgroup_per_chunk_equals_workgroup_per_trajectory(N, resampler, B):
+    """The two particles-in-HBM kernels (bpf_big.hpp: a workgroup per trajectory; bpf_wide.hpp: a workgroup per
+    1024-particle chunk, six launches per step) keep the same reduction / scan trees: identical weights, particles,
+    ancestors, ESS and evidence over steps that do and do not resample, chunked runs through the carry included."""
+    import bayesianfiltering_amd as bfa
+    from bayesianfiltering_amd import _lib
+    nl = bfa.nonlinearities
+    T = 6
+    h = nl.linear_emission(np.eye(3, dtype=F32))
+    pp = bfa.ParamsBPF(np.array([0.0, 1.0, 1.05], F32), np.eye(3, dtype=F32), nl.lorenz63(), np.zeros(3, F32),
+                       0.1 * np.eye(3, dtype=F32), h, np.zeros(3, F32), 4.0 * np.eye(3, dtype=F32),
+                       nl.gaussian_log_prob(h, 4.0 * np.eye(3, dtype=F32)))
+    rng = np.random.default_rng(N)
+    ys = (np.array([0.0, 1.0, 1.05], F32) + rng.normal(size=(B, T, 3))).astype(F32)
+    if B == 1:
+        ys = ys[0]
+    lib = _lib.load()
+    outs = []
+    try:
+        for mode in (1, 2):
+            _lib.check(lib.bf_set_option(b"bpf_hbm_mode", mode))
+            out = bfa.bootstrap_particle_filter(pp, ys, N, bfa.PRNGKey(5), None, 0.6, resampler=resampler, output="both",
+                                                return_ancestors=True)
+            outs.append({k: v.cpu().numpy() for k, v in out.items()})
+        # the per-chunk kernel in two pieces through the carry
+        first, carry = bfa.bootstrap_particle_filter(pp, ys[..., :4, :], N, bfa.PRNGKey(5), None, 0.6, resampler=resampler,
+                                                     output="both", return_carry=True)
+        second = bfa.bootstrap_particle_filter(pp, ys[..., 4:, :], N, None, None, 0.6, resampler=resampler, output="both",
+                                               carry=carry)
+    finally:
+        lib.bf_set_option(b"bpf_hbm_mode", 0)
+    a, b_ = outs
+    res = a["resampled"].reshape(-1)
+    assert 0 < res.sum() < res.size, res           # both branches exercised
+    for k in ("weights", "particles", "ancestors", "ess", "logz", "resampled"):
+        assert np.array_equal(a[k], b_[k]), k
+    assert cm.rel_err(b_["mean"], a["mean"]) < 1e-5
+    t_axis = a["weights"].ndim - 1
+    joined = np.concatenate([first["weights"].cpu().numpy(), second["weights"].cpu().numpy()], axis=t_axis)
+    assert np.array_equal(joined, b_["weights"])
+    joined = np.concatenate([first["particles"].cpu().numpy(), second["particles"].cpu().numpy()], axis=t_axis if B == 1 else t_axis)
+    assert np.array_equal(joined, b_["particles"])
