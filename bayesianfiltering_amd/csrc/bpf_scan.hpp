@@ -386,8 +386,13 @@ static inline int launch_bpf_dims(const bf_bpf_model* bp, const bf_cstream* y, c
     (void)hipFreeAsync(d_mdl, stream);
     BF_HIP_CHECK(e);
   }
+  // few trajectories with thousands of particles: one workgroup per trajectory would leave the chip idle (a step of the
+  // in-register kernel takes ~19 us per 1024 particles on its one CU); the workgroup-per-chunk kernels of bpf_wide.hpp
+  // spread the particles over the CUs at ~25 us of launches per step
+  const bool spread = NP > 2048 && B <= 32 && g_bpf_hbm_mode != 1;
   // smallest compiled particle capacity that holds NP
-  if (NP <= 64) rc = launch_bpf_cfg<N, DQ, M, 1, 1>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
+  if (spread) rc = launch_bpf_hbm_dims<N, DQ, M>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
+  else if (NP <= 64) rc = launch_bpf_cfg<N, DQ, M, 1, 1>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
   else if (NP <= 256) rc = launch_bpf_cfg<N, DQ, M, 1, 4>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
   else if (NP <= 1024) rc = launch_bpf_cfg<N, DQ, M, 1, 16>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
   else if (NP <= 4096) {
