@@ -85,41 +85,87 @@ __device__ __forceinline__ float rsqrt_newton(float d) {
   return fmaf(0.5f * y0, e0, y0);
 }
 
-template <bool PUBLISH, class LP>
-__device__ __forceinline__ void chol32_rows(float* a, float& rdv, int li, LP Lc, lds_i* progress) {
-  float rinv = rsqrt_newton(rdlane(a[0], 0));
-  static_for<0, 32>([&](auto J) {
+#ifndef BF_MFMA_POLL_SLEEP
+#define BF_MFMA_POLL_SLEEP 1  // x 64 cycles between polls of the progress counter
+#endif
+#ifndef BF_MFMA_PUB
+#define BF_MFMA_PUB 4  // columns per progress publication of the factorizing wave
+#endif
+
+// Software pipelining: the LDS round trip of column j + 1 (its write, and the broadcast reads of its
+// multipliers) is issued BEFORE the trailing update of column j: the look-ahead already brings a[j + 1] up to date, so
+// column j + 1 can be scaled and published one iteration early and its multipliers arrive while the 30 - j
+// multiply-adds of column j issue.  Two multiplier buffers alternate by column parity.
+template <bool PUBLISH, bool INVERT, class LP>
+__device__ __forceinline__ void chol32_rows_pipe(float* a, float& rdv, int li, LP Lc, lds_i* progress, float* x) {
+  float mult[2][32];
+  auto load_mult = [&](auto C, float* dst) {  // multipliers L[k][c], k >= c + 2, of column c from LDS
+    constexpr int c = decltype(C)::value;
+    constexpr int kq = (c + 2 + 3) / 4 * 4;
+    static_for<c + 2, (kq < 32 ? kq : 32)>([&](auto Kk) {
+      constexpr int k = decltype(Kk)::value;
+      dst[k] = Lc[32 * c + k];
+    });
+    static_for<kq / 4, 8>([&](auto Qd) {
+      constexpr int q = decltype(Qd)::value;
+      const v4f v = *reinterpret_cast<lds_f4*>(Lc + 32 * c + 4 * q);
+      dst[4 * q + 0] = v.x;
+      dst[4 * q + 1] = v.y;
+      dst[4 * q + 2] = v.z;
+      dst[4 * q + 3] = v.w;
+    });
+  };
+  float rinv = rsqrt_newton(rdlane(a[0], 0));  // 1 / L[j][j] of the column whose trailing update is running
+  float lj = a[0] * rinv;
+  rdv = (li == 0) ? rinv : rdv;
+  a[0] = lj;
+  Lc[li] = (li == 0) ? rinv : lj;
+  float l1 = rdlane(lj, 1);                     // L[j + 1][j]
+  a[1] = fmaf(-lj, l1, a[1]);
+  float rinv_n = rsqrt_newton(rdlane(a[1], 1));
+  wave_lds_order();
+  load_mult(std::integral_constant<int, 0>{}, mult[0]);
+  static_for<0, 31>([&](auto J) {
     constexpr int j = decltype(J)::value;
-    rdv = (li == j) ? rinv : rdv;
-    const float lj = a[j] * rinv;            // L[row][j] for row > j (rows < j: unused upper triangle)
-    a[j] = lj;
-    Lc[32 * j + li] = (li == j) ? rinv : lj;
-    if constexpr (PUBLISH && j % 4 == 3) {  // columns up to j are in LDS: let the inverting wave proceed
-      wave_lds_order();
-      *progress = j + 1;
-    }
-    if constexpr (j < 31) {
-      // look-ahead: row j + 1 takes its update through a lane broadcast and the next column's
-      // reciprocal square root starts at once, overlapping the LDS round trip of the other rows
-      a[j + 1] = fmaf(-lj, rdlane(lj, j + 1), a[j + 1]);
-      rinv = rsqrt_newton(rdlane(a[j + 1], j + 1));
-      wave_lds_order();
-      // rows up to the next multiple of four one by one, the rest as whole float4s
-      constexpr int kq = (j + 2 + 3) / 4 * 4;
-      static_for<j + 2, (kq < 32 ? kq : 32)>([&](auto Kk) {
-        constexpr int k = decltype(Kk)::value;
-        a[k] = fmaf(-lj, Lc[32 * j + k], a[k]);
+    float* cur = mult[j & 1];
+    float* nxt = mult[(j + 1) & 1];
+    // column j + 1: scale, publish
+    const float lj_n = a[j + 1] * rinv_n;
+    rdv = (li == j + 1) ? rinv_n : rdv;
+    a[j + 1] = lj_n;
+    Lc[32 * (j + 1) + li] = (li == j + 1) ? rinv_n : lj_n;
+    wave_lds_order();
+    if constexpr (PUBLISH && (j + 1) % BF_MFMA_PUB == BF_MFMA_PUB - 1) *progress = j + 2;
+    if constexpr (j < 30) load_mult(std::integral_constant<int, j + 1>{}, nxt);
+    // trailing update of column j with the multipliers loaded one iteration ago
+    static_for<j + 2, 32>([&](auto Kk) {
+      constexpr int k = decltype(Kk)::value;
+      a[k] = fmaf(-lj, cur[k], a[k]);
+    });
+    if constexpr (INVERT) {
+      // forward substitution for L^-1 on the same multipliers (lane = column of the inverse, x[r] = its row r):
+      // step j needs column j of L only, which is exactly what this iteration holds -- no second wave, no second
+      // set of LDS reads, and its multiply-adds fill the latency bubbles of the factorization chain
+      const float xj = x[j] * rinv;
+      x[j] = xj;
+      x[j + 1] = fmaf(-l1, xj, x[j + 1]);
+      static_for<j + 2, 32>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        x[r] = fmaf(-cur[r], xj, x[r]);
+        asm volatile("" : "+v"(x[r]));  // keep the update here (see invert_following)
       });
-      static_for<kq / 4, 8>([&](auto Qd) {
-        constexpr int q = decltype(Qd)::value;
-        const v4f v = *reinterpret_cast<lds_f4*>(Lc + 32 * j + 4 * q);
-        a[4 * q + 0] = fmaf(-lj, v.x, a[4 * q + 0]);
-        a[4 * q + 1] = fmaf(-lj, v.y, a[4 * q + 1]);
-        a[4 * q + 2] = fmaf(-lj, v.z, a[4 * q + 2]);
-        a[4 * q + 3] = fmaf(-lj, v.w, a[4 * q + 3]);
-      });
     }
+    float l1_n = 0.f;
+    if constexpr (j < 30) {  // look-ahead: row j + 2 of column j + 1, next reciprocal square root
+      l1_n = rdlane(lj_n, j + 2);
+      a[j + 2] = fmaf(-lj_n, l1_n, a[j + 2]);
+    }
+    rinv = rinv_n;
+    if constexpr (j < 30) rinv_n = rsqrt_newton(rdlane(a[j + 2], j + 2));
+    l1 = l1_n;
+    lj = lj_n;
   });
+  if constexpr (INVERT) x[31] *= rinv;  // rinv is 1 / L[31][31] after the last iteration
 }
 
 // Phase C of the scan as out-of-line functions: everything they touch lives in LDS, so the call costs
@@ -134,7 +180,23 @@ __device__ __attribute__((noinline)) void factor_publish(lds_f* sS, lds_f* Lc, l
   float a[32];
   BF_UNROLL for (int k = 0; k < 32; ++k) a[k] = sS[lr * PS + k] + 1e-6f;  // psd_solve's jitter on every entry
   float rdv = 0.f;
-  chol32_rows<true>(a, rdv, lr, Lc, progress);
+  chol32_rows_pipe<true, false>(a, rdv, lr, Lc, progress, nullptr);
+}
+
+// chol(S + 1e-6) and its inverse in ONE wave: sLi[i][c] = (L^-1)[i][c] (lane (l & 31) holds column c).  The factor
+// columns still pass through Lc (the broadcast of the multipliers), nothing polls.  Measured (-DBF_MFMA_FUSED_INVERSE):
+// phase C drops from 9.3 to 6.7 us, yet the scan is 7 % SLOWER (2.98e7 against 3.20e7 steps/s): the two workgroups of
+// a CU alternate -- one factorizes while the other runs its MFMA phases -- and a shorter phase C only makes their MFMA
+// phases collide.  Kept as the starting point for a design with a third workgroup per CU.
+__device__ __attribute__((noinline)) void factor_invert(lds_f* sS, lds_f* Lc, lds_f* sLi, int lane) {
+  constexpr int PS = 33;
+  const int lr = lane & 31;
+  float a[32], x[32];
+  BF_UNROLL for (int k = 0; k < 32; ++k) a[k] = sS[lr * PS + k] + 1e-6f;  // psd_solve's jitter on every entry
+  BF_UNROLL for (int i = 0; i < 32; ++i) x[i] = (lr == i) ? 1.f : 0.f;
+  float rdv = 0.f;
+  chol32_rows_pipe<false, true>(a, rdv, lr, Lc, nullptr, x);
+  if (lane < 32) BF_UNROLL for (int i = 0; i < 32; ++i) sLi[i * PS + lr] = x[i];
 }
 
 // The inverse of that factor, computed by another wave while the factorization is still running:
@@ -146,26 +208,51 @@ __device__ __attribute__((noinline)) void invert_following(lds_f* Lc, lds_i* pro
   const int lr = lane & 31;
   float x[32];
   BF_UNROLL for (int i = 0; i < 32; ++i) x[i] = (lr == i) ? 1.f : 0.f;
-  int seen = 0;
-  static_for<0, 32>([&](auto I) {
-    constexpr int i = decltype(I)::value;
-    if constexpr (i % 4 == 0) {  // columns are published four at a time
-      while (seen < i + 4) seen = *(volatile lds_i*)progress;  // wave-uniform; the producer always reaches 32
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  // column i of the factor (reciprocal diagonal + the multipliers below it) is loaded while column i - 1 is applied:
+  // two buffers by column parity, fenced per column so that the loads of a whole block are not hoisted together
+  // (they were: 248 VGPRs and spills to scratch on the critical path)
+  float mult[2][32], dg[2];
+  auto wait_for = [&](int cols) {  // wave-uniform; the producer always reaches 32
+    int seen = *(volatile lds_i*)progress;
+    while (seen < cols) {
+      __builtin_amdgcn_s_sleep(BF_MFMA_POLL_SLEEP);  // a tight poll floods the LDS queue the factorizing waves live on
+      seen = *(volatile lds_i*)progress;
     }
-    x[i] *= Lc[32 * i + i];  // 1 / L[i][i]
-    constexpr int rq = (i + 1 + 3) / 4 * 4;
-    static_for<i + 1, (rq < 32 ? rq : 32)>([&](auto R) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+  auto load_col = [&](auto C, float* dst, float& d) {
+    constexpr int c = decltype(C)::value;
+    d = Lc[32 * c + c];  // 1 / L[c][c]
+    constexpr int rq = (c + 1 + 3) / 4 * 4;
+    static_for<c + 1, (rq < 32 ? rq : 32)>([&](auto R) {
       constexpr int r = decltype(R)::value;
-      x[r] = fmaf(-Lc[32 * i + r], x[i], x[r]);
+      dst[r] = Lc[32 * c + r];
     });
     static_for<rq / 4, 8>([&](auto Qd) {
       constexpr int q = decltype(Qd)::value;
-      const v4f v = *reinterpret_cast<lds_f4*>(Lc + 32 * i + 4 * q);
-      x[4 * q + 0] = fmaf(-v.x, x[i], x[4 * q + 0]);
-      x[4 * q + 1] = fmaf(-v.y, x[i], x[4 * q + 1]);
-      x[4 * q + 2] = fmaf(-v.z, x[i], x[4 * q + 2]);
-      x[4 * q + 3] = fmaf(-v.w, x[i], x[4 * q + 3]);
+      const v4f v = *reinterpret_cast<lds_f4*>(Lc + 32 * c + 4 * q);
+      dst[4 * q + 0] = v.x;
+      dst[4 * q + 1] = v.y;
+      dst[4 * q + 2] = v.z;
+      dst[4 * q + 3] = v.w;
+    });
+  };
+  wait_for(BF_MFMA_PUB);
+  load_col(std::integral_constant<int, 0>{}, mult[0], dg[0]);
+  static_for<0, 32>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    if constexpr (i < 31) {
+      if constexpr ((i + 1) % BF_MFMA_PUB == 0) wait_for(i + 1 + BF_MFMA_PUB);
+      load_col(std::integral_constant<int, i + 1>{}, mult[(i + 1) & 1], dg[(i + 1) & 1]);
+    }
+    const float* cur = mult[i & 1];
+    x[i] *= dg[i & 1];
+    static_for<i + 1, 32>([&](auto R) {
+      constexpr int r = decltype(R)::value;
+      x[r] = fmaf(-cur[r], x[i], x[r]);
+      // pin the update here: without it every multiply-add sinks below the loads of ALL later columns (the
+      // loads have no ordering against pure arithmetic), which is what cost 248 VGPRs and the spills
+      asm volatile("" : "+v"(x[r]) : : "memory");
     });
   });
   if (lane < 32) BF_UNROLL for (int i = 0; i < 32; ++i) sLi[i * PS + lr] = x[i];
@@ -178,7 +265,7 @@ __device__ __attribute__((noinline)) float factor_loglik(lds_f* sS, lds_f* Lc, l
   float a[32];
   BF_UNROLL for (int k = 0; k < 32; ++k) a[k] = sS[lr * PS + k];
   float rdv = 0.f;
-  chol32_rows<false>(a, rdv, lr, Lc, nullptr);
+  chol32_rows_pipe<false, false>(a, rdv, lr, Lc, nullptr, nullptr);
   // z = L^-1 v by forward substitution across lanes; lane i carries the running residual of row i
   float acc = sv[lr], quad = 0.f, dprod = 1.f;
   static_for<0, 32>([&](auto Kk) {
@@ -277,9 +364,13 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
     float ll = 0.f;
     if (wave == 0) {
       // -(K S) is dead between phases H and G: scratch for the factor columns of both factorizations
+#ifndef BF_MFMA_FUSED_INVERSE
       factor_publish((lds_f*)sS, (lds_f*)sKS, (lds_i*)sflag, lane);
     } else if (wave == 1) {
       invert_following((lds_f*)sKS, (lds_i*)sflag, (lds_f*)sLi, lane);
+#else
+      factor_invert((lds_f*)sS, (lds_f*)sKS, (lds_f*)sLi, lane);
+#endif
     } else if (wave == 3) {
       ll = factor_loglik((lds_f*)sS, (lds_f*)(sKS + 1024), (lds_f*)sv, lane);
     }
