@@ -175,6 +175,7 @@ __device__ __forceinline__ void chol32_rows_pipe(float* a, float& rdv, int li, L
 // chol(S + 1e-6), published four columns at a time: Lc[32 j + i] = L[i][j] (1 / L[j][j] on the
 // diagonal) and *progress = number of finished columns
 __device__ __attribute__((noinline)) void factor_publish(lds_f* sS, lds_f* Lc, lds_i* progress, int lane) {
+  if (lane >= 32) return;  // rows live in lanes 0..31: the upper half would only double the LDS return traffic
   constexpr int PS = 33;
   const int lr = lane & 31;
   float a[32];
@@ -204,6 +205,7 @@ __device__ __attribute__((noinline)) void factor_invert(lds_f* sS, lds_f* Lc, ld
 // one by a block of columns (it polls *progress) and the two serial chains overlap instead of adding
 // up.  sLi[i][c] = (L^-1)[i][c]; lane (l & 31) holds column c = l & 31.
 __device__ __attribute__((noinline)) void invert_following(lds_f* Lc, lds_i* progress, lds_f* sLi, int lane) {
+  if (lane >= 32) return;  // rows live in lanes 0..31: the upper half would only double the LDS return traffic
   constexpr int PS = 33;
   const int lr = lane & 31;
   float x[32];
@@ -260,6 +262,7 @@ __device__ __attribute__((noinline)) void invert_following(lds_f* Lc, lds_i* pro
 
 // chol(S) (no jitter), z = L^-1 v, log N(v; 0, S) -- inference.py:104, :24
 __device__ __attribute__((noinline)) float factor_loglik(lds_f* sS, lds_f* Lc, lds_f* sv, int lane) {
+  if (lane >= 32) return 0.f;  // rows live in lanes 0..31 (the caller reads the result in lane 0)
   constexpr int PS = 33;
   const int lr = lane & 31;
   float a[32];
