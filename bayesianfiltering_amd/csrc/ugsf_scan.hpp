@@ -144,8 +144,15 @@ __device__ __forceinline__ float ukf_condition_on(const UkfModel<N, DQ, M, DR>& 
   sym_sqrt<N>(sP);
   float h0[M], mu[M];
   ukf_emi(mdl, m, mdl.r0, u0, h0);
-  // visits the 2 L sigma points in the order of utils.py:251-253: the plus rows, then the minus rows
-  auto for_points = [&](auto&& fn) __attribute__((always_inline)) {
+  // visits the 2 L sigma points in the order of utils.py:251-253: the plus rows, then the minus rows.  The points are
+  // needed twice (mean, then covariances about the mean): small problems keep the 2 L images h(x) in registers, large
+  // ones push the points through h again (2 L M floats would not fit)
+  constexpr int NPTS = 2 * (N + DR);
+  constexpr bool STORE = NPTS * M <= 96;
+  float img[STORE ? NPTS * M : 1];
+  auto for_points = [&](auto Eval, auto&& fn) __attribute__((always_inline)) {
+    constexpr bool eval = decltype(Eval)::value || !STORE;
+    int pt = 0;
     BF_UNROLL for (int sg = 0; sg < 2; ++sg) {
       const float cs = sg == 0 ? mdl.c_u : -mdl.c_u;
       BF_UNROLL for (int j = 0; j < N; ++j) {
@@ -154,25 +161,37 @@ __device__ __forceinline__ float ukf_condition_on(const UkfModel<N, DQ, M, DR>& 
           dx[i] = cs * sP[j * N + i];
           x[i] = m[i] + dx[i];
         }
-        ukf_emi(mdl, x, mdl.r0, u0, yy);
+        if constexpr (eval) {
+          ukf_emi(mdl, x, mdl.r0, u0, yy);
+          if constexpr (STORE) BF_UNROLL for (int a = 0; a < M; ++a) img[pt * M + a] = yy[a];
+        } else {
+          BF_UNROLL for (int a = 0; a < M; ++a) yy[a] = img[pt * M + a];
+        }
         fn(yy, dx, true);
+        ++pt;
       }
       BF_UNROLL for (int j = 0; j < DR; ++j) {
         float r[DR], dx[N], yy[M];
         BF_UNROLL for (int i = 0; i < DR; ++i) r[i] = mdl.r0[i] + cs * mdl.sR[j * DR + i];
         BF_UNROLL for (int i = 0; i < N; ++i) dx[i] = 0.f;
-        ukf_emi(mdl, m, r, u0, yy);
+        if constexpr (eval) {
+          ukf_emi(mdl, m, r, u0, yy);
+          if constexpr (STORE) BF_UNROLL for (int a = 0; a < M; ++a) img[pt * M + a] = yy[a];
+        } else {
+          BF_UNROLL for (int a = 0; a < M; ++a) yy[a] = img[pt * M + a];
+        }
         fn(yy, dx, false);
+        ++pt;
       }
     }
   };
   BF_UNROLL for (int a = 0; a < M; ++a) mu[a] = 0.f;
-  for_points([&](const float* yy, const float*, bool) { BF_UNROLL for (int a = 0; a < M; ++a) mu[a] += yy[a]; });
+  for_points(std::true_type{}, [&](const float* yy, const float*, bool) { BF_UNROLL for (int a = 0; a < M; ++a) mu[a] += yy[a]; });
   BF_UNROLL for (int a = 0; a < M; ++a) mu[a] = mu[a] * mdl.ws_u + h0[a] * mdl.w0_u;
   float S[M * M], C[M * N];
   BF_UNROLL for (int i = 0; i < M * M; ++i) S[i] = 0.f;
   BF_UNROLL for (int i = 0; i < M * N; ++i) C[i] = 0.f;
-  for_points([&](const float* yy, const float* dx, bool moved) {
+  for_points(std::false_type{}, [&](const float* yy, const float* dx, bool moved) {
     float dy[M];
     BF_UNROLL for (int a = 0; a < M; ++a) dy[a] = yy[a] - mu[a];
     BF_UNROLL for (int a = 0; a < M; ++a) BF_UNROLL for (int c2 = 0; c2 < M; ++c2) S[a * M + c2] = fmaf(dy[a], dy[c2], S[a * M + c2]);
@@ -217,28 +236,45 @@ __device__ __forceinline__ void ukf_predict(const UkfModel<N, DQ, M, DR>& mdl, f
   sym_sqrt<N>(sP);
   float f0[N], mu[N];
   ukf_dyn(mdl, m, mdl.q0, u0, f0);
-  auto for_points = [&](auto&& fn) __attribute__((always_inline)) {
+  constexpr int NPTS = 2 * (N + DQ);
+  constexpr bool STORE = NPTS * N <= 96;  // keep the 2 L images f(x) in registers instead of evaluating f twice
+  float img[STORE ? NPTS * N : 1];
+  auto for_points = [&](auto Eval, auto&& fn) __attribute__((always_inline)) {
+    constexpr bool eval = decltype(Eval)::value || !STORE;
+    int pt = 0;
     BF_UNROLL for (int sg = 0; sg < 2; ++sg) {
       const float cs = sg == 0 ? mdl.c_p : -mdl.c_p;
       BF_UNROLL for (int j = 0; j < N; ++j) {
         float x[N], xx[N];
-        BF_UNROLL for (int i = 0; i < N; ++i) x[i] = m[i] + cs * sP[j * N + i];
-        ukf_dyn(mdl, x, mdl.q0, u0, xx);
+        if constexpr (eval) {
+          BF_UNROLL for (int i = 0; i < N; ++i) x[i] = m[i] + cs * sP[j * N + i];
+          ukf_dyn(mdl, x, mdl.q0, u0, xx);
+          if constexpr (STORE) BF_UNROLL for (int i = 0; i < N; ++i) img[pt * N + i] = xx[i];
+        } else {
+          BF_UNROLL for (int i = 0; i < N; ++i) xx[i] = img[pt * N + i];
+        }
         fn(xx);
+        ++pt;
       }
       BF_UNROLL for (int j = 0; j < DQ; ++j) {
         float q[DQ], xx[N];
-        BF_UNROLL for (int i = 0; i < DQ; ++i) q[i] = mdl.q0[i] + cs * mdl.sQ[j * DQ + i];
-        ukf_dyn(mdl, m, q, u0, xx);
+        if constexpr (eval) {
+          BF_UNROLL for (int i = 0; i < DQ; ++i) q[i] = mdl.q0[i] + cs * mdl.sQ[j * DQ + i];
+          ukf_dyn(mdl, m, q, u0, xx);
+          if constexpr (STORE) BF_UNROLL for (int i = 0; i < N; ++i) img[pt * N + i] = xx[i];
+        } else {
+          BF_UNROLL for (int i = 0; i < N; ++i) xx[i] = img[pt * N + i];
+        }
         fn(xx);
+        ++pt;
       }
     }
   };
   BF_UNROLL for (int i = 0; i < N; ++i) mu[i] = 0.f;
-  for_points([&](const float* xx) { BF_UNROLL for (int i = 0; i < N; ++i) mu[i] += xx[i]; });
+  for_points(std::true_type{}, [&](const float* xx) { BF_UNROLL for (int i = 0; i < N; ++i) mu[i] += xx[i]; });
   BF_UNROLL for (int i = 0; i < N; ++i) mu[i] = mu[i] * mdl.ws_p + f0[i] * mdl.w0_p;
   BF_UNROLL for (int i = 0; i < EP; ++i) P[i] = 0.f;
-  for_points([&](const float* xx) {
+  for_points(std::false_type{}, [&](const float* xx) {
     float d[N];
     BF_UNROLL for (int i = 0; i < N; ++i) d[i] = xx[i] - mu[i];
     BF_UNROLL for (int i = 0; i < N; ++i) BF_UNROLL for (int j = 0; j < N; ++j) P[i * N + j] = fmaf(d[i], d[j], P[i * N + j]);
