@@ -84,11 +84,14 @@ __device__ __forceinline__ void dyn_linearize(const EkfModel<N, M>& p, const flo
         BF_UNROLL for (int i = 0; i < 16; ++i) J[i] = 0.f;
         const float s2 = x[1] * x[1] + x[3] * x[3];
         const float nrm = sqrtf(s2);
+        // the two turn matrices differ in the sign of the angle only: one sincos serves both (sin is odd, cos even)
+        float sn0, cs0;
+        sincosf(dt * (0.1f * acc / nrm), &sn0, &cs0);
         BF_UNROLL for (int sgn = 0; sgn < 2; ++sgn) {
           const float cc = sgn == 0 ? c1 : c2;
           const float a = sgn == 0 ? acc : -acc;
           const float om = 0.1f * a / nrm;
-          const float sn = sinf(dt * om), cs = cosf(dt * om);
+          const float sn = sgn == 0 ? sn0 : -sn0, cs = cs0;
           const float so = sn / om, co = (1.f - cs) / om;
           const float Fm[16] = {1, so, 0, -co, 0, cs, 0, -sn, 0, co, 1, so, 0, sn, 0, cs};
           const float dso = (dt * cs * om - sn) / (om * om);          // d(sn/om)/d om

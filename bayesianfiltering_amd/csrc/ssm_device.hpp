@@ -56,10 +56,13 @@ __device__ __forceinline__ void dyn_value_t(const MDL& p, const float* x, const 
         const float c0 = 0.5f * (u0 - 1.f) * (u0 - 2.f), c1 = -u0 * (u0 - 2.f), c2 = 0.5f * u0 * (u0 - 1.f);
         float Mx[16] = {c0, c0 * dt, 0, 0, 0, c0, 0, 0, 0, 0, c0, c0 * dt, 0, 0, 0, c0};
         const float nrm = sqrtf(x[1] * x[1] + x[3] * x[3]);
+        // the two turn matrices differ in the sign of the angle only: one sincos serves both (sin is odd, cos even)
+        float sn0, cs0;
+        sincosf(dt * (0.1f * acc / nrm), &sn0, &cs0);
         BF_UNROLL for (int sgn = 0; sgn < 2; ++sgn) {
           const float cc = sgn == 0 ? c1 : c2;
           const float om = 0.1f * (sgn == 0 ? acc : -acc) / nrm;
-          const float sn = sinf(dt * om), cs = cosf(dt * om);
+          const float sn = sgn == 0 ? sn0 : -sn0, cs = cs0;
           const float so = sn / om, co = (1.f - cs) / om;
           const float Fm[16] = {1, so, 0, -co, 0, cs, 0, -sn, 0, co, 1, so, 0, sn, 0, cs};
           BF_UNROLL for (int i = 0; i < 16; ++i) Mx[i] += cc * Fm[i];
