@@ -108,14 +108,21 @@ __device__ __forceinline__ float propagate_particle(const BpfModel<N, DQ, M>& md
   BF_UNROLL for (int d = 0; d < N; ++d) xp[d] = xn[d];
   float hx[M], zz[M];
   emi_value<N, DQ, M>(mdl, xn, u0, hx);
-  float quad = 0.f;
+  float quad = 0.f, lsc = 0.f;
   BF_UNROLL for (int a = 0; a < M; ++a) {
     float s = yv[a] - hx[a];
+    if constexpr (N == M) {
+      if (mdl.emi_id == EMI_STOCH_VOL) {  // state-dependent covariance M R M^T (ssm_device.hpp)
+        const float d = sv_scale(mdl, xn[a], u0);
+        s /= d;
+        lsc += logf(d);
+      }
+    }
     BF_UNROLL for (int cc = 0; cc < a; ++cc) s = fmaf(-mdl.LR[a * M + cc], zz[cc], s);
     zz[a] = s * mdl.rdLR[a];
     quad = fmaf(zz[a], zz[a], quad);
   }
-  return -0.5f * quad + mdl.lp_const;
+  return -0.5f * quad + mdl.lp_const - lsc;
 }
 
 template <int N, int DQ, int M>

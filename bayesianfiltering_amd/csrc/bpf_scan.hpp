@@ -250,14 +250,21 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
       } else {
         emi_value<N, DQ, M>(mdl, xn, u0, hx);
       }
-      float quad = 0.f;
+      float quad = 0.f, lsc = 0.f;
       BF_UNROLL for (int a = 0; a < M; ++a) {
         float s = yv[a] - hx[a];
+        if constexpr (N == M) {
+          if (mdl.emi_id == EMI_STOCH_VOL) {  // state-dependent covariance M R M^T (ssm_device.hpp)
+            const float d = sv_scale(mdl, xn[a], u0);
+            s /= d;
+            lsc += logf(d);
+          }
+        }
         if (!mdl.lr_diag) BF_UNROLL for (int c = 0; c < a; ++c) s = fmaf(-mdl.LR[a * M + c], zz[c], s);
         zz[a] = s * mdl.rdLR[a];
         quad = fmaf(zz[a], zz[a], quad);
       }
-      ll[p] = valid[p] ? (-0.5f * quad + mdl.lp_const) : -__builtin_inff();
+      ll[p] = valid[p] ? (-0.5f * quad + mdl.lp_const - lsc) : -__builtin_inff();
       // one particle at a time: interleaving the PPT independent Threefry / erfinv chains overruns the
       // 128-VGPR budget of the 1024-thread geometry and spills
       __builtin_amdgcn_sched_barrier(0);

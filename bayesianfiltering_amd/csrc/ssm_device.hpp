@@ -118,9 +118,27 @@ __device__ __forceinline__ void emi_mean_t(const MDL& p, const float* x, float u
   }
 }
 
-// mean of the emission density: h(x, r_eval, u) for the registry emissions with constant H_r
+// The stochastic-volatility emission h(x, r, u) = M(x, u) r + (1 - u) c x with M = diag(u beta exp(x / sigma) + (1 - u))
+// (glmsv, docs/experiments/adaptive_experiment.py:54) has the state-dependent log-density
+// MVN(h(x, r_eval, u), M R M^T).log_prob(y) (lmsvlp, :55-57).  chol(M R M^T) = M chol(R) for the positive diagonal M:
+// the residual is divided by the diagonal of M before the constant factor's forward substitution, and sum log M_ii
+// joins the log-determinant.
+template <class MDL>
+__device__ __forceinline__ float sv_scale(const MDL& p, float xa, float u0) {
+  return u0 * p.eth[1] * expf(xa / p.eth[0]) + (1.f - u0);
+}
+
+// mean of the emission density: h(x, r_eval, u) for the registry emissions with constant H_r (hb = H_r r_eval), and
+// for the stochastic-volatility emission (hb = r_eval)
 template <int N, int DQ, int M>
 __device__ __forceinline__ void emi_value(const BpfModel<N, DQ, M>& p, const float* x, float u0, float* hx) {
+  if constexpr (N == M) {
+    if (p.emi_id == EMI_STOCH_VOL) {
+      BF_UNROLL for (int a = 0; a < M; ++a)
+        hx[a] = u0 * p.eth[1] * expf(x[a] / p.eth[0]) * p.hb[a] + (1.f - u0) * (p.eth[2] * x[a] + p.hb[a]);
+      return;
+    }
+  }
   emi_mean_t<N, M>(p, x, u0, hx);
   BF_UNROLL for (int a = 0; a < M; ++a) hx[a] += p.hb[a];
 }
@@ -206,8 +224,13 @@ static inline int fill_bpf_model(const bf_bpf_model* bp, BpfModel<N, DQ, M>& e) 
       if (M != 1 || dr != 1 || p->n_emi_theta != 1) return set_error(BF_EINVAL, "quadratic: m = dr = 1");
       e.eth[0] = th[0];
       break;
+    case EMI_STOCH_VOL:
+      if (N != M || dr != M || p->n_emi_theta != 3) return set_error(BF_EINVAL, "stoch_vol: n = m = dr, theta = (sigma, beta, c)");
+      for (int i = 0; i < 3; ++i) e.eth[i] = th[i];
+      for (int i = 0; i < M * dr; ++i) D[i] = (i / dr == i % dr) ? 1.f : 0.f;  // hb = r_eval itself
+      break;
     default:
-      return set_error(BF_EUNSUPPORTED, "emission function id %d has no Gaussian log-density with constant covariance", p->emi_id);
+      return set_error(BF_EUNSUPPORTED, "emission function id %d has no Gaussian log-density on the device", p->emi_id);
   }
   for (int i = 0; i < M; ++i) {
     float s = 0.f;

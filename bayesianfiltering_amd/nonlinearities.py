@@ -180,7 +180,32 @@ class GaussianLogProb:
 
 
 def gaussian_log_prob(emission_function, covariance, r_eval=None):
+    if getattr(emission_function, "fn_id", None) == EMI_STOCH_VOL:
+        raise ValueError("the stochastic-volatility emission has a state-dependent noise scale: use stoch_vol_log_prob "
+                         "(the reference's lmsvlp), not a constant-covariance Gaussian")
     return GaussianLogProb(emission_function, covariance, r_eval)
+
+
+class StochVolLogProb(GaussianLogProb):
+    """``lmsvlp`` of docs/experiments/adaptive_experiment.py:55-57: ``MVN(loc=glmsv(x, r0, u),
+    covariance_matrix=M R M^T).log_prob(y)`` with ``M = u beta diag(exp(x / sigma)) + (1 - u) I`` -- the emission
+    log-density of the stochastic-volatility model, whose noise scale depends on the state."""
+
+    def __call__(self, x, y, u):
+        x = np.asarray(x, dtype=np.float64)
+        sigma, beta, _ = (float(v) for v in self.emission_function.theta)
+        uu = float(np.asarray(u).reshape(-1)[0])
+        d = uu * beta * np.exp(x / sigma) + (1.0 - uu)
+        mu = self.emission_function(x, self.r_eval, uu)
+        L = np.linalg.cholesky((d[:, None] * self.covariance.astype(np.float64)) * d[None, :])
+        z = np.linalg.solve(L, np.asarray(y, dtype=np.float64) - mu)
+        return F32(-0.5 * z @ z - np.log(np.diag(L)).sum() - 0.5 * len(z) * np.log(2 * np.pi))
+
+
+def stoch_vol_log_prob(emission_function, covariance, r_eval=None):
+    if getattr(emission_function, "fn_id", None) != EMI_STOCH_VOL:
+        raise ValueError("stoch_vol_log_prob needs the stoch_vol emission function")
+    return StochVolLogProb(emission_function, covariance, r_eval)
 
 
 def require_device_function(fn, kind, what):

@@ -225,7 +225,8 @@ typedef struct bf_bpf_model {
   bf_model ssm;
   const float* m0;     /* [n]      */
   const float* P0;     /* [n,n]    */
-  const float* lp_cov; /* [m,m] covariance of the emission log-density          */
+  const float* lp_cov; /* [m,m] covariance R of the emission log-density (the stochastic-volatility
+                        * emission uses M(x,u) R M(x,u)^T, adaptive_experiment.py:55-57)          */
   const float* r_eval; /* [dr] noise value h is evaluated at (NULL = zeros)     */
 } bf_bpf_model;
 

@@ -589,6 +589,23 @@ class GaussianEmissionLogProb:
         return mvn_log_prob(self.hn.value(np.asarray(x, dtype=F32), self.r_eval, u), self.R, y)
 
 
+class StochVolEmissionLogProb:
+    """lmsvlp (docs/experiments/adaptive_experiment.py:55-57): MVN(loc=glmsv(x, r0, u), covariance_matrix=M R M^T)
+    .log_prob(y) with M = u beta diag(exp(x / sigma)) + (1 - u) I, the noise Jacobian of the stochastic-volatility
+    emission (models.StochVol.jac_noise)."""
+
+    def __init__(self, hn, R, r_eval=None):
+        self.hn = hn
+        self.R = np.asarray(R, dtype=F32)
+        self.r_eval = np.zeros(hn.noise_dim, dtype=F32) if r_eval is None else np.asarray(r_eval, dtype=F32)
+
+    def __call__(self, x, y, u):
+        x = np.asarray(x, dtype=F32)
+        Mx = self.hn.jac_noise(x, self.r_eval, u)
+        cov = _mm(_mm(Mx, self.R), Mx.T)
+        return mvn_log_prob(self.hn.value(x, self.r_eval, u), cov, y)
+
+
 def sample_dynamics_distribution(params, key, x, u, cholQ=None):
     """models.py:82-84: q = MVN(q0, Q).sample(seed=key); return f(x, q, u)."""
     if cholQ is None:

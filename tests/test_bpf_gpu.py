@@ -248,3 +248,60 @@ def test_workgroup_per_chunk_equals_workgroup_per_trajectory(N, resampler, B):
     assert np.array_equal(joined, b_["weights"])
     joined = np.concatenate([first["particles"].cpu().numpy(), second["particles"].cpu().numpy()], axis=t_axis if B == 1 else t_axis)
     assert np.array_equal(joined, b_["particles"])
+
+
+@pytest.mark.parametrize("N,n", [(64, 3), (300, 2), (5000, 3)])
+def test_stochastic_volatility_log_density(N, n):
+    """The reference's adaptive experiment (docs/experiments/adaptive_experiment.py:47-57, :150-164): linear dynamics,
+    emission u beta exp(x / sigma) r + (1 - u)(0.1 x + r) switched on half-way by the input, and the state-dependent
+    log-density lmsvlp = MVN(glmsv(x, r0, u), M R M^T).  In-register kernel (N = 64, 300) and workgroup-per-chunk
+    kernels (N = 5000): ancestors bit-exact, particles / weights to rounding."""
+    bfa, nl = _bfa()
+    T = 12
+    Phi = (0.8 * np.eye(n)).astype(F32)
+    Q = (2.0 * np.eye(n)).astype(F32)
+    R = (1e-1 * np.eye(n) + 0.02).astype(F32)              # a full R: exercises the forward substitution
+    r0 = np.zeros(n, F32)
+    u = np.array([0] * (T // 2) + [1] * (T - T // 2), F32)
+    hn = om.StochVol(n)
+    po = go.ParamsBPF(np.zeros(n, F32), np.eye(n, dtype=F32), om.Linear(Phi), np.zeros(n, F32), Q, hn, r0, R,
+                      go.StochVolEmissionLogProb(hn, R))
+    h = nl.stoch_vol(n)
+    pp = bfa.ParamsBPF(np.zeros(n, F32), np.eye(n, dtype=F32), nl.linear_dynamics(Phi), np.zeros(n, F32), Q, h, r0, R,
+                       nl.stoch_vol_log_prob(h, R))
+    ys = go.sample_ssm(go.ParamsNLSSM(*po[:8]), otf.PRNGKey(21), T, u.reshape(T, 1))[1]
+    key = otf.PRNGKey(4)
+    if N <= 300:
+        ref, dbg = go.bootstrap_particle_filter(po, ys, N, key=key, inputs=u.reshape(T, 1), debug=True)
+        out = bfa.bootstrap_particle_filter(pp, ys, N, key, u, output="both", return_ancestors=True)
+        assert np.array_equal(out["resampled"].cpu().numpy() > 0.5, dbg["resampled"])
+        assert dbg["resampled"].any()
+        assert np.array_equal(out["ancestors"].cpu().numpy().T, dbg["ancestors"])
+        assert cm.rel_err(out["particles"].cpu().numpy(), ref["particles"]) < 1e-5
+        assert np.max(np.abs(out["weights"].cpu().numpy() - ref["weights"])) < 2e-6
+        assert cm.rel_err(out["ess"].cpu().numpy(), dbg["ess"]) < 1e-4
+    else:
+        # the particles-in-HBM kernels against the in-register kernel (same trees; bpf_hbm_mode 1 keeps N = 5000 in one
+        # workgroup's registers only when it fits -- n = 3 does, 16 particles per thread)
+        from bayesianfiltering_amd import _lib
+        lib = _lib.load()
+        outs = []
+        try:
+            for mode in (1, 2):
+                _lib.check(lib.bf_set_option(b"bpf_hbm_mode", mode))
+                o = bfa.bootstrap_particle_filter(pp, ys, N, key, u, output="both", return_ancestors=True)
+                outs.append({k: v.cpu().numpy() for k, v in o.items()})
+        finally:
+            lib.bf_set_option(b"bpf_hbm_mode", 0)
+        a, b_ = outs
+        assert (a["ancestors"] == b_["ancestors"]).mean() > 0.999
+        assert cm.rel_err(b_["ess"], a["ess"]) < 1e-4
+        assert bool(np.isfinite(b_["mean"]).all())
+
+
+def test_constant_covariance_log_prob_rejects_stochastic_volatility():
+    bfa, nl = _bfa()
+    with pytest.raises(ValueError):
+        nl.gaussian_log_prob(nl.stoch_vol(3), np.eye(3, dtype=F32))
+    with pytest.raises(ValueError):
+        nl.stoch_vol_log_prob(nl.linear_emission(np.eye(3, dtype=F32)), np.eye(3, dtype=F32))

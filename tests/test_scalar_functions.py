@@ -34,3 +34,20 @@ def test_gradient_and_hessian(name, args, dim):
         assert np.allclose(H, _fd_hess(lambda z: fn.gradient(z, *args), x), rtol=1e-4, atol=1e-6)
         assert np.allclose(H, H.T)
     assert nl.J3 is nl.f3.gradient and nl.H5 is nl.f5.hessian
+
+
+def test_stochastic_volatility_log_prob_host_matches_oracle():
+    """nonlinearities.StochVolLogProb (host evaluation of lmsvlp, adaptive_experiment.py:55-57) against the oracle's
+    StochVolEmissionLogProb, input off and on."""
+    import numpy as np
+    from bayesianfiltering_amd import nonlinearities as nl
+    from oracle import gaussfilt_oracle as go, models as om
+    F32 = np.float32
+    R = (0.1 * np.eye(3) + 0.02).astype(F32)
+    lp = nl.stoch_vol_log_prob(nl.stoch_vol(3), R)
+    ref = go.StochVolEmissionLogProb(om.StochVol(3), R)
+    rng = np.random.default_rng(0)
+    for u in (0.0, 1.0):
+        for _ in range(5):
+            x, y = rng.normal(size=3).astype(F32) * 3, rng.normal(size=3).astype(F32)
+            assert abs(float(lp(x, y, u)) - float(ref(x, y, np.array([u], F32)))) < 2e-4 * max(1.0, abs(float(ref(x, y, np.array([u], F32)))))
