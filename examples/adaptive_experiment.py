@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""The reference's adaptive (linear <-> stochastic-volatility) experiment on the HIP engine.
+
+Mirrors docs/experiments/adaptive_experiment.py of kostastsa/BayesianFiltering: a 3-state linear model
+x' = 0.8 x + q (Q = 20 I, :44-49) observed through glmsv (:54) -- 0.1 x + r while the input is 0, the multiplicative
+stochastic-volatility form 0.5 exp(x / 5) r once it switches to 1 half-way (:67) -- with R = 1e-3 I, T = 100; the
+filters of its loop (:106-164): GSF with 5 components, the augmented GSF [5, 2, 2] with opt_args (0.8, 1e4), and the
+bootstrap particle filter with 100 particles under the state-dependent log-density lmsvlp (:55-57).  The reference's
+`for i in range(Nsim)` loop becomes the batch axis: every filter runs all Nsim trajectories in one launch.
+
+Differences by necessity: the functions come from the device registry; all trajectories of a launch share the filter's
+PRNG key (the reference draws one per run); opt_args[1] = 1e4 makes P- - Lambda indefinite, so -- exactly as in the
+reference, containers.py:121 -- every s-sample falls back to its node mean; and once the input switches the emission
+to the multiplicative form, H_x = 0 at r0 = 0, nothing shrinks the leaf covariance Lambda = 1e4 P- any more: it grows
+1e4-fold per step and overflows within a dozen steps, so the AGSF line reads NaN with the script's own opt_args
+(--agsf-lambda 0.5 gives a working filter).
+
+    python examples/adaptive_experiment.py [--nsim 100] [--particles 100] [--agsf-lambda 1e4]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nsim", type=int, default=100)
+    ap.add_argument("--particles", type=int, default=100)
+    ap.add_argument("--agsf-lambda", type=float, default=1e4, help="opt_args[1] of the augmented filter (:126)")
+    args = ap.parse_args()
+
+    import torch
+    import bayesianfiltering_amd as gf
+    from bayesianfiltering_amd import ParamsNLSSM, ParamsBPF, NonlinearSSM, nonlinearities as nl
+
+    F32 = np.float32
+    n, T, M = 3, 100, 5                                                               # :35-39, :108
+    mu0, Sigma0 = np.zeros(n, F32), np.eye(n, dtype=F32)                              # :40-43
+    Q, R = 20.0 * np.eye(n, dtype=F32), 1e-3 * np.eye(n, dtype=F32)                   # :44-45
+    q0, r0 = np.zeros(n, F32), np.zeros(n, F32)
+    f = nl.linear_dynamics(0.8 * np.eye(n, dtype=F32))                                # fmsv  :48-49
+    g = nl.stoch_vol(n, sigma=5.0, beta=0.5, c=0.1)                                   # glmsv :51-54
+    inputs = np.array([0] * (T // 2) + [1] * (T // 2), F32)                           # :67
+    params = ParamsNLSSM(mu0, Sigma0, f, q0, Q, g, r0, R)
+    params_bpf = ParamsBPF(mu0, Sigma0, f, q0, Q, g, r0, R, nl.stoch_vol_log_prob(g, R))   # lmsvlp :55-57
+
+    # key, next_key = jr.split(next_key) from PRNGKey(10), one data key per run                   :103, :107
+    from bayesianfiltering_amd import legacy
+    keys, nk = [], gf.PRNGKey(10)
+    for _ in range(args.nsim):
+        k, nk = legacy._split(nk, 2)
+        keys.append(k)
+    states, emissions = NonlinearSSM(n, n, n, n).sample(params, np.stack(keys), T, inputs=inputs)
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        return out, time.perf_counter() - t0
+
+    def point_estimate(weights, means):       # jnp.sum(jnp.einsum('ijk,ij->ijk', means, weights), axis=0)   :113
+        return (weights.unsqueeze(-1) * means).sum(dim=1)
+
+    results = {}
+    post, dt = timed(lambda: gf.gaussian_sum_filter(params, emissions, M, 1, inputs, fields=("weights", "means")))
+    results["GSF"] = (point_estimate(post.weights, post.means), dt)
+    (post, _), dt = timed(lambda: gf.augmented_gaussian_sum_filter(params, emissions, [M, 2, 2], keys[0], 1, (0.8, args.agsf_lambda), inputs))
+    results["AGSF"] = (point_estimate(post.weights, post.means), dt)
+    out, dt = timed(lambda: gf.bootstrap_particle_filter(params_bpf, emissions, args.particles, keys[0], inputs,
+                                                         output="summary"))
+    results["BPF"] = (out["mean"], dt)
+
+    print(f"{args.nsim} Monte-Carlo runs, T = {T}, {M} components / {args.particles} particles")
+    print(f"{'filter':8s} {'RMSE (mean +- std)':>24s} {'time for all runs':>20s} {'per run':>12s}")
+    for name, (est, dt) in results.items():
+        rmse = torch.sqrt(((est - states) ** 2).sum(dim=(1, 2)) / T).cpu().numpy()    # utils.rmse, per run
+        ok = np.isfinite(rmse)
+        stat = f"{rmse[ok].mean():12.5f} +- {rmse[ok].std():8.5f}" if ok.any() else f"{'nan':>12s}    {'':8s}"
+        note = "" if ok.all() else f"   ({(~ok).sum()} runs NaN)"
+        print(f"{name:8s} {stat} {dt * 1e3:17.1f} ms {dt / args.nsim * 1e3:9.3f} ms{note}")
+
+
+if __name__ == "__main__":
+    main()

@@ -91,7 +91,13 @@ def _mm(a, b):
 def psd_solve(A, b):
     """utils.py:256-259: solve(A + 1e-6 (every entry), b) by LU with partial pivoting."""
     A = (np.asarray(A, dtype=F32) + F32(1e-6)).astype(F32)
-    return np.linalg.solve(A, np.asarray(b, dtype=F32)).astype(F32)
+    b = np.asarray(b, dtype=F32)
+    if not (np.all(np.isfinite(A)) and np.all(np.isfinite(b))):
+        return np.full(b.shape, np.nan, dtype=F32)      # jax propagates non-finite values; LAPACK may raise
+    try:
+        return np.linalg.solve(A, b).astype(F32)
+    except np.linalg.LinAlgError:                        # exactly singular: jax returns inf / nan, never raises
+        return np.full(b.shape, np.nan, dtype=F32)
 
 
 def lu_solve_explicit(A, b):
