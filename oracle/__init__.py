@@ -15,6 +15,7 @@ its own tests hold no assertions, golden vectors or fixtures (docs/tests/test_in
 only ``return`` values).  What pins this restatement to the real reference are the results the
 reference's author recorded in the stored cell outputs of docs/notebooks/*.ipynb
 (tests/golden/extract_reference_outputs.py): the 20 PRNG keys of BOTExperiment.ipynb (bit-exact),
+the matrix autocov_sims.ipynb computes from 30 normal draws (all 8 printed digits),
 the GSF / UGSF RMSEs of Experiment_TSP_2023.ipynb (<= 3e-6 relative, NaN pattern included) and the
 GSF-NaN / 100-particle BPF RMSE / weights of test_single_run.ipynb (6e-7) --
 tests/test_reference_recorded_outputs.py, tests/test_oracle_rng.py.  PARITY UNPINNED for the

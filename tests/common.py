@@ -76,3 +76,38 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+
+def autocov_sims_replay(z):
+    """The computation of docs/notebooks/autocov_sims.ipynb cells 1-2 on given standard-normal draws z (10, 3), in
+    float32 like the notebook's jnp arrays: sample = 1 + z (= jr.multivariate_normal(key, ones(3), eye(3), (10,))),
+    Hessians of the cubic map of cell 1, 100 gradient steps on X, the three PSD projections; returns X (3, 3)."""
+    def project_to_psd(D):
+        ev, V = np.linalg.eig(D)
+        nd = V @ np.diag(np.multiply(ev > 0, ev)) @ V.T
+        return (nd + nd.T) / 2
+
+    def hessian(x, sigma=10.0, dt=0.01):
+        H = np.zeros((3, 3, 3))
+        x0, x1, x2 = x
+        H[0, 1, 1] = 6 * x1; H[0, 0, 1] = H[0, 1, 0] = -x2; H[0, 0, 2] = H[0, 2, 0] = -x1; H[0, 1, 2] = H[0, 2, 1] = -x0
+        H[0] *= dt * sigma
+        H[1, 0, 2] = H[1, 2, 0] = -2 * x2; H[1, 2, 2] = -2 * x0
+        H[1] *= dt
+        H[2, 0, 1] = H[2, 1, 0] = dt
+        return H
+
+    sample = (np.ones(3, F32) + np.asarray(z, F32).reshape(10, 3)).astype(F32)
+    ha = np.stack([hessian(s) for s in sample]).astype(F32)
+    X, eta, L, N = np.eye(3, dtype=F32), F32(0.01), F32(0.1), 10
+    sh = ha.sum(axis=0)
+    for _ in range(100):
+        coeffs = np.trace(np.matmul(X, ha), axis1=2, axis2=3).sum(axis=0)
+        t2 = np.zeros((3, 3), F32)
+        for j in range(3):
+            t2 += coeffs[j] * sh[j]
+        X = (X - eta * (-(2 * L ** 2 / N) * np.eye(3, dtype=F32) + (1 / 2 / N ** 2) * t2)).astype(F32)
+    S = np.eye(3, dtype=F32)
+    X = project_to_psd(X)
+    X = S - project_to_psd(S - X)
+    return project_to_psd(X)

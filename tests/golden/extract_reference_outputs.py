@@ -15,6 +15,11 @@ reference_notebook_outputs.json  Experiment_TSP_2023.ipynb cell 6 (Lorenz-63 + 0
                                  test_single_run.ipynb cells 4-6, 9 (manoeuvring target, bearing + range, T = 30, explicit
                                  keys): GSF RMSE (nan), BPF RMSE (100 particles, ess 0.5), weights[:, 16].
 
+                                 autocov_sims.ipynb cell 2: ``jrandom.multivariate_normal(PRNGKey(0), ones(3), eye(3), (10,))``
+                                 pushed through the Hessians of a cubic map and 100 gradient steps; the matrix X the
+                                 cell printed (the second of its two stored outputs is the one its current source
+                                 produces): pins the 30 normal draws and their (10, 3) layout.
+
 Not usable (the notebook's code cells were edited after the stored run, or the run used an older library): the
 augmented-filter RMSEs of both notebooks (AGSF and UAGSF agree to 6 digits there, which the current node operations cannot
 produce), every RMSE of BOTExperiment.ipynb (neither FCV gain 1.05 nor 1.0 reproduces them) and of Experiment A.ipynb.
@@ -76,6 +81,16 @@ def outputs():
                      "BPF": float(re.search(r"BPF RMSE:\s*(\S+)", single).group(1))},
             "bpf_weights_t16": [float(v) for v in re.findall(r"\d+\.\d+", w16)],
         },
+    }
+    auto = _stream(json.load(open(NB + "autocov_sims.ipynb")), 2)
+    nums = [float(v) for v in re.findall(r"-?\d+\.\d+(?:e-?\d+)?", auto)]
+    assert len(nums) == 18
+    doc["autocov"] = {
+        "source": "docs/notebooks/autocov_sims.ipynb cells 1-2 (second printed matrix)",
+        "settings": {"sample": "multivariate_normal(PRNGKey(0), ones(3), eye(3), (10,))", "eta": 0.01, "L": 0.1, "N": 10,
+                     "steps": 100, "map": "x + 0.01 * [10 (x1^3 - x0 x1 x2), 28 x0 - x1 - x0 x2^2, x0 x1 - 2.667 x2]"},
+        "X_first_output": [nums[0:3], nums[3:6], nums[6:9]],
+        "X": [nums[9:12], nums[12:15], nums[15:18]],
     }
     json.dump(doc, open(os.path.join(OUT, "reference_notebook_outputs.json"), "w"), indent=1)
     print(json.dumps({"tsp": doc["tsp"]["rmse"], "single_run": doc["single_run"]["rmse"],

@@ -86,3 +86,14 @@ def test_single_run_gsf_nan_and_particle_filter(recorded):
     assert abs(got - rec["rmse"]["BPF"]) <= TOL * rec["rmse"]["BPF"], (got, rec["rmse"]["BPF"])
     w16 = np.array(rec["bpf_weights_t16"], F32)
     assert np.array_equal(out["weights"][:len(w16), 16], w16)
+
+
+def test_autocov_sims_matrix_pins_the_normal_draws(recorded):
+    """autocov_sims.ipynb cell 2 printed the matrix it computes from ``jrandom.multivariate_normal(PRNGKey(0), ones(3),
+    eye(3), (10,))``: replaying the cell on the oracle's 30 normal draws (bits -> uniform -> erf_inv, (10, 3) layout)
+    reproduces all 8 printed digits."""
+    from tests import common as cm
+    X = cm.autocov_sims_replay(tf.normal(tf.PRNGKey(0), 30))
+    assert np.max(np.abs(X - np.array(recorded["autocov"]["X"]))) < 5e-7, X
+    # and the draws matter: another key is far from the recorded matrix
+    assert np.max(np.abs(cm.autocov_sims_replay(tf.normal(tf.PRNGKey(1), 30)) - np.array(recorded["autocov"]["X"]))) > 1e-3

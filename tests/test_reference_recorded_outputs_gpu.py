@@ -91,3 +91,13 @@ def test_single_run_notebook(recorded):
     _close(rmse(np.einsum("ntd,nt->td", x, w), states), rec["rmse"]["BPF"], "BPF")
     w16 = np.array(rec["bpf_weights_t16"], F32)
     assert np.array_equal(w[:len(w16), 16], w16)
+
+
+def test_autocov_sims_matrix_from_library_normals(recorded):
+    """autocov_sims.ipynb cell 2 (see the CPU test of the same name) replayed on the LIBRARY's normal draws
+    (bf_random_normal_f32: the Threefry / erf_inv code the kernels inline)."""
+    import bayesianfiltering_amd as bfa
+    from bayesianfiltering_amd import inference
+    from tests import common as cm
+    X = cm.autocov_sims_replay(inference._random_normal(bfa.PRNGKey(0), 30))
+    assert np.max(np.abs(X - np.array(recorded["autocov"]["X"]))) < 5e-7, X
