@@ -13,7 +13,8 @@ reference_notebook_outputs.json  Experiment_TSP_2023.ipynb cell 6 (Lorenz-63 + 0
                                  gaussian_sum_filter (M = 2), unscented_gaussian_sum_filter (M = 2, ParamsUKF(1,0,0))
                                  and bootstrap_particle_filter (5e5 particles);
                                  test_single_run.ipynb cells 4-6, 9 (manoeuvring target, bearing + range, T = 30, explicit
-                                 keys): GSF RMSE (nan), BPF RMSE (100 particles, ess 0.5), weights[:, 16].
+                                 keys): GSF RMSE (nan), BPF RMSE (100 particles, ess 0.5), weights[:, 16] and the printed
+                                 particle cloud particles[:, 16] (100 x 4).
 
                                  autocov_sims.ipynb cell 2: ``jrandom.multivariate_normal(PRNGKey(0), ones(3), eye(3), (10,))``
                                  pushed through the Hessians of a cubic map and 100 gradient steps; the matrix X the
@@ -80,6 +81,8 @@ def outputs():
             "rmse": {"GSF": float(re.search(r"GSF RMSE:\s*(\S+)", single).group(1)),
                      "BPF": float(re.search(r"BPF RMSE:\s*(\S+)", single).group(1))},
             "bpf_weights_t16": [float(v) for v in re.findall(r"\d+\.\d+", w16)],
+            # print(posterior_bpf["particles"][:, 16]): the whole cloud (100 x 4) after the 17th step
+            "bpf_particles_t16": [float(v) for v in re.findall(r"-?\d+\.\d+(?:e-?\d+)?", _stream(single_nb, 9))],
         },
     }
     auto = _stream(json.load(open(NB + "autocov_sims.ipynb")), 2)

@@ -86,6 +86,10 @@ def test_single_run_gsf_nan_and_particle_filter(recorded):
     assert abs(got - rec["rmse"]["BPF"]) <= TOL * rec["rmse"]["BPF"], (got, rec["rmse"]["BPF"])
     w16 = np.array(rec["bpf_weights_t16"], F32)
     assert np.array_equal(out["weights"][:len(w16), 16], w16)
+    # the printed cloud at t = 16: every slot holds the reference's particle (ancestry of 17 resampling-gated steps)
+    x16 = np.array(rec["bpf_particles_t16"]).reshape(100, 4)
+    assert np.max(np.abs(out["particles"][:, 16] - x16)) < 1e-6
+    assert len(np.unique(x16, axis=0)) == 2
 
 
 def test_autocov_sims_matrix_pins_the_normal_draws(recorded):

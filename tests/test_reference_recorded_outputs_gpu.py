@@ -91,6 +91,8 @@ def test_single_run_notebook(recorded):
     _close(rmse(np.einsum("ntd,nt->td", x, w), states), rec["rmse"]["BPF"], "BPF")
     w16 = np.array(rec["bpf_weights_t16"], F32)
     assert np.array_equal(w[:len(w16), 16], w16)
+    x16 = np.array(rec["bpf_particles_t16"]).reshape(100, 4)      # the printed cloud at t = 16, slot by slot
+    assert np.max(np.abs(x[:, 16] - x16)) < 1e-6
 
 
 def test_autocov_sims_matrix_from_library_normals(recorded):
