@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BAYESFILT_HIP_LIB") or os.path.join(_HERE, "libbayesfilt_hip.so")
 
 BF_OK, BF_EINVAL, BF_EUNSUPPORTED, BF_EHIP, BF_ENOGPU = 0, -1, -2, -3, -4
+HEADER_VERSION = 200  # the BF_VERSION of include/bayesfilt.h these bindings were written against
 
 
 class BayesFiltError(RuntimeError):
@@ -80,6 +81,7 @@ class bf_bpf_out(C.Structure):
 # every symbol include/bayesfilt.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "bf_version": (C.c_int, []),
+    "bf_abi_check": (C.c_int, [C.c_int32, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]),
     "bf_last_error": (C.c_char_p, []),
     "bf_device_count": (C.c_int, []),
     "bf_set_option": (C.c_int, [C.c_char_p, C.c_int]),
@@ -131,6 +133,10 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    # the structs above mirror include/bayesfilt.h by hand: let the library compare layouts before anything is launched
+    if lib.bf_abi_check(HEADER_VERSION, C.sizeof(bf_out_desc), C.sizeof(bf_lgssm), C.sizeof(bf_model), C.sizeof(bf_bpf_model),
+                        C.sizeof(bf_bpf_out)) != BF_OK:
+        raise ImportError("ABI mismatch between _lib.py and the built library: " + lib.bf_last_error().decode())
     _lib = lib
     return lib
 

@@ -470,21 +470,14 @@ static inline int launch_uagsf(const bf_model* p, const bf_ukf_params* up, const
                                long long T, const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry,
                                const bf_out_desc* out, int* d_leaf_idx, int variant, hipStream_t stream) {
   UkfModel<N, DQ, M, DR> h;
+  std::memset(&h, 0, sizeof(h));  // the constant cache compares contents
   int rc = fill_ukf_model<N, DQ, M, DR>(p, up, h);
   if (rc != BF_OK) return rc;
-  UkfModel<N, DQ, M, DR>* d_mdl = nullptr;
-  BF_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&d_mdl), sizeof(h), stream));
-  hipError_t e = hipMemcpyAsync(d_mdl, &h, sizeof(h), hipMemcpyHostToDevice, stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(stream);  // h lives on this stack frame
-  if (e != hipSuccess) {
-    (void)hipFreeAsync(d_mdl, stream);
-    BF_HIP_CHECK(e);
-  }
-  rc = launch_agsf_nodes<N, M, UkfNodes<N, DQ, M, DR>>(d_mdl, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, variant, stream);
-  const hipError_t fe = hipFreeAsync(d_mdl, stream);
+  const void* dv = nullptr;
+  rc = device_constants(&h, sizeof(h), stream, &dv);
   if (rc != BF_OK) return rc;
-  BF_HIP_CHECK(fe);
-  return BF_OK;
+  const UkfModel<N, DQ, M, DR>* d_mdl = static_cast<const UkfModel<N, DQ, M, DR>*>(dv);
+  return launch_agsf_nodes<N, M, UkfNodes<N, DQ, M, DR>>(d_mdl, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, variant, stream);
 }
 
 }  // namespace bf

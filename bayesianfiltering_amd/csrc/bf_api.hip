@@ -47,17 +47,34 @@ int launch_sample_ssm(const bf_bpf_model* bp, const uint32_t* d_keys, const bf_c
 int launch_resample(const float* d_w, const uint32_t* d_keys, long long B, int NP, int resampler, int* d_idx,
                     hipStream_t stream);
 
-extern int g_bpf_variant;
-extern int g_bpf_hbm_mode;
-extern int g_gsf_structured;
-static int g_kf_emit_mode = -1;  // -1 = choose from the layout
-static int g_kf_lanes = 0;       // 0 = default lanes per trajectory for the (n, m) pair
+// process-wide tuning options: atomics, each read once at the top of a call (a launch never sees a torn mix)
+extern std::atomic<int> g_bpf_variant;
+extern std::atomic<int> g_bpf_hbm_mode;
+extern std::atomic<int> g_gsf_structured;
+static std::atomic<int> g_kf_emit_mode{-1};  // -1 = choose from the layout
+static std::atomic<int> g_kf_lanes{0};       // 0 = default lanes per trajectory for the (n, m) pair
 
 }  // namespace bf
 
 extern "C" {
 
 int bf_version(void) { return BF_VERSION; }
+
+int bf_abi_check(int32_t header_version, size_t sizeof_out_desc, size_t sizeof_lgssm, size_t sizeof_model,
+                 size_t sizeof_bpf_model, size_t sizeof_bpf_out) {
+  if (header_version / 100 != BF_VERSION / 100)
+    return bf::set_error(BF_EINVAL, "binding was written against header version %d, the library is %d", (int)header_version, BF_VERSION);
+#define BF_ABI_SIZE(NAME_, T_)                                                                                  \
+  if (NAME_ != 0 && NAME_ != sizeof(T_)) \
+    return bf::set_error(BF_EINVAL, "binding's sizeof(" #T_ ") = %zu, the library's is %zu: the struct layouts differ", NAME_, sizeof(T_));
+  BF_ABI_SIZE(sizeof_out_desc, bf_out_desc)
+  BF_ABI_SIZE(sizeof_lgssm, bf_lgssm)
+  BF_ABI_SIZE(sizeof_model, bf_model)
+  BF_ABI_SIZE(sizeof_bpf_model, bf_bpf_model)
+  BF_ABI_SIZE(sizeof_bpf_out, bf_bpf_out)
+#undef BF_ABI_SIZE
+  return BF_OK;
+}
 
 const char* bf_last_error(void) { return bf::last_error_buf(); }
 
@@ -135,8 +152,8 @@ int bf_kalman_filter_f32(const bf_lgssm* model, const bf_cstream* y, int64_t B, 
   if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
   if (model->n == 64 && model->m == 32)  // dense products large enough for the fp32 matrix cores
     return bf::launch_kf_mfma(model, y, B, T, carry, out, static_cast<hipStream_t>(stream));
-  return bf::launch_kf_group(model, y, B, T, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode,
-                             bf::g_kf_lanes);
+  return bf::launch_kf_group(model, y, B, T, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode.load(),
+                             bf::g_kf_lanes.load());
 }
 
 int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream* u, int64_t B, int64_t T, int32_t K,
@@ -148,8 +165,8 @@ int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream*
   if (!model->Q || !model->R) return bf::set_error(BF_EINVAL, "Q and R are required");
   if (!y->ptr) return bf::set_error(BF_EINVAL, "observations pointer is NULL");
   if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
-  return bf::launch_gsf_ekf(model, y, u, B, T, K, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode,
-                            bf::g_kf_lanes);
+  return bf::launch_gsf_ekf(model, y, u, B, T, K, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode.load(),
+                            bf::g_kf_lanes.load());
 }
 
 int bf_ugsf_ukf_f32(const bf_model* model, const bf_ukf_params* uparams, const bf_cstream* y, const bf_cstream* u,

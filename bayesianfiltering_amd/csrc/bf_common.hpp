@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
+#include <atomic>
 #include "../../include/bayesfilt.h"
 
 namespace bf {
@@ -19,6 +20,10 @@ int set_error(int code, const char* fmt, ...);
       return ::bf::set_error(BF_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
                              __FILE__, __LINE__);                                            \
   } while (0)
+
+// Device-resident copy of a host constant block (model struct, per-step covariance table), cached by content and
+// uploaded stream-ordered through pinned staging: no host synchronisation, nothing to free (const_cache.hip).
+int device_constants(const void* host, size_t bytes, hipStream_t stream, const void** d_out);
 
 // Device-side view of one strided stream with the component axis folded in by the caller.
 struct SView {

@@ -369,8 +369,8 @@ static inline int launch_bpf_cfg(const BpfModel<N, DQ, M>* d_mdl, const bf_cstre
   return BF_OK;
 }
 
-extern int g_bpf_variant;   // tuning hook (bf_set_option "bpf_variant")
-extern int g_bpf_hbm_mode;  // bf_set_option "bpf_hbm_mode": 0 = choose, 1 = workgroup per trajectory, 2 = per chunk
+extern std::atomic<int> g_bpf_variant;   // tuning hook (bf_set_option "bpf_variant")
+extern std::atomic<int> g_bpf_hbm_mode;  // bf_set_option "bpf_hbm_mode": 0 = choose, 1 = workgroup per trajectory, 2 = per chunk
 
 // bpf_big.hpp / bpf_wide.hpp: particle counts beyond the in-register capacities (declared here, defined after the kernels there)
 template <int N, int DQ, int M>
@@ -383,16 +383,13 @@ static inline int launch_bpf_dims(const bf_bpf_model* bp, const bf_cstream* y, c
                            int NP, float ess, int resampler, const uint32_t key[2], const BpfCarry& cr, const BpfOut& out,
                            hipStream_t stream) {
   BpfModel<N, DQ, M> h;
+  std::memset(&h, 0, sizeof(h));  // the constant cache compares contents
   int rc = fill_bpf_model<N, DQ, M>(bp, h);
   if (rc != BF_OK) return rc;
-  BpfModel<N, DQ, M>* d_mdl = nullptr;
-  BF_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&d_mdl), sizeof(h), stream));
-  hipError_t e = hipMemcpyAsync(d_mdl, &h, sizeof(h), hipMemcpyHostToDevice, stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(stream);  // h lives on this stack frame
-  if (e != hipSuccess) {
-    (void)hipFreeAsync(d_mdl, stream);
-    BF_HIP_CHECK(e);
-  }
+  const void* dv = nullptr;
+  rc = device_constants(&h, sizeof(h), stream, &dv);
+  if (rc != BF_OK) return rc;
+  const BpfModel<N, DQ, M>* d_mdl = static_cast<const BpfModel<N, DQ, M>*>(dv);
   // few trajectories with thousands of particles: one workgroup per trajectory would leave the chip idle (a step of the
   // in-register kernel takes ~19 us per 1024 particles on its one CU); the workgroup-per-chunk kernels of bpf_wide.hpp
   // spread the particles over the CUs at ~25 us of launches per step
@@ -415,10 +412,7 @@ static inline int launch_bpf_dims(const bf_bpf_model* bp, const bf_cstream* y, c
     if constexpr (N <= 4 && DQ <= 4) rc = launch_bpf_cfg<N, DQ, M, 16, 16>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
   }
   else rc = launch_bpf_hbm_dims<N, DQ, M>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);  // particles in HBM (bpf_big.hpp, bpf_wide.hpp)
-  hipError_t fe = hipFreeAsync(d_mdl, stream);
-  if (rc != BF_OK) return rc;
-  BF_HIP_CHECK(fe);
-  return BF_OK;
+  return rc;
 }
 
 }  // namespace bf

@@ -372,7 +372,8 @@ static inline int launch_bpf_hbm_dims(const BpfModel<N, DQ, M>* d_mdl, const bf_
   if (NP > BIG_NT * BIG_MAXCH)
     return set_error(BF_EUNSUPPORTED, "bootstrap particle filter: %d particles exceed the capacity of %d per trajectory", NP,
                      BIG_NT * BIG_MAXCH);
-  const bool wide = B <= 65535 && (g_bpf_hbm_mode == 2 || (g_bpf_hbm_mode == 0 && B < 128));
+  const int hbm_mode = g_bpf_hbm_mode.load();
+  const bool wide = B <= 65535 && (hbm_mode == 2 || (hbm_mode == 0 && B < 128));
   if (wide) return launch_bpf_wide_dims<N, DQ, M>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
   return launch_bpf_big_dims<N, DQ, M>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
 }

@@ -732,21 +732,19 @@ static inline int launch_gsf(const bf_model* p, const bf_cstream* y, const bf_cs
   const size_t lds_bytes = sizeof(float) * (GSF_HDR + (SPEC == SPEC_L96_PICK ? N * N : 0) + (size_t)lds_per_wave * 4);
   if (lds_bytes > 160 * 1024) return set_error(BF_EUNSUPPORTED, "staging tiles exceed the 160 KiB LDS");
   // per-step covariance products: device copies for the duration of the launch
-  float* d_tv = nullptr;
+  // (stream-ordered upload through the constant cache, const_cache.hip: no host synchronisation)
   const float *d_tvq = nullptr, *d_tvr = nullptr;
-  if (!tvq.empty() || !tvr.empty()) {
-    BF_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&d_tv), sizeof(float) * (tvq.size() + tvr.size()), stream));
-    hipError_t ce = hipSuccess;
-    if (!tvq.empty()) ce = hipMemcpyAsync(d_tv, tvq.data(), sizeof(float) * tvq.size(), hipMemcpyHostToDevice, stream);
-    if (ce == hipSuccess && !tvr.empty())
-      ce = hipMemcpyAsync(d_tv + tvq.size(), tvr.data(), sizeof(float) * tvr.size(), hipMemcpyHostToDevice, stream);
-    if (ce == hipSuccess) ce = hipStreamSynchronize(stream);  // the host vectors die with this frame
-    if (ce != hipSuccess) {
-      (void)hipFreeAsync(d_tv, stream);
-      BF_HIP_CHECK(ce);
-    }
-    if (!tvq.empty()) d_tvq = d_tv;
-    if (!tvr.empty()) d_tvr = d_tv + tvq.size();
+  if (!tvq.empty()) {
+    const void* dv = nullptr;
+    const int rc = device_constants(tvq.data(), sizeof(float) * tvq.size(), stream, &dv);
+    if (rc != BF_OK) return rc;
+    d_tvq = static_cast<const float*>(dv);
+  }
+  if (!tvr.empty()) {
+    const void* dv = nullptr;
+    const int rc = device_constants(tvr.data(), sizeof(float) * tvr.size(), stream, &dv);
+    if (rc != BF_OK) return rc;
+    d_tvr = static_cast<const float*>(dv);
   }
   dim3 block(256);
   dim3 grid((unsigned)((B + tpb - 1) / tpb));
@@ -766,9 +764,7 @@ static inline int launch_gsf(const bf_model* p, const bf_cstream* y, const bf_cs
       hipLaunchKernelGGL((gsf_scan_kernel<N, M, NL, EMIT_STAGED, SPEC>), grid, block, lds_bytes, stream, e, yv, uv, cv, ov, B, T, K,
                          KP, lds_per_wave, d_tvq, d_tvr, (int)wscalar);
   }
-  const hipError_t le = hipGetLastError();
-  if (d_tv) (void)hipFreeAsync(d_tv, stream);
-  BF_HIP_CHECK(le);
+  BF_HIP_CHECK(hipGetLastError());
   return BF_OK;
 }
 

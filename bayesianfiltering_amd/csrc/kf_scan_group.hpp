@@ -30,6 +30,7 @@
 // wave's newer stores in flight (gfx9 counts loads and stores on one in-order counter).
 #pragma once
 #include <cstdlib>
+#include <vector>
 #include "bf_common.hpp"
 #include "kf_math.hpp"
 #include "lane_group.hpp"
@@ -483,37 +484,36 @@ static inline int launch_nml(const bf_lgssm* p, const bf_cstream* y, long long B
     return set_error(BF_EINVAL, "staged emitter needs the contiguous reference layout, 16-byte aligned rows and n in {1,2,4,8}");
 
   // time-varying covariances: per-step G Q_t G^T / D R_t D^T tables on the device
-  float* d_gqg = nullptr;
-  float* d_drd = nullptr;
+  // (stream-ordered upload through the constant cache: no host synchronisation, found again by content on the next call)
+  const float* d_gqg = nullptr;
+  const float* d_drd = nullptr;
   const bool tv = (p->Q_steps > 1) || (p->R_steps > 1);
   if (tv) {
     if ((p->Q_steps > 1 && p->Q_steps != T) || (p->R_steps > 1 && p->R_steps != T))
       return set_error(BF_EINVAL, "time-varying Q/R need exactly T=%lld matrices", T);
     if (p->Q_steps > 1) {
-      float* h = new float[T * N * N];
+      std::vector<float> h((size_t)T * N * N);
       for (long long t = 0; t < T; ++t) {
         KFConst<N, M> ct;
         fill_const<N, M>(p, ct, p->Q + t * p->dq * p->dq, p->R);
         for (int i = 0; i < N * N; ++i) h[t * N * N + i] = ct.GQG[i];
       }
-      hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&d_gqg), sizeof(float) * T * N * N, stream);
-      if (e == hipSuccess) e = hipMemcpyAsync(d_gqg, h, sizeof(float) * T * N * N, hipMemcpyHostToDevice, stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(stream);
-      delete[] h;
-      BF_HIP_CHECK(e);
+      const void* dv = nullptr;
+      const int rc = device_constants(h.data(), sizeof(float) * h.size(), stream, &dv);
+      if (rc != BF_OK) return rc;
+      d_gqg = static_cast<const float*>(dv);
     }
     if (p->R_steps > 1) {
-      float* h = new float[T * M * M];
+      std::vector<float> h((size_t)T * M * M);
       for (long long t = 0; t < T; ++t) {
         KFConst<N, M> ct;
         fill_const<N, M>(p, ct, p->Q, p->R + t * p->dr * p->dr);
         for (int i = 0; i < M * M; ++i) h[t * M * M + i] = ct.DRD[i];
       }
-      hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&d_drd), sizeof(float) * T * M * M, stream);
-      if (e == hipSuccess) e = hipMemcpyAsync(d_drd, h, sizeof(float) * T * M * M, hipMemcpyHostToDevice, stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(stream);
-      delete[] h;
-      BF_HIP_CHECK(e);
+      const void* dv = nullptr;
+      const int rc = device_constants(h.data(), sizeof(float) * h.size(), stream, &dv);
+      if (rc != BF_OK) return rc;
+      d_drd = static_cast<const float*>(dv);
     }
   }
 
@@ -566,8 +566,6 @@ static inline int launch_nml(const bf_lgssm* p, const bf_cstream* y, long long B
     launch(EMIT_SCALAR, 0, B);
   }
   BF_HIP_CHECK(hipGetLastError());
-  if (d_gqg) BF_HIP_CHECK(hipFreeAsync(d_gqg, stream));
-  if (d_drd) BF_HIP_CHECK(hipFreeAsync(d_drd, stream));
   return BF_OK;
 }
 

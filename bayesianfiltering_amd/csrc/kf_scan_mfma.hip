@@ -470,7 +470,7 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
   if (p->Q_steps > 1 || p->R_steps > 1)
     return set_error(BF_EUNSUPPORTED, "time-varying Q/R are not supported on the MFMA Kalman kernel");
   const int dq = p->dq, dr = p->dr;
-  MfmaConst<N, M>* h = new MfmaConst<N, M>;
+  MfmaConst<N, M>* h = new MfmaConst<N, M>();  // zero-filled: the constant cache compares contents
   auto Gat = [&](int i, int k) { return p->G ? p->G[i * dq + k] : (i == k ? 1.f : 0.f); };
   auto Dat = [&](int i, int k) { return p->D ? p->D[i * dr + k] : (i == k ? 1.f : 0.f); };
   for (int i = 0; i < N * N; ++i) h->A[i] = p->A[i];
@@ -515,12 +515,11 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
     for (int k = 0; k < dr; ++k) s = fmaf(Dat(i, k), p->r0 ? p->r0[k] : 0.f, s);
     h->Dr0[i] = s;
   }
-  MfmaConst<N, M>* d = nullptr;
-  hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&d), sizeof(*h), stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d, h, sizeof(*h), hipMemcpyHostToDevice, stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  const void* dv = nullptr;
+  const int crc = device_constants(h, sizeof(*h), stream, &dv);
   delete h;
-  BF_HIP_CHECK(e);
+  if (crc != BF_OK) return crc;
+  const MfmaConst<N, M>* d = static_cast<const MfmaConst<N, M>*>(dv);
 
   CView yv{y->ptr, y->sB, y->sT, y->sE};
   CarryView cv{carry->w_in, carry->m_in, carry->P_in, carry->w_out, carry->m_out, carry->P_out};
@@ -531,10 +530,7 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
   if (lds_bytes > 64 * 1024)
     BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(256), lds_bytes, stream, d, yv, cv, ov, B, T);
-  hipError_t le = hipGetLastError();
-  hipError_t fe = hipFreeAsync(d, stream);
-  BF_HIP_CHECK(le);
-  BF_HIP_CHECK(fe);
+  BF_HIP_CHECK(hipGetLastError());
   return BF_OK;
 }
 

@@ -6,6 +6,7 @@
 // experiment script (docs/experiments/BOT_Experiment_script.py:95).  One lane per trajectory
 // (the recursion is sequential in t); all randomness is per-lane Threefry with JAX's layout, so
 // trajectory b depends only on keys[b].
+#include <cstring>
 #include "bf_common.hpp"
 #include "bf_rng.hpp"
 #include "ssm_device.hpp"
@@ -93,6 +94,7 @@ static int launch_sample_dims(const bf_bpf_model* bp, const uint32_t* d_keys, co
     BpfModel<N, DQ, M> mdl;
     EmissionNoise<M> en;
   } h;
+  std::memset(&h, 0, sizeof(h));  // the constant cache compares contents: no indeterminate padding
   std::memset(&h, 0, sizeof(h));
   // reuse the particle-filter model fill with the emission-noise covariance standing in for the
   // log-density covariance and r_eval = 0; the stochastic-volatility emission is evaluated here
@@ -129,17 +131,13 @@ static int launch_sample_dims(const bf_bpf_model* bp, const uint32_t* d_keys, co
   }
   for (int i = 0; i < M * M; ++i) h.en.LRn[i] = h.mdl.LR[i];
   for (int i = 0; i < M; ++i) h.en.r0[i] = p->r0 ? p->r0[i] : 0.f;
-  Pack* d = nullptr;
-  hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&d), sizeof(h), stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d, &h, sizeof(h), hipMemcpyHostToDevice, stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(stream);
-  BF_HIP_CHECK(e);
+  const void* dv = nullptr;
+  rc = device_constants(&h, sizeof(h), stream, &dv);
+  if (rc != BF_OK) return rc;
+  const Pack* d = static_cast<const Pack*>(dv);
   hipLaunchKernelGGL((sample_ssm_kernel<N, DQ, M>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, &d->mdl, &d->en, d_keys,
                      (u && u->ptr) ? u->ptr : nullptr, u ? u->sB : 0, u ? u->sT : 0, d_states, d_emis, B, T);
-  hipError_t le = hipGetLastError();
-  hipError_t fe = hipFreeAsync(d, stream);
-  BF_HIP_CHECK(le);
-  BF_HIP_CHECK(fe);
+  BF_HIP_CHECK(hipGetLastError());
   return BF_OK;
 }
 

@@ -498,6 +498,7 @@ template <int N, int DQ, int M, int DR>
 static inline int launch_ugsf(const bf_model* p, const bf_ukf_params* up, const bf_cstream* y, const bf_cstream* u, long long B,
                               long long T, int K, const bf_carry* carry, const bf_out_desc* out, hipStream_t stream) {
   UkfModel<N, DQ, M, DR> h;
+  std::memset(&h, 0, sizeof(h));  // the constant cache compares contents
   int rc = fill_ukf_model<N, DQ, M, DR>(p, up, h);
   if (rc != BF_OK) return rc;
   int KP = 1;
@@ -505,14 +506,10 @@ static inline int launch_ugsf(const bf_model* p, const bf_ukf_params* up, const 
   if (KP > 256) return set_error(BF_EUNSUPPORTED, "unscented Gaussian-sum filter: %d components exceed one workgroup (256 lanes)", K);
   if (out->coll_mean.ptr || out->coll_cov.ptr)
     return set_error(BF_EUNSUPPORTED, "collapsed streams are produced by bf_gsf_ekf_f32 only");
-  UkfModel<N, DQ, M, DR>* d_mdl = nullptr;
-  BF_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&d_mdl), sizeof(h), stream));
-  hipError_t e = hipMemcpyAsync(d_mdl, &h, sizeof(h), hipMemcpyHostToDevice, stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(stream);  // h lives on this stack frame
-  if (e != hipSuccess) {
-    (void)hipFreeAsync(d_mdl, stream);
-    BF_HIP_CHECK(e);
-  }
+  const void* dv = nullptr;
+  rc = device_constants(&h, sizeof(h), stream, &dv);
+  if (rc != BF_OK) return rc;
+  const UkfModel<N, DQ, M, DR>* d_mdl = static_cast<const UkfModel<N, DQ, M, DR>*>(dv);
   CView yv{y->ptr, y->sB, y->sT, y->sE};
   CarryView cv{carry->w_in, carry->m_in, carry->P_in, carry->w_out, carry->m_out, carry->P_out};
   OutViews ov{make_sview(out->weights), make_sview(out->means), make_sview(out->covs),
@@ -520,10 +517,7 @@ static inline int launch_ugsf(const bf_model* p, const bf_ukf_params* up, const 
   const int tpb = 256 / KP;
   hipLaunchKernelGGL((ugsf_scan_kernel<N, DQ, M, DR>), dim3((unsigned)((B + tpb - 1) / tpb)), dim3(256), 0, stream, d_mdl, yv,
                      (u && u->ptr) ? u->ptr : nullptr, u ? u->sB : 0, u ? u->sT : 0, cv, ov, B, T, K, KP);
-  const hipError_t le = hipGetLastError();
-  const hipError_t fe = hipFreeAsync(d_mdl, stream);
-  BF_HIP_CHECK(le);
-  BF_HIP_CHECK(fe);
+  BF_HIP_CHECK(hipGetLastError());
   return BF_OK;
 }
 

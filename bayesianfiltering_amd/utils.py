@@ -15,8 +15,6 @@ def rmse(x_est, x_base):
 
 
 def _post_desc(post):
-    from . import _lib
-    from .inference import _stream_desc
     w, m, P = post.weights, post.means, post.covariances
     if w.dim() == 2:                       # (K, T, ...) single trajectory -> add the batch axis
         w, m, P = w.unsqueeze(0), m.unsqueeze(0), (P.unsqueeze(0) if P is not None else None)

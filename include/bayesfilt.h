@@ -15,7 +15,9 @@
  * named `d_*` or carried in bf_stream/bf_cstream/bf_carry are DEVICE pointers owned by the
  * caller; the engine never allocates outputs.  Model parameter structs hold HOST pointers to
  * small row-major fp32 arrays which are copied into kernel arguments at launch.  `stream` is a
- * hipStream_t passed as void* (NULL = the default stream).  Launches are asynchronous.
+ * hipStream_t passed as void* (NULL = the default stream).  Launches are asynchronous: no entry point synchronises
+ * the host with the stream (constant blocks are uploaded stream-ordered through a content-keyed cache and found
+ * again on later calls, so a warmed-up call is also capturable into a hipGraph).
  *
  * Arithmetic is fp32 like the reference's JAX path (no jax_enable_x64 anywhere); the
  * reference's quirks are reproduced: update -> reweight -> predict order,
@@ -33,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BF_VERSION 100 /* 0.1.0 */
+#define BF_VERSION 200 /* 0.2.0: major = ABI revision (struct layouts), see bf_abi_check */
 
 #define BF_OK 0
 #define BF_EINVAL (-1)       /* bad argument (NULL pointer, non-positive size, misaligned) */
@@ -106,6 +108,12 @@ typedef struct bf_lgssm {
 } bf_lgssm;
 
 int bf_version(void);
+/* ABI guard.  A binding that mirrors the structs of this header by hand (ctypes, cgo, JNI ...) calls this once after
+ * loading the library, with the BF_VERSION it was written against and ITS sizes of the structs it fills; a mismatch
+ * (e.g. a bf_out_desc with six streams against the library's eight) returns BF_EINVAL with the offending struct in
+ * bf_last_error() instead of an out-of-bounds read later.  A size of 0 means "this binding does not mirror that struct". */
+int bf_abi_check(int32_t header_version, size_t sizeof_out_desc, size_t sizeof_lgssm, size_t sizeof_model,
+                 size_t sizeof_bpf_model, size_t sizeof_bpf_out);
 const char* bf_last_error(void);
 /* Number of visible gfx950 devices (0 if none / HIP unavailable). */
 int bf_device_count(void);

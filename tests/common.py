@@ -111,3 +111,11 @@ def autocov_sims_replay(z):
     X = project_to_psd(X)
     X = S - project_to_psd(S - X)
     return project_to_psd(X)
+
+
+def device_observations(params, dims, B, T, seed):
+    """(B, T, m) observations of the model itself, drawn on the device by the engine's data generator
+    (NonlinearSSM.sample, gaussfiltax/models.py:240-289) with keys split(PRNGKey(seed), B) -- what bench.py filters."""
+    import bayesianfiltering_amd as bfa
+    keys = otf.split(otf.PRNGKey(seed), B)
+    return bfa.NonlinearSSM(*dims).sample(params, keys, T)[1]

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 from scipy.linalg import solve_discrete_are
 
-from oracle import gaussfilt_oracle as go, models as om
+from oracle import gaussfilt_oracle as go, models as om, c_oracle
 from tests import common as cm
 
 pytestmark = pytest.mark.gpu
@@ -151,3 +151,148 @@ def test_kalman_n64_T2000_B4096():
     for k in ("means", "covariances", "predicted_covariances"):
         assert cm.rel_err(getattr(short, k).cpu().numpy(), ref[k]) < 1e-4, k   # observations not drawn from the model: large innovations
     assert bool(torch.isfinite(ll).all())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The benchmarked launches themselves: same entry point, same output mode, same layout, same sizes as bench.py.
+
+def _sym(P):
+    return 0.5 * (P + np.swapaxes(P, -1, -2))
+
+
+def test_cfg2_full5_reference_layout_at_benchmark_size():
+    """configs[1] exactly as bench.py runs it: FULL5, contiguous reference layout [B][1][T][E] (the LDS time-transpose
+    emitter, 107 GB of posterior), B = 65 536, T = 10 000, observations drawn from the model on the device.
+    * whole trajectories (first / wave and workgroup edges / middle / last) x all five streams + log-likelihood against
+      the oracle: 1e-5 before the reference recursion's antisymmetric mode leaves the rounding noise (t < 300), the
+      documented bound on the asymmetric fixed point (last 2 000 steps), and a bound on means and the SYMMETRIC part of
+      the covariances over the whole trajectory (inference.py:102 has no symmetrisation: see DESIGN.md 2);
+    * every element of every stream equal between the one-shot launch and four T-chunks through the carry (different
+      row strides, same rows: any 32-/64-bit offset slip in 107 GB shows);
+    * the strided emitter (batch-inner layout) on slices of the batch equal to the staged emitter bit for bit."""
+    import torch
+    import bayesianfiltering_amd as bfa
+    a = cm.cv_model_arrays()
+    p = cm.product_params(a)
+    B, T, Tc = 65536, 10000, 2500
+    y = cm.device_observations(p, (4, 2, 2, 2), B, T, seed=1000)
+    init = torch.zeros((B, 4), device="cuda")
+    post, ll = bfa.kalman_filter(p, y, initial_means=init, return_loglik=True)
+    assert tuple(post.covariances.shape) == (B, 1, T, 4, 4) and post.covariances.is_contiguous()
+    assert bool((post.weights == 1.0).all())                                     # K = 1: exactly 1 unless something is non-finite
+
+    # ---- oracle on whole trajectories (C port of the NumPy oracle for 12 of them, the NumPy oracle itself for 3)
+    idx = [0, 31, 32, 127, 128, 4095, 4096, B // 2 + 17, B // 2 + 18, B - 129, B - 2, B - 1]
+    ys = y[idx].cpu().numpy()
+    ref = c_oracle.kalman_filter(a, ys, np.zeros((len(idx), 4), F32))
+    ref_np = cm.oracle_kalman_batch(a, ys[[0, 7, 11]], np.zeros((3, 4), F32))
+    names = {"means": "means", "covariances": "covariances", "predicted_means": "predicted_means",
+             "predicted_covariances": "predicted_covariances"}
+    got = {k: getattr(post, k)[idx].cpu().numpy() for k in names}
+    got["loglik"] = ll[idx].cpu().numpy()
+    for k in list(names) + ["loglik"]:
+        g, r = got[k], ref[k]
+        assert cm.rel_err(g[:, :, :300], r[:, :, :300]) < 1e-5, (k, cm.rel_err(g[:, :, :300], r[:, :, :300]))
+        assert cm.rel_err(g[:, :, -2000:], r[:, :, -2000:]) < 1e-3, (k, cm.rel_err(g[:, :, -2000:], r[:, :, -2000:]))
+        rn = ref_np[k]
+        assert cm.rel_err(g[[0, 7, 11]][:, :, :300], rn[:, :, :300]) < 1e-5, k
+        assert cm.rel_err(g[[0, 7, 11]][:, :, -2000:], rn[:, :, -2000:]) < 1e-3, k
+    # the whole trajectory, crossover window included: means, log-likelihoods and the symmetric part of the covariances
+    for k in ("means", "predicted_means", "loglik"):
+        assert cm.rel_err(got[k], ref[k]) < 2e-3, (k, cm.rel_err(got[k], ref[k]))
+    for k in ("covariances", "predicted_covariances"):
+        assert cm.rel_err(_sym(got[k]), _sym(ref[k])) < 2e-3, (k, cm.rel_err(_sym(got[k]), _sym(ref[k])))
+
+    # ---- one-shot == four T-chunks through the carry, every element of every stream
+    carry = None
+    for t0 in range(0, T, Tc):
+        chunk, cl, carry = bfa.kalman_filter(p, y[:, t0:t0 + Tc], initial_means=init, carry=carry, return_loglik=True,
+                                             return_carry=True)
+        for k in bfa.FULL5:
+            assert torch.equal(getattr(post, k)[:, :, t0:t0 + Tc], getattr(chunk, k)), (k, t0)
+        assert torch.equal(ll[:, :, t0:t0 + Tc], cl), t0
+        del chunk, cl
+    # ---- strided emitter on slices of the batch == staged emitter
+    for lo in (0, B // 2 - 128, B - 256):
+        sl = slice(lo, lo + 256)
+        alt = bfa.kalman_filter(p, y[sl], initial_means=init[sl], layout="batch_inner")
+        for k in bfa.FULL5:
+            assert torch.equal(getattr(post, k)[sl], getattr(alt, k)), (k, lo)
+
+
+def test_cfg1_single_trajectory_T1000():
+    """configs[0]: n = 4, m = 2, T = 1 000, batch = 1 -- the reference's own CPU-runnable case, one trajectory through the
+    same entry point: against the oracle (all five streams + log-likelihood) and against the fp64 textbook Kalman filter."""
+    import bayesianfiltering_amd as bfa
+    a = cm.cv_model_arrays()
+    p = cm.product_params(a)
+    T = 1000
+    ys = cm.simulate_batch(a, 1, T, seed=1)[0]
+    init = a["m0"].reshape(1, 4)
+    post, ll = bfa.kalman_filter(p, ys, initial_means=init, return_loglik=True)
+    assert tuple(post.means.shape) == (1, T, 4) and tuple(post.covariances.shape) == (1, T, 4, 4)    # (K, T, ...) :372
+    ref = cm.oracle_kalman_batch(a, ys[None], init)
+    for k in bfa.FULL5:
+        g, r = getattr(post, k).cpu().numpy(), ref[k][0]
+        assert cm.rel_err(g[:, :300], r[:, :300]) < 1e-5, (k, cm.rel_err(g[:, :300], r[:, :300]))
+        assert cm.rel_err(g, r) < 1e-4, (k, cm.rel_err(g, r))
+    assert cm.rel_err(ll.cpu().numpy()[:, :300], ref["loglik"][0][:, :300]) < 1e-5
+    # gaussian_sum_filter(num_components = 1) is the same computation (the reference has no separate Kalman filter)
+    gsf = bfa.gaussian_sum_filter(p, ys, 1, 1, initial_means=init)
+    for k in bfa.FULL5:
+        assert cm.rel_err(getattr(gsf, k).cpu().numpy()[:, :300], ref[k][0][:, :300]) < 1e-5, k
+    # fp64 textbook recursion (no jitter, Joseph-free standard form): agreement at the size of the reference's 1e-6 jitter
+    GQG = (a["G"] @ a["Q"] @ a["G"].T).astype(np.float64)
+    tm, tP, _, _, tll = go.textbook_kalman_f64(a["A"], GQG, a["H"], a["R"], a["m0"], a["P0"], ys)
+    assert cm.rel_err(post.means.cpu().numpy()[0, :300], tm[:300]) < 1e-4
+    assert cm.rel_err(post.covariances.cpu().numpy()[0, :300], tP[:300]) < 1e-4
+    assert cm.rel_err(ll.cpu().numpy()[0, :300], tll[:300]) < 1e-4
+
+
+def test_cfg4_instance_n16_N4096_against_oracle():
+    """configs[3]'s kernel instance itself -- bpf_scan_kernel<16,16,8,4,16>: Lorenz-96 n = 16, m = 8, N = 4 096 particles
+    (inference.py:1330-1377) -- against oracle.bootstrap_particle_filter on B = 2 trajectories, T = 5: resampling decisions,
+    ancestors, weights (1e-6 absolute), particles (1e-5) and the ESS."""
+    import bayesianfiltering_amd as bfa
+    from oracle import threefry as otf
+    nl = bfa.nonlinearities
+    N, T, n, m = 4096, 5, 16, 8
+    R = 0.5 * np.eye(m, dtype=F32)
+    Q = 1e-1 * np.eye(n, dtype=F32)
+    po = go.ParamsBPF(8 * np.ones(n, F32), np.eye(n, dtype=F32), om.Lorenz96(n), np.zeros(n, F32), Q, om.PickEven(n),
+                      np.zeros(m, F32), R, go.GaussianEmissionLogProb(om.PickEven(n), R))
+    g = nl.pick_even(n)
+    pp = bfa.ParamsBPF(8 * np.ones(n, F32), np.eye(n, dtype=F32), nl.lorenz96(n), np.zeros(n, F32), Q, g, np.zeros(m, F32), R,
+                       nl.gaussian_log_prob(g, R))
+    ys = np.stack([go.sample_ssm(go.ParamsNLSSM(*po[:8]), otf.PRNGKey(40 + b), T)[1] for b in range(2)])
+    key = np.array([0, 1], np.uint32)
+    out = bfa.bootstrap_particle_filter(pp, ys, N, key, output="both", return_ancestors=True)
+    for b in range(2):
+        ref, dbg = go.bootstrap_particle_filter(po, ys[b], N, key=key, debug=True)
+        assert np.array_equal(out["resampled"][b].cpu().numpy() > 0.5, dbg["resampled"])
+        assert dbg["resampled"].any()
+        assert np.array_equal(out["ancestors"][b].cpu().numpy().T, dbg["ancestors"])          # bit-exact ancestry, all steps
+        assert cm.rel_err(out["particles"][b].cpu().numpy(), ref["particles"]) < 1e-5
+        assert np.max(np.abs(out["weights"][b].cpu().numpy() - ref["weights"])) < 1e-6
+        assert cm.rel_err(out["ess"][b].cpu().numpy(), dbg["ess"]) < 1e-4
+
+
+def test_cfg5_two_trajectories_T2000_against_oracle():
+    """configs[4]: the MFMA kernel over its full horizon, T = 2 000, observations drawn from the model: two whole
+    trajectories, all five streams + log-likelihood, against the oracle's C port (oracle/c/kf_oracle.c)."""
+    import bayesianfiltering_amd as bfa
+    a = cm.random_stable_lgssm(64, 32, seed=64)
+    a["Q"] = (1e-2 * np.eye(64)).astype(F32)
+    a["R"] = (1e-1 * np.eye(32)).astype(F32)
+    a["m0"] = np.zeros(64, F32)
+    p = cm.product_params(a)
+    T = 2000
+    y = cm.device_observations(p, (64, 64, 32, 32), 2, T, seed=5)
+    init = np.zeros((2, 64), F32)
+    post, ll = bfa.kalman_filter(p, y, initial_means=init, return_loglik=True)
+    ref = c_oracle.kalman_filter(a, y.cpu().numpy(), init)
+    for k in bfa.FULL5:
+        g, r = getattr(post, k).cpu().numpy(), ref[k]
+        assert cm.rel_err(g[:, :, :300], r[:, :, :300]) < 1e-5, (k, cm.rel_err(g[:, :, :300], r[:, :, :300]))
+        assert cm.rel_err(g, r) < 1e-4, (k, cm.rel_err(g, r))
+    assert cm.rel_err(ll.cpu().numpy(), ref["loglik"]) < 1e-4
