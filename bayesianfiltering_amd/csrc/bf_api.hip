@@ -24,6 +24,10 @@ int launch_kf_group(const bf_lgssm* p, const bf_cstream* y, long long B, long lo
 
 int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
                    const bf_out_desc* out, hipStream_t stream);
+int launch_kf_generic(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
+                      const bf_out_desc* out, hipStream_t stream);
+int launch_gsf_generic(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int K,
+                       const bf_carry* carry, const bf_out_desc* out, hipStream_t stream);
 int launch_collapse(const bf_stream* w, const bf_stream* m, const bf_stream* P, long long B, long long T, int K, int n,
                     float* mean_out, float* cov_out, hipStream_t stream);
 int launch_gsf_ekf(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int K,
@@ -53,6 +57,21 @@ extern std::atomic<int> g_bpf_hbm_mode;
 extern std::atomic<int> g_gsf_structured;
 static std::atomic<int> g_kf_emit_mode{-1};  // -1 = choose from the layout
 static std::atomic<int> g_kf_lanes{0};       // 0 = default lanes per trajectory for the (n, m) pair
+static std::atomic<int> g_force_generic{0};  // 1 = run the run-time-dimension kernel even where a compiled instance exists
+
+// A shape / option the compiled instances do not cover falls through to the run-time-dimension kernel
+// (generic_scan.hip); if that cannot run it either, both reasons are reported.
+template <class F>
+static int with_generic_fallback(int rc, F&& generic) {
+  if (rc != BF_EUNSUPPORTED) return rc;
+  char first[512];
+  std::snprintf(first, sizeof(first), "%s", last_error_buf());
+  const int rc2 = generic();
+  if (rc2 == BF_OK) return BF_OK;
+  char second[512];
+  std::snprintf(second, sizeof(second), "%s", last_error_buf());
+  return set_error(rc2, "%.240s; generic kernel: %.240s", first, second);
+}
 
 }  // namespace bf
 
@@ -98,6 +117,11 @@ int bf_set_option(const char* name, int value) {
   if (name && std::strcmp(name, "kf_lanes") == 0) {
     if (value < 0 || value > 64 || (value & (value - 1)) != 0) return bf::set_error(BF_EINVAL, "kf_lanes must be 0 or a power of two <= 64");
     bf::g_kf_lanes = value;
+    return BF_OK;
+  }
+  if (name && std::strcmp(name, "force_generic") == 0) {
+    if (value < 0 || value > 1) return bf::set_error(BF_EINVAL, "force_generic must be 0 or 1");
+    bf::g_force_generic = value;
     return BF_OK;
   }
   if (name && std::strcmp(name, "gsf_structured") == 0) {
@@ -150,10 +174,13 @@ int bf_kalman_filter_f32(const bf_lgssm* model, const bf_cstream* y, int64_t B, 
   if (model->Q_steps < 1 || model->R_steps < 1) return bf::set_error(BF_EINVAL, "Q_steps / R_steps must be >= 1");
   if (!y->ptr) return bf::set_error(BF_EINVAL, "observations pointer is NULL");
   if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  auto generic = [&]() { return bf::launch_kf_generic(model, y, B, T, carry, out, hs); };
+  if (bf::g_force_generic.load()) return generic();
   if (model->n == 64 && model->m == 32)  // dense products large enough for the fp32 matrix cores
-    return bf::launch_kf_mfma(model, y, B, T, carry, out, static_cast<hipStream_t>(stream));
-  return bf::launch_kf_group(model, y, B, T, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode.load(),
-                             bf::g_kf_lanes.load());
+    return bf::with_generic_fallback(bf::launch_kf_mfma(model, y, B, T, carry, out, hs), generic);
+  return bf::with_generic_fallback(
+      bf::launch_kf_group(model, y, B, T, carry, out, hs, bf::g_kf_emit_mode.load(), bf::g_kf_lanes.load()), generic);
 }
 
 int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream* u, int64_t B, int64_t T, int32_t K,
@@ -165,8 +192,11 @@ int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream*
   if (!model->Q || !model->R) return bf::set_error(BF_EINVAL, "Q and R are required");
   if (!y->ptr) return bf::set_error(BF_EINVAL, "observations pointer is NULL");
   if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
-  return bf::launch_gsf_ekf(model, y, u, B, T, K, carry, out, static_cast<hipStream_t>(stream), bf::g_kf_emit_mode.load(),
-                            bf::g_kf_lanes.load());
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  auto generic = [&]() { return bf::launch_gsf_generic(model, y, u, B, T, K, carry, out, hs); };
+  if (bf::g_force_generic.load()) return generic();
+  return bf::with_generic_fallback(
+      bf::launch_gsf_ekf(model, y, u, B, T, K, carry, out, hs, bf::g_kf_emit_mode.load(), bf::g_kf_lanes.load()), generic);
 }
 
 int bf_ugsf_ukf_f32(const bf_model* model, const bf_ukf_params* uparams, const bf_cstream* y, const bf_cstream* u,

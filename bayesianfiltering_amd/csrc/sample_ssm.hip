@@ -95,7 +95,6 @@ static int launch_sample_dims(const bf_bpf_model* bp, const uint32_t* d_keys, co
     EmissionNoise<M> en;
   } h;
   std::memset(&h, 0, sizeof(h));  // the constant cache compares contents: no indeterminate padding
-  std::memset(&h, 0, sizeof(h));
   // reuse the particle-filter model fill with the emission-noise covariance standing in for the
   // log-density covariance and r_eval = 0; the stochastic-volatility emission is evaluated here
   bf_bpf_model tmp = *bp;
@@ -141,11 +140,14 @@ static int launch_sample_dims(const bf_bpf_model* bp, const uint32_t* d_keys, co
   return BF_OK;
 }
 
+int launch_sample_generic(const bf_bpf_model* bp, const uint32_t* d_keys, const bf_cstream* u, long long B, long long T,
+                          float* d_states, float* d_emis, hipStream_t stream);
+
 int launch_sample_ssm(const bf_bpf_model* bp, const uint32_t* d_keys, const bf_cstream* u, long long B, long long T,
                       float* d_states, float* d_emis, hipStream_t stream) {
   const bf_model* p = &bp->ssm;
 #define BF_CASE(N_, DQ_, M_) \
-  if (p->n == N_ && p->dq == DQ_ && p->m == M_) return launch_sample_dims<N_, DQ_, M_>(bp, d_keys, u, B, T, d_states, d_emis, stream)
+  if (p->n == N_ && p->dq == DQ_ && p->m == M_ && p->dr == M_) return launch_sample_dims<N_, DQ_, M_>(bp, d_keys, u, B, T, d_states, d_emis, stream)
   BF_CASE(1, 1, 1);
   BF_CASE(2, 2, 1);
   BF_CASE(2, 2, 2);
@@ -160,7 +162,8 @@ int launch_sample_ssm(const bf_bpf_model* bp, const uint32_t* d_keys, const bf_c
   BF_CASE(16, 16, 8);
   BF_CASE(4, 4, 4);
 #undef BF_CASE
-  return set_error(BF_EUNSUPPORTED, "sample_ssm: (n=%d, dq=%d, m=%d) is not compiled in", p->n, p->dq, p->m);
+  // any other shape: the run-time-dimension kernel (generic_scan.hip), one wave per trajectory
+  return launch_sample_generic(bp, d_keys, u, B, T, d_states, d_emis, stream);
 }
 
 }  // namespace bf

@@ -123,6 +123,8 @@ int bf_device_count(void);
  *                   stores, 2 = LDS time-transpose (contiguous reference layout only).
  *   "kf_lanes":     lanes that cooperate on one trajectory (0 = default for the dimensions;
  *                   otherwise one of the compiled powers of two, e.g. 1, 2 or 4 at n = 4).
+ *   "force_generic": 1 = bf_kalman_filter_f32 / bf_gsf_ekf_f32 run the run-time-dimension kernel (any n, m, K; state in
+ *                   LDS) even where a compile-time-dimension instance exists (test hook; default 0).
  *   "gsf_structured": 1 (default) lets bf_gsf_ekf_f32 use the structure-aware kernel instances
  *                   (banded Lorenz-96 Jacobian, selection emission) when the model qualifies;
  *                   0 forces the dense generic instances.

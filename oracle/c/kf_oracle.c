@@ -23,7 +23,7 @@
 
 #pragma STDC FP_CONTRACT OFF
 
-#define MAXN 64
+#define MAXN 128
 
 static void mm(const float* a, const float* b, float* c, int R, int K, int C) { /* c = a b */
   for (int i = 0; i < R; ++i)

@@ -119,3 +119,48 @@ def device_observations(params, dims, B, T, seed):
     import bayesianfiltering_amd as bfa
     keys = otf.split(otf.PRNGKey(seed), B)
     return bfa.NonlinearSSM(*dims).sample(params, keys, T)[1]
+
+
+def record(name, **metrics):
+    """Append measured parity figures to gpurun_out/parity_metrics.jsonl (best effort: evidence for DESIGN.md, never
+    a condition of the test)."""
+    import json
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_metrics.jsonl"), "a") as f:
+            f.write(json.dumps({"test": name, **{k: (float(v) if np.isscalar(v) else v) for k, v in metrics.items()}}) + "\n")
+    except OSError:
+        pass
+
+
+def one_step_parity(a, ys, pred_means, pred_covs, means, covs, loglik, steps):
+    """Teacher-forced parity of ONE trajectory: for every t in ``steps`` (t >= 1) the oracle's _condition_on + _predict
+    (gaussfiltax/inference.py:72-105, :51-70) are applied to the ENGINE's own carried prior (predicted mean / covariance
+    of step t - 1) and must reproduce the engine's outputs of step t.  Unlike a free-running comparison this does not
+    compound: it checks every step of a long scan at fp32 rounding level whatever the recursion's sensitivity (the
+    reference's un-symmetrised P - K S K^T has an unstable antisymmetric mode).  Arrays are (T, ...).
+    Returns the worst relative errors (per quantity, normalised by the quantity's own magnitude at that step)."""
+    p = oracle_params(a)
+    fn, hn = p.dynamics_function, p.emission_function
+    Q, R = np.asarray(a["Q"], F32), np.asarray(a["R"], F32)
+    q0, r0 = np.asarray(a["q0"], F32), np.asarray(a["r0"], F32)
+    u = np.zeros(1, F32)
+    worst = {"means": 0.0, "covariances": 0.0, "predicted_means": 0.0, "predicted_covariances": 0.0, "loglik": 0.0}
+
+    def upd(k, got, ref, floor):
+        e = float(np.max(np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64))) / max(float(np.max(np.abs(ref))), floor))
+        worst[k] = max(worst[k], e)
+
+    for t in steps:
+        ll, fm, fP, _, _ = go._condition_on(pred_means[t - 1].astype(F32), pred_covs[t - 1].astype(F32), hn, R, r0, u, ys[t])
+        pm, pP, _ = go._predict(fm, fP, fn, Q, q0, u)
+        upd("means", means[t], fm, 1e-3)
+        upd("covariances", covs[t], fP, 1e-6)
+        upd("loglik", loglik[t], ll, 1.0)
+        # the predict is checked on the engine's own filtered state, so an update error is not counted twice
+        pm2, pP2, _ = go._predict(means[t].astype(F32), covs[t].astype(F32), fn, Q, q0, u)
+        upd("predicted_means", pred_means[t], pm2, 1e-3)
+        upd("predicted_covariances", pred_covs[t], pP2, 1e-6)
+    return worst

@@ -193,9 +193,13 @@ def test_gsf_errors():
     from bayesianfiltering_amd import _lib
     a = cm.cv_model_arrays()
     ys = cm.simulate_batch(a, 1, 8, seed=1)[0]
-    with pytest.raises(_lib.BayesFiltError) as e:
-        bfa.gaussian_sum_filter(cm.product_params(a), ys, 300, initial_means=np.zeros((300, 4), F32))   # > 256 lanes
-    assert e.value.code == _lib.BF_EUNSUPPORTED
+    # 300 components exceed the 256 lanes of the register kernel: the run-time-dimension kernel takes over (tests/test_generic_gpu.py)
+    post = bfa.gaussian_sum_filter(cm.product_params(a), ys, 300, initial_means=np.zeros((300, 4), F32), fields=("weights",))
+    assert tuple(post.weights.shape) == (300, 8)
+    with pytest.raises(_lib.BayesFiltError) as e:   # what nothing can run: more LDS than a workgroup has
+        big = cm.random_stable_lgssm(200, 3, seed=1)
+        bfa.kalman_filter(cm.product_params(big), np.zeros((1, 4, 3), F32))
+    assert e.value.code == _lib.BF_EUNSUPPORTED and "LDS" in str(e.value)
 
 
 def test_collapse_matches_reference_formula():
