@@ -106,6 +106,7 @@ SYMBOLS = {
     "bf_sample_ssm_f32": (C.c_int, [C.POINTER(bf_bpf_model), C.c_void_p, C.POINTER(bf_cstream), C.c_int64, C.c_int64,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "bf_resample_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "bf_canon_eval_f32": (C.c_int, [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "bf_random_normal_f32": (C.c_int, [C.POINTER(C.c_uint32), C.c_int64, _FP]),
     "bf_random_split": (C.c_int, [C.POINTER(C.c_uint32), C.c_int64, C.POINTER(C.c_uint32)]),
     "bf_kalman_filter_f32": (C.c_int, [C.POINTER(bf_lgssm), C.POINTER(bf_cstream), C.c_int64, C.c_int64,

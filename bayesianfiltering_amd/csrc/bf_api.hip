@@ -57,6 +57,13 @@ extern std::atomic<int> g_bpf_hbm_mode;
 extern std::atomic<int> g_gsf_structured;
 static std::atomic<int> g_kf_emit_mode{-1};  // -1 = choose from the layout
 static std::atomic<int> g_kf_lanes{0};       // 0 = default lanes per trajectory for the (n, m) pair
+__global__ void canon_eval_kernel(int op, const float* __restrict__ in, long long n, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = in[i];
+  out[i] = op == 0 ? canon_log(x) : op == 1 ? canon_exp(x) : bits_to_normal(canon_f_bits(x));
+}
+
 static std::atomic<int> g_force_generic{0};  // 1 = run the run-time-dimension kernel even where a compiled instance exists
 
 // A shape / option the compiled instances do not cover falls through to the run-time-dimension kernel
@@ -289,6 +296,19 @@ int bf_resample_f32(const float* d_w, const uint32_t* d_keys, int64_t B, int32_t
                     void* stream) {
   if (!d_w || !d_keys || !d_idx || B <= 0 || N <= 0) return bf::set_error(BF_EINVAL, "bad argument");
   return bf::launch_resample(d_w, d_keys, B, N, resampler, d_idx, static_cast<hipStream_t>(stream));
+}
+
+int bf_canon_eval_f32(int32_t op, const float* in, int64_t n, float* out, int32_t on_device, void* stream) {
+  if (op < 0 || op > 2 || !in || !out || n < 0) return bf::set_error(BF_EINVAL, "bad argument");
+  if (n == 0) return BF_OK;
+  if (!on_device) {
+    for (int64_t i = 0; i < n; ++i)
+      out[i] = op == 0 ? bf::canon_log(in[i]) : op == 1 ? bf::canon_exp(in[i]) : bf::bits_to_normal(bf::canon_f_bits(in[i]));
+    return BF_OK;
+  }
+  hipLaunchKernelGGL(bf::canon_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), op, in, n, out);
+  BF_HIP_CHECK(hipGetLastError());
+  return BF_OK;
 }
 
 int bf_random_normal_f32(const uint32_t key[2], int64_t count, float* host_out) {

@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include "bf_canon_math.hpp"
 
 namespace bf {
 
@@ -56,51 +57,47 @@ __host__ __device__ __forceinline__ float bits_to_unit(uint32_t bits) {  // [0, 
   return c.f - 1.0f;
 }
 
-// XLA's float32 erf_inv (Giles' single-precision polynomial)
+// XLA's float32 erf_inv (Giles' single-precision polynomial) on the canonical arithmetic of bf_canon_math.hpp:
+// t = x x and 1 - t rounded on their own (as XLA's log1p(-x x) sees them), w = -log(1 - t) by canon_log, the
+// polynomial by fma, an IEEE square root in the tail branch.  Host and device, and the oracle's restatement
+// (the test oracle: fp32.erfinv), return the same bits; against the libm-based form the result moves by <= 3 ulp.
 __host__ __device__ __forceinline__ float erfinv_f32(float x) {
-#ifdef __HIP_DEVICE_COMPILE__
-  // w = -log1p(-x^2) as -log(1 - x^2) on v_log_f32: forming 1 - x^2 costs w an ABSOLUTE error of ~6e-8, which
-  // the polynomials below (|p'/p| < 0.2) turn into < 2e-8 relative on the result -- under an ulp -- while
-  // libm's log1pf is ~35 instructions, 16 times per particle and step in the particle filter
-  float w = -0.6931471805599453f * __builtin_amdgcn_logf(fmaf(-x, x, 1.0f));
-#else
-  float w = -log1pf(-x * x);
-#endif
+#pragma clang fp contract(off)
+  const float t = x * x;
+  const float a = 1.0f - t;
+  float w = -canon_log(a);
   float p;
   if (w < 5.0f) {
     w = w - 2.5f;
     p = 2.81022636e-08f;
-    p = fmaf(p, w, 3.43273939e-07f);
-    p = fmaf(p, w, -3.5233877e-06f);
-    p = fmaf(p, w, -4.39150654e-06f);
-    p = fmaf(p, w, 0.00021858087f);
-    p = fmaf(p, w, -0.00125372503f);
-    p = fmaf(p, w, -0.00417768164f);
-    p = fmaf(p, w, 0.246640727f);
-    p = fmaf(p, w, 1.50140941f);
+    p = __builtin_fmaf(p, w, 3.43273939e-07f);
+    p = __builtin_fmaf(p, w, -3.5233877e-06f);
+    p = __builtin_fmaf(p, w, -4.39150654e-06f);
+    p = __builtin_fmaf(p, w, 0.00021858087f);
+    p = __builtin_fmaf(p, w, -0.00125372503f);
+    p = __builtin_fmaf(p, w, -0.00417768164f);
+    p = __builtin_fmaf(p, w, 0.246640727f);
+    p = __builtin_fmaf(p, w, 1.50140941f);
   } else {
-#ifdef __HIP_DEVICE_COMPILE__
-    w = __builtin_amdgcn_sqrtf(w) - 3.0f;
-#else
-    w = sqrtf(w) - 3.0f;
-#endif
+    w = __builtin_sqrtf(w) - 3.0f;  // correctly rounded (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt)
     p = -0.000200214257f;
-    p = fmaf(p, w, 0.000100950558f);
-    p = fmaf(p, w, 0.00134934322f);
-    p = fmaf(p, w, -0.00367342844f);
-    p = fmaf(p, w, 0.00573950773f);
-    p = fmaf(p, w, -0.0076224613f);
-    p = fmaf(p, w, 0.00943887047f);
-    p = fmaf(p, w, 1.00167406f);
-    p = fmaf(p, w, 2.83297682f);
+    p = __builtin_fmaf(p, w, 0.000100950558f);
+    p = __builtin_fmaf(p, w, 0.00134934322f);
+    p = __builtin_fmaf(p, w, -0.00367342844f);
+    p = __builtin_fmaf(p, w, 0.00573950773f);
+    p = __builtin_fmaf(p, w, -0.0076224613f);
+    p = __builtin_fmaf(p, w, 0.00943887047f);
+    p = __builtin_fmaf(p, w, 1.00167406f);
+    p = __builtin_fmaf(p, w, 2.83297682f);
   }
   return fabsf(x) == 1.0f ? x * __builtin_inff() : p * x;
 }
 
 // jax.random.normal's map: u = max(lo, unit * (1 - lo) + lo), lo = nextafter(-1, 0); sqrt(2) * erf_inv(u)
 __host__ __device__ __forceinline__ float bits_to_normal(uint32_t bits) {
+#pragma clang fp contract(off)
   const float lo = -0.99999994f;
-  float u = bits_to_unit(bits) * (1.0f - lo) + lo;
+  float u = __builtin_fmaf(bits_to_unit(bits), 1.0f - lo, lo);  // (1 - lo) = 2.0f in binary32: the product is exact
   u = u > lo ? u : lo;
   return 1.41421356237309515f * erfinv_f32(u);
 }

@@ -92,37 +92,10 @@ template <int N, int DQ, int M>
 __device__ __forceinline__ float propagate_particle(const BpfModel<N, DQ, M>& mdl, U32x2 ki, float* xp, float u0, const float* yv) {
   float x[N], q[DQ], xn[N];
   BF_UNROLL for (int d = 0; d < N; ++d) x[d] = xp[d];
-  constexpr int h = (DQ + 1) / 2;
-  float zhi[h];
-  BF_UNROLL for (int d = 0; d < DQ; ++d) q[d] = 0.f;
-  BF_UNROLL for (int j = 0; j < h; ++j) {
-    const U32x2 o = threefry2x32(ki.x, ki.y, (uint32_t)j, (h + j < DQ) ? (uint32_t)(h + j) : 0u);
-    const float zj = bits_to_normal(o.x);
-    zhi[j] = (h + j < DQ) ? bits_to_normal(o.y) : 0.f;
-    BF_UNROLL for (int d = j; d < DQ; ++d) q[d] = fmaf(mdl.LQ[d * DQ + j], zj, q[d]);
-  }
-  BF_UNROLL for (int j = 0; h + j < DQ; ++j)
-    BF_UNROLL for (int d = h + j; d < DQ; ++d) q[d] = fmaf(mdl.LQ[d * DQ + h + j], zhi[j], q[d]);
-  BF_UNROLL for (int d = 0; d < DQ; ++d) q[d] = mdl.q0[d] + q[d];
+  draw_dynamics_noise<N, DQ, M>(mdl, ki, q);
   dyn_value<N, DQ, M>(mdl, x, q, u0, xn);
   BF_UNROLL for (int d = 0; d < N; ++d) xp[d] = xn[d];
-  float hx[M], zz[M];
-  emi_value<N, DQ, M>(mdl, xn, u0, hx);
-  float quad = 0.f, lsc = 0.f;
-  BF_UNROLL for (int a = 0; a < M; ++a) {
-    float s = yv[a] - hx[a];
-    if constexpr (N == M) {
-      if (mdl.emi_id == EMI_STOCH_VOL) {  // state-dependent covariance M R M^T (ssm_device.hpp)
-        const float d = sv_scale(mdl, xn[a], u0);
-        s /= d;
-        lsc += logf(d);
-      }
-    }
-    BF_UNROLL for (int cc = 0; cc < a; ++cc) s = fmaf(-mdl.LR[a * M + cc], zz[cc], s);
-    zz[a] = s * mdl.rdLR[a];
-    quad = fmaf(zz[a], zz[a], quad);
-  }
-  return -0.5f * quad + mdl.lp_const - lsc;
+  return emission_loglik<N, DQ, M>(mdl, xn, u0, yv);
 }
 
 template <int N, int DQ, int M>
@@ -240,7 +213,7 @@ bpf_big_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const float
       float e = 0.f;
       if (i < NP) {
 #pragma clang fp contract(off)
-        e = expf(gl[i] - mx) * gw[i];
+        e = canon_exp(gl[i] - mx) * gw[i];
         gl[i] = e;
       }
       const float cs = block_reduce(e, fadd);
@@ -349,7 +322,7 @@ bpf_big_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const float
     }
     if (tid == 0) {
       if (out.ess) out.ess[b * T + t] = ess;
-      if (out.logz) out.logz[b * T + t] = mx + logf(tot);
+      if (out.logz) out.logz[b * T + t] = mx + canon_log(tot);
       if (out.resampled) out.resampled[b * T + t] = do_resample ? 1.0f : 0.0f;
     }
     if (do_resample) {  // the gather target becomes the current buffer

@@ -201,7 +201,7 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
       BF_UNROLL for (int d = 0; d < N; ++d) z[d] = bits_to_normal(threefry_bits(ki.x, ki.y, (uint32_t)d, (uint32_t)N));
       BF_UNROLL for (int d = 0; d < N; ++d) {
         float s = 0.f;
-        BF_UNROLL for (int c = 0; c <= d; ++c) s = fmaf(mdl.L0[d * N + c], z[c], s);
+        BF_UNROLL for (int c = 0; c <= d; ++c) s = __builtin_fmaf(mdl.L0[d * N + c], z[c], s);
         x[p][d] = mdl.m0[d] + s;
       }
       w[p] = valid[p] ? 1.0f / (float)NP : 0.f;
@@ -212,6 +212,8 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
   }
 
   for (long long t = 0; t < T; ++t) {
+    // canonical arithmetic of the weight path (bf_canon_math.hpp): products are rounded before they enter a tree or a sum
+#pragma clang fp contract(off)
     float yv[M];
     BF_UNROLL for (int a = 0; a < M; ++a) yv[a] = y.p[b * y.sB + t * y.sT + a * y.sE];
     const float u0 = uptr ? uptr[b * u_sB + t * u_sT] : 0.f;
@@ -223,48 +225,11 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
       const uint32_t i = valid[p] ? (uint32_t)(tid * PPT + p) : 0u;
       const U32x2 ki = threefry_split(k0, k1, i + 1u, (uint32_t)NP + 1u);
       float q[DQ], xn[N];
-      // q = q0 + chol(Q) z accumulated column by column as the normals arrive (same fmaf order per
-      // entry as the row-wise product: ascending column), so no z vector stays live.
-      // normal(key_i, (dq,)): block j yields entries j and h + j
-      constexpr int h = (DQ + 1) / 2;
-      float zhi[h];
-      BF_UNROLL for (int d = 0; d < DQ; ++d) q[d] = 0.f;
-      BF_UNROLL for (int j = 0; j < h; ++j) {
-        const U32x2 o = threefry2x32(ki.x, ki.y, (uint32_t)j, (h + j < DQ) ? (uint32_t)(h + j) : 0u);
-        const float zj = bits_to_normal(o.x);
-        zhi[j] = (h + j < DQ) ? bits_to_normal(o.y) : 0.f;
-        if (mdl.lq_diag) q[j] = mdl.LQ[j * DQ + j] * zj;
-        else BF_UNROLL for (int d = j; d < DQ; ++d) q[d] = fmaf(mdl.LQ[d * DQ + j], zj, q[d]);
-      }
-      BF_UNROLL for (int j = 0; h + j < DQ; ++j) {
-        if (mdl.lq_diag) q[h + j] = mdl.LQ[(h + j) * DQ + h + j] * zhi[j];
-        else BF_UNROLL for (int d = h + j; d < DQ; ++d) q[d] = fmaf(mdl.LQ[d * DQ + h + j], zhi[j], q[d]);
-      }
-      BF_UNROLL for (int d = 0; d < DQ; ++d) q[d] = mdl.q0[d] + q[d];
+      draw_dynamics_noise<N, DQ, M>(mdl, ki, q);
       dyn_value<N, DQ, M>(mdl, x[p], q, u0, xn);
       BF_UNROLL for (int d = 0; d < N; ++d) x[p][d] = xn[d];
-      // MVN(h(x), R).log_prob(y) through the Cholesky factor (tfp), forward substitution
-      float hx[M], zz[M];
-      if (mdl.h_pick) {  // selection emission (e.g. the even states of Lorenz-96): the zero terms of H x are skipped
-        BF_UNROLL for (int a = 0; a < M; ++a) hx[a] = xn[(2 * a) % N] + mdl.hb[a];
-      } else {
-        emi_value<N, DQ, M>(mdl, xn, u0, hx);
-      }
-      float quad = 0.f, lsc = 0.f;
-      BF_UNROLL for (int a = 0; a < M; ++a) {
-        float s = yv[a] - hx[a];
-        if constexpr (N == M) {
-          if (mdl.emi_id == EMI_STOCH_VOL) {  // state-dependent covariance M R M^T (ssm_device.hpp)
-            const float d = sv_scale(mdl, xn[a], u0);
-            s /= d;
-            lsc += logf(d);
-          }
-        }
-        if (!mdl.lr_diag) BF_UNROLL for (int c = 0; c < a; ++c) s = fmaf(-mdl.LR[a * M + c], zz[c], s);
-        zz[a] = s * mdl.rdLR[a];
-        quad = fmaf(zz[a], zz[a], quad);
-      }
-      ll[p] = valid[p] ? (-0.5f * quad + mdl.lp_const - lsc) : -__builtin_inff();
+      const float llp = emission_loglik<N, DQ, M>(mdl, xn, u0, yv);
+      ll[p] = valid[p] ? llp : -__builtin_inff();
       // one particle at a time: interleaving the PPT independent Threefry / erfinv chains overruns the
       // 128-VGPR budget of the 1024-thread geometry and spills
       __builtin_amdgcn_sched_barrier(0);
@@ -273,7 +238,7 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
     // ---- reweight (inference.py:1350-1353)
     const float mx = block_reduce(thread_tree(ll, nanmax), nanmax);
     float e[PPT];
-    BF_UNROLL for (int p = 0; p < PPT; ++p) e[p] = valid[p] ? expf(ll[p] - mx) * w[p] : 0.f;
+    BF_UNROLL for (int p = 0; p < PPT; ++p) e[p] = valid[p] ? canon_exp(ll[p] - mx) * w[p] : 0.f;
     const float tot = block_reduce(thread_tree(e, fadd), fadd);
     float wn[PPT], w2[PPT];
     BF_UNROLL for (int p = 0; p < PPT; ++p) {
@@ -334,7 +299,7 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
     }
     if (tid == 0) {
       if (out.ess) out.ess[b * T + t] = ess;
-      if (out.logz) out.logz[b * T + t] = mx + logf(tot);
+      if (out.logz) out.logz[b * T + t] = mx + canon_log(tot);
       if (out.resampled) out.resampled[b * T + t] = do_resample ? 1.0f : 0.0f;
     }
   }

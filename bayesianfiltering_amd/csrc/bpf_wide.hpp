@@ -162,7 +162,7 @@ static __global__ void __launch_bounds__(BIG_NT) wide_weights_kernel(WideScratch
   float e = 0.f;
   if (i < NP) {
 #pragma clang fp contract(off)
-    e = expf(sc.s.ll[b * NP + i] - mx) * sc.s.w[b * NP + i];
+    e = canon_exp(sc.s.ll[b * NP + i] - mx) * sc.s.w[b * NP + i];
     sc.s.ll[b * NP + i] = e;
   }
   const float cs = wide_block_reduce(e, WideAdd(), red);
@@ -286,7 +286,7 @@ wide_finish_kernel(WideScratch sc, BpfOut out, long long B, long long T, long lo
   }
   if (tid == 0) {
     if (out.ess) out.ess[b * T + t] = ess;
-    if (out.logz) out.logz[b * T + t] = mx + logf(tot);
+    if (out.logz) out.logz[b * T + t] = mx + canon_log(tot);
     if (out.resampled) out.resampled[b * T + t] = do_resample ? 1.0f : 0.0f;
     const uint32_t k0 = sc.keys[(p * B + b) * 2], k1 = sc.keys[(p * B + b) * 2 + 1];
     U32x2 nk = threefry_split(k0, k1, 0u, (uint32_t)NP + 1u);

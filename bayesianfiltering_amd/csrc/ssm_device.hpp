@@ -4,8 +4,10 @@
 #pragma once
 #include <cstring>
 #include "bf_common.hpp"
+#include "bf_rng.hpp"
 #include "kf_math.hpp"
 #include "models.hpp"
+#include "bf_canon_math.hpp"
 
 namespace bf {
 
@@ -31,6 +33,9 @@ struct BpfModel {
 // with the fields dyn_id, dth, A, Gm, g_identity
 template <int N, int DQ, class MDL>
 __device__ __forceinline__ void dyn_value_t(const MDL& p, const float* x, const float* q, float u0, float* out) {
+  // canonical arithmetic (bf_canon_math.hpp): every operation rounded on its own, in the order written -- the order
+  // of the test oracle's NumPy expressions -- and fused multiply-adds only where spelled out (mv)
+#pragma clang fp contract(off)
   switch (p.dyn_id) {
     case DYN_LINEAR: mv<N, N>(p.A, x, out); break;
     case DYN_LORENZ96: {
@@ -96,6 +101,7 @@ __device__ __forceinline__ void dyn_value(const BpfModel<N, DQ, M>& p, const flo
 // model struct with the fields emi_id, eth, Hm
 template <int N, int M, class MDL>
 __device__ __forceinline__ void emi_mean_t(const MDL& p, const float* x, float u0, float* hx) {
+#pragma clang fp contract(off)
   switch (p.emi_id) {
     case EMI_LINEAR: mv<M, N>(p.Hm, x, hx); break;
     case EMI_BEARING_RANGE:
@@ -125,17 +131,19 @@ __device__ __forceinline__ void emi_mean_t(const MDL& p, const float* x, float u
 // joins the log-determinant.
 template <class MDL>
 __device__ __forceinline__ float sv_scale(const MDL& p, float xa, float u0) {
-  return u0 * p.eth[1] * expf(xa / p.eth[0]) + (1.f - u0);
+#pragma clang fp contract(off)
+  return u0 * p.eth[1] * canon_exp(xa / p.eth[0]) + (1.f - u0);
 }
 
 // mean of the emission density: h(x, r_eval, u) for the registry emissions with constant H_r (hb = H_r r_eval), and
 // for the stochastic-volatility emission (hb = r_eval)
 template <int N, int DQ, int M>
 __device__ __forceinline__ void emi_value(const BpfModel<N, DQ, M>& p, const float* x, float u0, float* hx) {
+#pragma clang fp contract(off)
   if constexpr (N == M) {
     if (p.emi_id == EMI_STOCH_VOL) {
       BF_UNROLL for (int a = 0; a < M; ++a)
-        hx[a] = u0 * p.eth[1] * expf(x[a] / p.eth[0]) * p.hb[a] + (1.f - u0) * (p.eth[2] * x[a] + p.hb[a]);
+        hx[a] = u0 * p.eth[1] * canon_exp(x[a] / p.eth[0]) * p.hb[a] + (1.f - u0) * (p.eth[2] * x[a] + p.hb[a]);
       return;
     }
   }
@@ -143,7 +151,60 @@ __device__ __forceinline__ void emi_value(const BpfModel<N, DQ, M>& p, const flo
   BF_UNROLL for (int a = 0; a < M; ++a) hx[a] += p.hb[a];
 }
 
+// q = q0 + chol(Q) normal(key_i, (dq,)) (gaussfiltax/models.py:82-83): accumulated column by column as the normals
+// arrive (per entry the same fma chain as the row-wise product, c ascending from 0), so no z vector stays live.
+// normal(key, (dq,)): Threefry block j yields entries j and h + j.
+template <int N, int DQ, int M>
+__device__ __forceinline__ void draw_dynamics_noise(const BpfModel<N, DQ, M>& mdl, U32x2 ki, float* q) {
+  constexpr int h = (DQ + 1) / 2;
+  float zhi[h];
+  BF_UNROLL for (int d = 0; d < DQ; ++d) q[d] = 0.f;
+  BF_UNROLL for (int j = 0; j < h; ++j) {
+    const U32x2 o = threefry2x32(ki.x, ki.y, (uint32_t)j, (h + j < DQ) ? (uint32_t)(h + j) : 0u);
+    const float zj = bits_to_normal(o.x);
+    zhi[j] = (h + j < DQ) ? bits_to_normal(o.y) : 0.f;
+    if (mdl.lq_diag) q[j] = mdl.LQ[j * DQ + j] * zj;
+    else BF_UNROLL for (int d = j; d < DQ; ++d) q[d] = __builtin_fmaf(mdl.LQ[d * DQ + j], zj, q[d]);
+  }
+  BF_UNROLL for (int j = 0; h + j < DQ; ++j) {
+    if (mdl.lq_diag) q[h + j] = mdl.LQ[(h + j) * DQ + h + j] * zhi[j];
+    else BF_UNROLL for (int d = h + j; d < DQ; ++d) q[d] = __builtin_fmaf(mdl.LQ[d * DQ + h + j], zhi[j], q[d]);
+  }
+  BF_UNROLL for (int d = 0; d < DQ; ++d) q[d] = mdl.q0[d] + q[d];
+}
+
+// MVN(h(x, r_eval, u), R_lp).log_prob(y) (the `*lp` functions of the reference's scripts, e.g. nonlinearities.py:51-52)
+// through the Cholesky factor: forward substitution by fma, multiplication by the reciprocal diagonal, the quadratic
+// form by fma, -0.5 quad + const as ONE fma.  The oracle restates exactly this sequence (gaussfilt_oracle.py,
+// arith = "canonical").
+template <int N, int DQ, int M>
+__device__ __forceinline__ float emission_loglik(const BpfModel<N, DQ, M>& mdl, const float* xn, float u0, const float* yv) {
+#pragma clang fp contract(off)
+  float hx[M], zz[M];
+  if (mdl.h_pick) {  // selection emission (e.g. the even states of Lorenz-96): the exact-zero terms of H x are skipped
+    BF_UNROLL for (int a = 0; a < M; ++a) hx[a] = xn[(2 * a) % N] + mdl.hb[a];
+  } else {
+    emi_value<N, DQ, M>(mdl, xn, u0, hx);
+  }
+  float quad = 0.f, lsc = 0.f;
+  BF_UNROLL for (int a = 0; a < M; ++a) {
+    float s = yv[a] - hx[a];
+    if constexpr (N == M) {
+      if (mdl.emi_id == EMI_STOCH_VOL) {  // state-dependent covariance M R M^T: chol(M R M^T) = M chol(R)
+        const float d = sv_scale(mdl, xn[a], u0);
+        s = s / d;
+        lsc = lsc + canon_log(d);
+      }
+    }
+    if (!mdl.lr_diag) BF_UNROLL for (int c = 0; c < a; ++c) s = __builtin_fmaf(-mdl.LR[a * M + c], zz[c], s);
+    zz[a] = s * mdl.rdLR[a];
+    quad = __builtin_fmaf(zz[a], zz[a], quad);
+  }
+  return __builtin_fmaf(-0.5f, quad, mdl.lp_const) - lsc;
+}
+
 static inline int cholesky_lower(const float* A, int n, float* L) {  // fp32, row-major; returns 0 or -1 (not PD)
+#pragma clang fp contract(off)  // every operation rounded on its own: what the test oracle's NumPy loop does
   for (int i = 0; i < n * n; ++i) L[i] = 0.f;
   for (int j = 0; j < n; ++j) {
     float d = A[j * n + j];
@@ -162,6 +223,7 @@ static inline int cholesky_lower(const float* A, int n, float* L) {  // fp32, ro
 
 template <int N, int DQ, int M>
 static inline int fill_bpf_model(const bf_bpf_model* bp, BpfModel<N, DQ, M>& e) {
+#pragma clang fp contract(off)
   const bf_model* p = &bp->ssm;
   if (p->Q_steps > 1 || p->R_steps > 1)
     return set_error(BF_EUNSUPPORTED, "time-varying Q/R are not supported by the sampling kernels (particle filter, data generator)");
@@ -256,7 +318,7 @@ static inline int fill_bpf_model(const bf_bpf_model* bp, BpfModel<N, DQ, M>& e) 
   float logdet = 0.f;
   for (int i = 0; i < M; ++i) {
     e.rdLR[i] = 1.0f / e.LR[i * M + i];
-    logdet += logf(e.LR[i * M + i]);
+    logdet += canon_log(e.LR[i * M + i]);
   }
   e.lp_const = -0.5f * (float)M * 1.8378770664093453f - logdet;
   for (int i = 0; i < N; ++i) e.m0[i] = bp->m0[i];

@@ -289,6 +289,13 @@ int bf_sample_ssm_f32(const bf_bpf_model* model, const uint32_t* d_keys, const b
 int bf_resample_f32(const float* d_w, const uint32_t* d_keys, int64_t B, int32_t N, int32_t resampler,
                     int32_t* d_idx, void* stream);
 
+/* The canonical fp32 arithmetic of the particle filter's weight path (csrc/bf_canon_math.hpp: IEEE add / mul / div /
+ * sqrt / fma and integer operations in a fixed order, identical on host and device, restated by the oracle so that
+ * in-filter resampling indices are bit-exact), evaluated elementwise: op 0 = log, 1 = exp, 2 = jax.random.normal's
+ * bits -> N(0,1) map (the input words are the raw uint32 bits).  on_device = 0: HOST buffers, evaluated by the host
+ * build of the same functions; 1: DEVICE buffers, one lane per element.  A test / audit hook. */
+int bf_canon_eval_f32(int32_t op, const float* in, int64_t n, float* out, int32_t on_device, void* stream);
+
 /* jax.random.normal(key, (count,)) for the default threefry PRNG, written to a HOST buffer
  * (used for the reference's fixed `MVN(m0, P0).sample(K, PRNGKey(0))` draw of the initial
  * component means, inference.py:367: m0 + chol(P0) z).  key = {hi, lo} as jr.PRNGKey. */

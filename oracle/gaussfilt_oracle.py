@@ -594,6 +594,40 @@ class GaussianEmissionLogProb:
     def __call__(self, x, y, u):
         return mvn_log_prob(self.hn.value(np.asarray(x, dtype=F32), self.r_eval, u), self.R, y)
 
+    def logprob_c(self, X, y, u):
+        """Canonical fp32 arithmetic (oracle/fp32.py), batched over particles X (N, n): the sequence the HIP engine runs
+        (ssm_device.hpp: emission_loglik) -- Cholesky factor by plain loops, forward substitution by fma, multiplication by
+        the reciprocal diagonal, quadratic form by fma, -0.5 quad + const as one fma."""
+        return _gaussian_logprob_c(self.hn.value_c(np.asarray(X, dtype=F32), np.tile(self.r_eval, (len(X), 1)), u), self.R, y, None)
+
+
+def _gaussian_logprob_c(HX, R, y, scale):
+    from . import fp32
+    R = np.asarray(R, dtype=F32)
+    m = R.shape[0]
+    L = fp32.cholesky_lower(R)
+    rd = (F32(1.0) / np.diag(L)).astype(F32)
+    logdet = F32(0.0)
+    for i in range(m):
+        logdet = F32(logdet + fp32.canon_log(L[i, i])[0])
+    lp_const = F32(F32(F32(-0.5) * F32(m)) * F32(1.8378770664093453) - logdet)
+    y = np.asarray(y, dtype=F32).reshape(m)
+    N = HX.shape[0]
+    zz = np.zeros((N, m), dtype=F32)
+    quad = np.zeros(N, dtype=F32)
+    lsc = np.zeros(N, dtype=F32)
+    with np.errstate(invalid="ignore", over="ignore", divide="ignore"):
+        for a in range(m):
+            sres = (y[a] - HX[:, a]).astype(F32)
+            if scale is not None:
+                sres = (sres / scale[:, a]).astype(F32)
+                lsc = (lsc + fp32.canon_log(scale[:, a])).astype(F32)
+            for c in range(a):
+                sres = fp32.fma(-L[a, c], zz[:, c], sres)
+            zz[:, a] = (sres * rd[a]).astype(F32)
+            quad = fp32.fma(zz[:, a], zz[:, a], quad)
+        return (fp32.fma(F32(-0.5), quad, lp_const) - lsc).astype(F32)
+
 
 class StochVolEmissionLogProb:
     """lmsvlp (docs/experiments/adaptive_experiment.py:55-57): MVN(loc=glmsv(x, r0, u), covariance_matrix=M R M^T)
@@ -610,6 +644,12 @@ class StochVolEmissionLogProb:
         Mx = self.hn.jac_noise(x, self.r_eval, u)
         cov = _mm(_mm(Mx, self.R), Mx.T)
         return mvn_log_prob(self.hn.value(x, self.r_eval, u), cov, y)
+
+    def logprob_c(self, X, y, u):
+        """Canonical arithmetic: chol(M R M^T) = M chol(R) for the positive diagonal M -- the residual is divided by
+        diag(M) before the constant factor's forward substitution and sum log M_ii joins the log-determinant."""
+        X = np.asarray(X, dtype=F32)
+        return _gaussian_logprob_c(self.hn.value_c(X, np.tile(self.r_eval, (len(X), 1)), u), self.R, y, self.hn.scale_c(X, u))
 
 
 def sample_dynamics_distribution(params, key, x, u, cholQ=None):
@@ -638,10 +678,74 @@ def systematic_indices(weights, u0):
     return np.minimum(np.searchsorted(cdf, pos.astype(F32), side="left"), N - 1).astype(np.int32)
 
 
+def _bpf_canonical(params, emissions, num_particles, key, inputs, ess_threshold, resampler, debug):
+    """inference.py:1302-1380 on the canonical fp32 arithmetic of oracle/fp32.py, vectorised over the particles: the
+    operation sequence of the HIP engine's particle kernels, so that weights -- and with them every ancestor index of
+    every step -- agree bit for bit.  Same structure as the loop below; only the rounding of each quantity is pinned."""
+    from . import fp32
+    emissions = np.asarray(emissions, dtype=F32)
+    T, N = len(emissions), num_particles
+    inputs = _process_input(inputs, T)
+    fn, lp = params.dynamics_function, params.emission_distribution_log_prob
+    if not hasattr(fn, "value_c") or not hasattr(lp, "logprob_c") or not hasattr(lp.hn, "value_c"):
+        raise NotImplementedError("canonical arithmetic is defined for models built from IEEE operations, exp and log")
+    m0 = np.asarray(params.initial_mean, dtype=F32)
+    n = m0.size
+    q0 = np.asarray(params.dynamics_noise_bias, dtype=F32)
+    L0 = fp32.cholesky_lower(params.initial_covariance)
+    LQ = fp32.cholesky_lower(_get_params(params.dynamics_noise_covariance, 2, 0))
+    dq = LQ.shape[0]
+    keys = tf.split(key, N + 1)                                  # :1369
+    next_key = keys[0]
+    weights = (np.ones(N, dtype=F32) / F32(N)).astype(F32)
+    z = fp32.bits_to_normal(tf.random_bits_keys(keys[1:], n))    # :1372-1373: MVN(m0, P0).sample(seed = keys[1 + i])
+    particles = (m0 + fp32.lower_matvec_fma(L0, z)).astype(F32)
+    out_w = np.empty((T, N), F32)
+    out_x = np.empty((T, N, n), F32)
+    dbg = {"resampled": np.zeros(T, bool), "ancestors": np.tile(np.arange(N, dtype=np.int32), (T, 1)),
+           "ess": np.zeros(T, F32), "pre_weights": np.empty((T, N), F32)}
+    for t in range(T):
+        u, y = inputs[t], emissions[t]
+        keys = tf.split(next_key, N + 1)                          # :1342
+        next_key = keys[0]
+        z = fp32.bits_to_normal(tf.random_bits_keys(keys[1:], dq))
+        q = (q0 + fp32.lower_matvec_fma(LQ, z)).astype(F32)       # models.py:82-83
+        new_particles = fn.value_c(particles, q, u)               # :1344-1345
+        lls = lp.logprob_c(new_particles, y, u)                   # :1348-1349
+        with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+            e = (fp32.canon_exp((lls - np.max(lls)).astype(F32)) * weights).astype(F32)   # :1350-1352
+            new_weights = (e / sum_f32(e)).astype(F32)            # :1353
+            ess = F32(1.0) / sum_f32((new_weights * new_weights).astype(F32))
+        dbg["ess"][t] = ess
+        dbg["pre_weights"][t] = new_weights
+        if ess < F32(ess_threshold) * F32(N):                    # :1356
+            if resampler == "multinomial":
+                weights, new_particles, next_key, idx = _resample(new_weights, new_particles, next_key)
+            else:
+                ks = tf.split(next_key, 2)
+                idx = systematic_indices(new_weights, tf.uniform(ks[0], 1)[0])
+                new_particles = new_particles[idx]
+                weights = (np.ones(N, dtype=F32) / F32(N)).astype(F32)
+                next_key = ks[1]
+            dbg["resampled"][t] = True
+            dbg["ancestors"][t] = idx
+        else:
+            weights = new_weights
+        particles = new_particles
+        out_w[t] = weights
+        out_x[t] = particles
+    out = {"weights": out_w.swapaxes(0, 1).copy(), "particles": out_x.swapaxes(0, 1).copy()}
+    return (out, dbg) if debug else out
+
+
 def bootstrap_particle_filter(params, emissions, num_particles, key=None, inputs=None,
-                              ess_threshold=0.5, resampler="multinomial", debug=False):
-    """inference.py:1302-1380."""
+                              ess_threshold=0.5, resampler="multinomial", debug=False, arith="libm"):
+    """inference.py:1302-1380.  ``arith``: "libm" = NumPy's float32 functions and BLAS products (the reference leaves the
+    rounding of exp / log1p / matrix products to XLA: any faithful choice is as good); "canonical" = the ONE definition of
+    oracle/fp32.py that the HIP engine also implements -- bit-exact ancestry (:func:`_bpf_canonical`)."""
     key = tf.PRNGKey(0) if key is None else np.asarray(key, dtype=np.uint32)
+    if arith == "canonical":
+        return _bpf_canonical(params, emissions, num_particles, key, inputs, ess_threshold, resampler, debug)
     emissions = np.asarray(emissions, dtype=F32)
     T = len(emissions)
     N = num_particles

@@ -47,6 +47,12 @@ class Linear(Fn):
     def value(self, x, w, u):
         return (self.M @ x + self.N @ w).astype(F32)
 
+    def value_c(self, X, W, u):
+        """Canonical fp32 arithmetic (oracle/fp32.py), batched: X (N, n), W (N, d) -> (N, out).  M x as an fma chain over
+        k ascending whose first term is a plain product (kf_math.hpp: mv), N w as an fma chain from 0, then one add."""
+        from . import fp32
+        return (fp32.dot_fma(self.M, X) + fp32.lower_matvec_fma(self.N, W)).astype(F32)
+
     def jac_x(self, x, w, u):
         return self.M
 
@@ -74,6 +80,14 @@ class Lorenz96(Fn):
     def value(self, x, w, u):
         ax, bx = self._ab(x)
         return (x + self.dt * (self.alpha * (ax * bx) - self.beta * x + self.gamma) + w).astype(F32)
+
+    def value_c(self, X, W, u):
+        """Canonical fp32 arithmetic, batched (N, n): the expression of :meth:`value` with every operation rounded on its
+        own, in the order written -- which is what NumPy does with float32 operands."""
+        X = np.asarray(X, dtype=F32)
+        ax = np.roll(X, 1, axis=-1)
+        bx = (np.roll(X, -1, axis=-1) - np.roll(X, 2, axis=-1)).astype(F32) if self.mode == "matrix_power" else np.zeros_like(X)
+        return (X + self.dt * (self.alpha * (ax * bx) - self.beta * X + self.gamma) + np.asarray(W, dtype=F32)).astype(F32)
 
     def jac_x(self, x, w, u):
         n = self.n
@@ -114,6 +128,16 @@ class Lorenz63(Fn):
         dy = dt * (x[0] * self.r - x[1] - x[0] * x[2])
         dz = dt * (x[0] * x[1] - self.b * x[2])
         return (np.array([dx + x[0], dy + x[1], dz + x[2]], dtype=F32) + w).astype(F32)
+
+    def value_c(self, X, W, u):
+        """Canonical fp32 arithmetic, batched (N, 3): :meth:`value` column-wise (every operation rounded on its own)."""
+        X = np.asarray(X, dtype=F32)
+        x0, x1, x2 = X[:, 0], X[:, 1], X[:, 2]
+        dt = self.dt
+        dx = dt * self.s * (x1 - x0)
+        dy = dt * (x0 * self.r - x1 - x0 * x2)
+        dz = dt * (x0 * x1 - self.b * x2)
+        return (np.stack([dx + x0, dy + x1, dz + x2], axis=1).astype(F32) + np.asarray(W, dtype=F32)).astype(F32)
 
     def jac_x(self, x, w, u):
         dt, s, r, b = self.dt, self.s, self.r, self.b
@@ -283,6 +307,22 @@ class StochVol(Fn):
     def value(self, x, w, u):
         uu = self._u(u)
         return (uu * self.beta * np.exp(x / self.sigma) * w + (1 - uu) * (self.c * x + w)).astype(F32)
+
+    def value_c(self, X, W, u):
+        """Canonical fp32 arithmetic, batched: :meth:`value` with exp by fp32.canon_exp."""
+        from . import fp32
+        uu = self._u(u)
+        X, W = np.asarray(X, dtype=F32), np.asarray(W, dtype=F32)
+        e = fp32.canon_exp((X / self.sigma).astype(F32)).reshape(X.shape)
+        return (uu * self.beta * e * W + (F32(1) - uu) * (self.c * X + W)).astype(F32)
+
+    def scale_c(self, X, u):
+        """Diagonal of the noise Jacobian M(x, u) = u beta exp(x / sigma) + (1 - u), canonical arithmetic."""
+        from . import fp32
+        uu = self._u(u)
+        X = np.asarray(X, dtype=F32)
+        e = fp32.canon_exp((X / self.sigma).astype(F32)).reshape(X.shape)
+        return (uu * self.beta * e + (F32(1) - uu)).astype(F32)
 
     def jac_x(self, x, w, u):
         uu = self._u(u)

@@ -42,13 +42,14 @@ def _rotl(x, r):
 
 
 def threefry2x32(k0, k1, x0, x1):
-    """Threefry-2x32-20 block function on uint32 arrays (vectorised over x0/x1)."""
+    """Threefry-2x32-20 block function on uint32 arrays (vectorised over x0/x1; the key words may be arrays that
+    broadcast against them: one key per row)."""
     with np.errstate(over="ignore"):
-        k0 = _U32(k0)
-        k1 = _U32(k1)
+        k0 = np.asarray(k0, dtype=_U32)
+        k1 = np.asarray(k1, dtype=_U32)
         x0 = np.asarray(x0, dtype=_U32).copy()
         x1 = np.asarray(x1, dtype=_U32).copy()
-        ks = (k0, k1, _U32(k0 ^ k1 ^ _U32(0x1BD11BDA)))
+        ks = (k0, k1, (k0 ^ k1 ^ _U32(0x1BD11BDA)).astype(_U32))
         x0 = (x0 + ks[0]).astype(_U32)
         x1 = (x1 + ks[1]).astype(_U32)
         for i in range(5):
@@ -87,6 +88,19 @@ def split(key, num=2):
 def random_bits(key, size):
     """jax.random.bits(key, (size,), uint32)."""
     return threefry_2x32(key, np.arange(size, dtype=_U32))
+
+
+def random_bits_keys(keys, size):
+    """random_bits for MANY keys at once: keys (N, 2) -> (N, size) uint32, row i = random_bits(keys[i], size)."""
+    keys = np.asarray(keys, dtype=_U32).reshape(-1, 2)
+    counts = np.arange(size, dtype=_U32)
+    odd = size % 2
+    if odd:
+        counts = np.concatenate([counts, np.zeros(1, dtype=_U32)])
+    half = counts.size // 2
+    o0, o1 = threefry2x32(keys[:, 0:1], keys[:, 1:2], counts[None, :half], counts[None, half:])
+    out = np.concatenate([o0, o1], axis=1)
+    return out[:, :-1] if odd else out
 
 
 def bits_to_uniform(bits, lo=np.float32(0.0), hi=np.float32(1.0)):
@@ -189,3 +203,10 @@ def mvn_sample(key, loc, chol):
     """tfp MultivariateNormalFullCovariance(loc, cov).sample(seed=key) = loc + chol @ z."""
     z = normal(key, loc.shape[0])
     return (loc + (chol @ z).astype(np.float32)).astype(np.float32)
+
+
+def normal_canonical(key, size):
+    """jax.random.normal(key, (size,)) on the canonical arithmetic of oracle/fp32.py (what the HIP engine computes,
+    bit for bit); within 3 ulp of :func:`normal`."""
+    from . import fp32
+    return fp32.bits_to_normal(random_bits(key, size))

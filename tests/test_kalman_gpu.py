@@ -105,7 +105,7 @@ def test_errors_are_loud():
     ys = cm.simulate_batch(a, 2, 8, seed=1)
     bfa.kalman_filter(cm.product_params(a), ys)     # n = 9 has no compiled instance: the run-time-dimension kernel runs it
     with pytest.raises(_lib.BayesFiltError) as e:
-        bfa.kalman_filter(cm.product_params(cm.random_stable_lgssm(200, 3, seed=1)), np.zeros((1, 4, 3), F32))
+        bfa.kalman_filter(cm.product_params(cm.random_stable_lgssm(200, 3, seed=1)), np.zeros((1, 4, 3), np.float32))
     assert e.value.code == _lib.BF_EUNSUPPORTED
     with pytest.raises(TypeError):
         bfa.kalman_filter(cm.product_params(a)._replace(dynamics_function=lambda x, q, u: x), ys)
