@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
-"""Headline benchmark: batched Kalman filter timesteps/s (BASELINE.json metric, configs[1]).
+"""Benchmark of the filtering hot path: filter timesteps/s (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                     # headline: BASELINE configs[1]
+    python bench.py --config {gsf32,bpf4096,kalman64} --gpus N ...    # configs[2..4]
 
-One "step" = one pass of the hot path (bf_kalman_filter_f32: the whole T-step scan) over one
-batch of B synthetic trajectories already resident in HBM.  N > 1 (launched by
-torch.distributed.run, one rank per GPU): every rank filters its own B trajectories (weak
-scaling: trajectories are independent, the batch axis shards with no traffic during the scan)
-and the per-trajectory posterior summaries (final mean, covariance, total log-likelihood) are
-all-gathered over RCCL inside the timed region.  Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path (the whole T-step scan) over one batch of synthetic trajectories already
+resident in HBM.  Observations are drawn FROM THE MODEL ITSELF on the device (bf_sample_ssm_f32 =
+NonlinearSSM.sample, gaussfiltax/models.py:240-289), so the filters track and stay finite; the JSON line reports the
+fraction of trajectories whose final posterior is finite.
 
-The line carries `roofline` (dominant kernel: algorithmic HBM bytes / HIP-event time vs the
-8 TB/s HBM3E peak) and `cpu_baseline` (the oracle's plain-C port on the host cores, a bounded
-sample of the same workload -- a reported baseline, not the target).
+N > 1 (launched by torch.distributed.run, one rank per GPU; the process group is initialised before anything else
+touches the GPU): trajectories are independent, the batch axis shards with no traffic during the scan, and the
+per-trajectory posterior summaries are all-gathered over RCCL inside the timed region.
+  * kalman4 (headline):           every rank filters its own 65 536 trajectories            -> "scaling": "weak"
+  * gsf32 / bpf4096 / kalman64:   BASELINE's total batch (16 384 / 8 192 / 32 768) is split
+                                  over the ranks with distributed.shard_bounds               -> "scaling": "strong"
+Rank 0 prints ONE JSON line carrying `roofline` (dominant kernel: algorithmic bytes / flops / issue slots per launch over
+its HIP-event time) and, for the headline at N = 1, `cpu_baseline` (the oracle's plain-C port on the host cores, a
+bounded sample of the same workload -- a reported baseline, not the target).
 """
 import argparse
 import json
@@ -20,39 +25,51 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL across processes)
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+FP32_PEAK_TFS = 157.3      # fp32 vector = fp32 MFMA peak
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2   # wave64 VALU instructions/ns the chip can issue: 256 CUs x 4 SIMDs x 2.4 GHz, 2 cycles each
+F32 = np.float32
 
 
 def cv_model():
     """constant-velocity LGSSM n=4, m=2 (BOT_Experiment_script.py:31-32,40)."""
     dt = 0.5
-    f32 = np.float32
     return dict(
-        A=np.array([[1, dt, 0, 0], [0, 1, 0, 0], [0, 0, 1, dt], [0, 0, 0, 1]], f32),
-        G=np.array([[0.5, 0], [1, 0], [0, 0.5], [0, 1]], f32),
-        H=np.array([[1, 0, 0, 0], [0, 0, 1, 0]], f32), D=np.eye(2, dtype=f32),
-        Q=1e-2 * np.eye(2, dtype=f32), R=1e-1 * np.eye(2, dtype=f32),
-        m0=np.zeros(4, f32), P0=np.eye(4, dtype=f32), q0=np.zeros(2, f32), r0=np.zeros(2, f32))
+        A=np.array([[1, dt, 0, 0], [0, 1, 0, 0], [0, 0, 1, dt], [0, 0, 0, 1]], F32),
+        G=np.array([[0.5, 0], [1, 0], [0, 0.5], [0, 1]], F32),
+        H=np.array([[1, 0, 0, 0], [0, 0, 1, 0]], F32), D=np.eye(2, dtype=F32),
+        Q=1e-2 * np.eye(2, dtype=F32), R=1e-1 * np.eye(2, dtype=F32),
+        m0=np.zeros(4, F32), P0=np.eye(4, dtype=F32), q0=np.zeros(2, F32), r0=np.zeros(2, F32))
 
 
-def simulate_on_device(params, B, T, seed, device):
-    """Synthetic observations (B, T, m): B independent trajectories of the model itself, generated by
-    the engine's device data generator (NonlinearSSM.sample, gaussfiltax/models.py:240-289) with
-    keys split(PRNGKey(seed), B).  Setup, untimed."""
+def random_stable_lgssm(n, m, seed):
+    """dense random-stable LGSSM (A = 0.95 x orthogonal, H ~ N(0, 1/n), Q = 1e-2 I, R = 1e-1 I)."""
+    rng = np.random.default_rng(seed)
+    Aq, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    return dict(A=(0.95 * Aq).astype(F32), G=np.eye(n, dtype=F32), H=(rng.normal(size=(m, n)) / np.sqrt(n)).astype(F32),
+                D=np.eye(m, dtype=F32), Q=(1e-2 * np.eye(n)).astype(F32), R=(1e-1 * np.eye(m)).astype(F32),
+                m0=np.zeros(n, F32), P0=np.eye(n, dtype=F32), q0=np.zeros(n, F32), r0=np.zeros(m, F32))
+
+
+def simulate_on_device(params, dims, B, T, seed, first=0):
+    """Synthetic observations (B, T, m): independent trajectories of the model itself from the engine's device data
+    generator with keys split(PRNGKey(seed), first + B)[first:].  Setup, untimed."""
     import ctypes as C
     import bayesianfiltering_amd as bfa
     from bayesianfiltering_amd import _lib
     lib = _lib.load()
     key = bfa.PRNGKey(seed)
-    keys = np.empty((B, 2), dtype=np.uint32)
-    _lib.check(lib.bf_random_split(key.ctypes.data_as(C.POINTER(C.c_uint32)), B, keys.ctypes.data_as(C.POINTER(C.c_uint32))))
-    _, y = bfa.NonlinearSSM(4, 2, 2, 2).sample(params, keys, T)
-    return y.to(device)
+    keys = np.empty((first + B, 2), dtype=np.uint32)
+    _lib.check(lib.bf_random_split(key.ctypes.data_as(C.POINTER(C.c_uint32)), first + B, keys.ctypes.data_as(C.POINTER(C.c_uint32))))
+    _, y = bfa.NonlinearSSM(*dims).sample(params, keys[first:], T)
+    return y
 
 
 def cpu_baseline(a, T, target_s=12.0):
@@ -78,112 +95,196 @@ def cpu_baseline(a, T, target_s=12.0):
                       f"all five streams, {dt:.1f} s"}
 
 
-def pmc_traffic(B, T, layout):
-    """HBM bytes per launch of the scan kernel from the committed rocprofv3 PMC passes
-    (profiles/*_summary.json: WRITE_SIZE and FETCH_SIZE collected in separate runs of the same
-    launch, in KiB).  WRITE_SIZE is exact for 16-byte-per-lane stores; FETCH_SIZE is taken as
-    reported (the reads here are 4-byte LDS-DMA loads, for which the gfx950 half-count of wide
-    loads is not calibrated -- reads are 5 % of the traffic).  None if no matching profile."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_%s_summary.json" % layout)
-    if not (os.path.exists(path) and B == 65536 and T == 10000):
-        return None
+def profiled(name):
+    """A figure measured by rocprofv3 PMC passes in ANOTHER run and committed under profiles/ (never read as live):
+    returns (value, source path) or (None, None)."""
+    path = os.path.join(ROOT, "profiles", name)
     try:
-        pmc = json.load(open(path)).get("pmc", {})
-        return (pmc["WRITE_SIZE"]["mean_per_dispatch"] + pmc["FETCH_SIZE"]["mean_per_dispatch"]) * 1024.0
-    except (KeyError, ValueError):
-        return None
+        return json.load(open(path)), os.path.relpath(path, ROOT)
+    except (OSError, ValueError):
+        return None, None
 
 
-def other_configs(args):
-    """BASELINE configs[2..4] at their per-GPU shapes.  Same timing contract as the headline (W
-    warm-up steps, K timed steps bracketed by synchronize); one step = the whole T-step scan,
-    processed in T-chunks through the scan carry where the full posterior history exceeds HBM
-    (output buffers are reused between chunks, the bytes are still written)."""
+# ------------------------------------------------------------------------------------------------ workloads
+def make_kalman4(args, rank, world, device):
+    """BASELINE configs[1]: n = 4, m = 2, T = 10 000, B = 65 536 per GPU, FULL5 in the reference layout."""
     import torch
     import bayesianfiltering_amd as bfa
-    F32 = np.float32
+    from bayesianfiltering_amd import _lib
+    lib = _lib.require_gpu()
+    _lib.check(lib.bf_set_option(b"kf_emit_mode", args.emit_mode))
+    a = cv_model()
     nl = bfa.nonlinearities
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(dev)
-    if args.config == "gsf32":          # configs[2]: Lorenz-96 n=8, m=4, K=32, T=5000, B=16384
-        B, T, K, n, m, Tc = 16384, 5000, 32, 8, 4, args.chunk
-        p = bfa.ParamsNLSSM(np.zeros(8, F32), np.eye(8, dtype=F32), nl.lorenz96(8), np.zeros(8, F32),
-                            1e-2 * np.eye(8, dtype=F32), nl.pick_even(8), np.zeros(4, F32), 1e-1 * np.eye(4, dtype=F32))
-        y = 8.0 + torch.randn((B, T, m), device=dev)
-        init = 8.0 + torch.randn((B, K, n), device=dev)
-        state = {"post": None}
+    params = bfa.ParamsNLSSM(a["m0"], a["P0"], nl.linear_dynamics(a["A"], a["G"]), a["q0"], a["Q"],
+                             nl.linear_emission(a["H"], a["D"]), a["r0"], a["R"])
+    B = args.batch or 65536
+    T, n, m = args.T or 10000, 4, 2
+    y = simulate_on_device(params, (4, 2, 2, 2), B, T, seed=1000 + rank)
+    init = torch.zeros((B, n), device=device)
+    st = {"post": None}
 
-        if args.mode == "collapsed":    # COLLAPSED mode (SURVEY.md 8d): per step only the moment-matched Gaussian leaves the chip
-            def step():
-                bfa.gaussian_sum_filter(p, y, K, 1, initial_means=init, fields=(), return_collapsed=True)
-            bytes_per_step, flop_per_step = 4 * m + 4 * (n + n * n + K), 1.4e5
-            work = (f"Gaussian-sum filter 32 components, Lorenz-96 state_dim=8 obs_dim=4, T={T} batch={B}, "
-                    "COLLAPSED output (in-scan moment matching), one launch")
+    def kernels():
+        st["post"] = bfa.kalman_filter(params, y, initial_means=init, layout=args.layout, out=st["post"])
+
+    def summary():
+        p = st["post"]
+        return torch.cat([p.means[:, 0, -1], p.covariances[:, 0, -1].reshape(B, n * n)], dim=1)
+
+    def finite():
+        p = st["post"]
+        return float((torch.isfinite(p.means[:, 0, -1]).all(dim=1) & torch.isfinite(p.covariances[:, 0, -1]).all(dim=(1, 2))).float().mean())
+
+    bps = int(lib.bf_bytes_per_step(n, m, 1, None))      # 4m + 4(1 + 2n + 2n^2) = 172
+    return dict(kernels=kernels, summary=summary, finite=finite, units=B * T, total_units=world * B * T, scaling="weak",
+                gather_rows=world * B, a=a, T=T,
+                roofline=lambda ms: {"bound": "hbm", "achieved": bps * B * T / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "kernel": "kf_scan_group_kernel<n=4,m=2,NL=2,EMIT_STAGED>", "bytes_per_step": bps},
+                workload=f"batched Kalman filter state_dim=4 obs_dim=2 T={T} batch={B} per GPU, K=1, all five posterior streams "
+                         f"(FULL5), layout={args.layout}, observations drawn from the model",
+                extra={"batch_per_gpu": B, "T": T, "state_dim": n, "obs_dim": m})
+
+
+def make_gsf32(args, rank, world, device):
+    """BASELINE configs[2]: Lorenz-96 n = 8, m = 4, K = 32, T = 5 000, B = 16 384 (split over the ranks)."""
+    import torch
+    import bayesianfiltering_amd as bfa
+    from bayesianfiltering_amd import distributed as bdist
+    nl = bfa.nonlinearities
+    Bt, T, K, n, m, Tc = args.batch or 16384, args.T or 5000, 32, 8, 4, args.chunk
+    lo, hi = bdist.shard_bounds(Bt, rank, world)
+    B = hi - lo
+    p = bfa.ParamsNLSSM(8 * np.ones(8, F32), np.eye(8, dtype=F32), nl.lorenz96(8), np.zeros(8, F32),
+                        1e-2 * np.eye(8, dtype=F32), nl.pick_even(8), np.zeros(4, F32), 1e-1 * np.eye(4, dtype=F32))
+    y = simulate_on_device(p, (8, 8, 4, 4), B, T, seed=2000, first=lo)
+    g = torch.Generator(device=device).manual_seed(20 + rank)
+    init = 8.0 + torch.randn((B, K, n), device=device, generator=g)       # initial component means ~ N(m0, P0) (inference.py:367)
+    st = {"post": None, "carry": None}
+    collapsed = args.mode == "collapsed"
+
+    def kernels():
+        if collapsed:      # COLLAPSED mode (SURVEY.md 8d): per step only the moment-matched Gaussian leaves the chip
+            _, st["carry"], _ = bfa.gaussian_sum_filter(p, y, K, 1, initial_means=init, fields=(), return_carry=True, return_collapsed=True)
+            return
+        carry = None
+        for t0 in range(0, T, Tc):
+            yc = y[:, t0:t0 + Tc]
+            reuse = st["post"] if (st["post"] is not None and st["post"].weights.shape[2] == yc.shape[1]) else None
+            st["post"], carry = bfa.gaussian_sum_filter(p, yc, K, 1, initial_means=init, carry=carry, out=reuse, return_carry=True)
+        st["carry"] = carry
+
+    def summary():
+        c = st["carry"]
+        return torch.cat([c.weights, c.means.reshape(B, K * n)], dim=1)
+
+    def finite():
+        c = st["carry"]
+        return float((torch.isfinite(c.weights).all(dim=1) & torch.isfinite(c.means).all(dim=(1, 2))).float().mean())
+
+    if collapsed:
+        bps, fl = 4 * m + 4 * (n + n * n + K), 1.4e5
+        roof = lambda ms: {"bound": "mfma", "achieved": fl * B * T / (ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFS, "unit": "TFLOP/s",
+                           "kernel": "gsf_scan_kernel<8,4,NL=2,EMIT_NONE,EXT>", "flop_per_step": fl, "bytes_per_step": bps,
+                           "note": "fp32 vector ALU work (no matrix products): 'mfma' stands for the fp32 vector peak"}
+        work = f"Gaussian-sum filter 32 components, Lorenz-96 state_dim=8 obs_dim=4, T={T} batch={Bt}, COLLAPSED output (in-scan moment matching)"
+    else:
+        bps = 4 * m + 4 * K * (1 + 2 * n + 2 * n * n)
+        roof = lambda ms: {"bound": "hbm", "achieved": bps * B * T / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "kernel": "gsf_scan_kernel<8,4,NL=2,EMIT_STAGED,L96_PICK>", "bytes_per_step": bps}
+        work = f"Gaussian-sum filter 32 components, Lorenz-96 state_dim=8 obs_dim=4, T={T} batch={Bt}, FULL5 in T-chunks of {Tc}"
+    return dict(kernels=kernels, summary=summary, finite=finite, units=B * T, total_units=Bt * T, scaling="strong", gather_rows=Bt,
+                roofline=roof, workload=work + ", observations drawn from the model", extra={"batch_total": Bt, "batch_this_rank": B, "T": T})
+
+
+def make_kalman64(args, rank, world, device):
+    """BASELINE configs[4]: n = 64, m = 32, T = 2 000, B = 32 768 split over the ranks (fp32 MFMA path)."""
+    import torch
+    import bayesianfiltering_amd as bfa
+    from bayesianfiltering_amd import distributed as bdist
+    nl = bfa.nonlinearities
+    Bt, T, n, m, Tc = args.batch or 32768, args.T or 2000, 64, 32, 100
+    lo, hi = bdist.shard_bounds(Bt, rank, world)
+    B = hi - lo
+    a = random_stable_lgssm(64, 32, seed=64)
+    p = bfa.ParamsNLSSM(a["m0"], a["P0"], nl.linear_dynamics(a["A"], a["G"]), a["q0"], a["Q"], nl.linear_emission(a["H"], a["D"]),
+                        a["r0"], a["R"])
+    y = simulate_on_device(p, (64, 64, 32, 32), B, T, seed=5000, first=lo)
+    init = torch.zeros((B, n), device=device)
+    st = {"post": None, "carry": None}
+
+    def kernels():
+        carry = None
+        for t0 in range(0, T, Tc):
+            st["post"], carry = bfa.kalman_filter(p, y[:, t0:t0 + Tc], initial_means=init, carry=carry, out=st["post"], return_carry=True)
+        st["carry"] = carry
+
+    def summary():
+        c = st["carry"]
+        return torch.cat([c.means.reshape(B, n), c.covariances.reshape(B, n * n)], dim=1)
+
+    def finite():
+        c = st["carry"]
+        return float((torch.isfinite(c.means.reshape(B, n)).all(dim=1) & torch.isfinite(c.covariances.reshape(B, n * n)).all(dim=1)).float().mean())
+
+    bps, fl = 4 * m + 4 * (1 + 2 * n + 2 * n * n), 512 * 4096   # 512 v_mfma_f32_32x32x2_f32 per step x 4096 flop
+    return dict(kernels=kernels, summary=summary, finite=finite, units=B * T, total_units=Bt * T, scaling="strong", gather_rows=Bt,
+                roofline=lambda ms: {"bound": "mfma", "achieved": fl * B * T / (ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFS, "unit": "TFLOP/s",
+                                     "kernel": "kf_scan_mfma_kernel<64,32>", "flop_per_step": fl, "bytes_per_step": bps,
+                                     "hbm_GBs": bps * B * T / (ms * 1e-3) / 1e9},
+                workload=f"Kalman filter state_dim=64 obs_dim=32 T={T} batch={Bt}, FULL5 in T-chunks of {Tc}, fp32 MFMA path, "
+                         "observations drawn from the model",
+                extra={"batch_total": Bt, "batch_this_rank": B, "T": T})
+
+
+def make_bpf4096(args, rank, world, device):
+    """BASELINE configs[3]: bootstrap PF, N = 4 096 particles, Lorenz-96 n = 16, m = 8, T = 2 000, B = 8 192 split over the ranks."""
+    import torch
+    import bayesianfiltering_amd as bfa
+    from bayesianfiltering_amd import distributed as bdist
+    nl = bfa.nonlinearities
+    Bt, T, N, n, m = args.batch or 8192, args.T or 2000, 4096, 16, 8
+    lo, hi = bdist.shard_bounds(Bt, rank, world)
+    B = hi - lo
+    g = nl.pick_even(16)
+    R = 0.5 * np.eye(8, dtype=F32)
+    p = bfa.ParamsBPF(8 * np.ones(16, F32), np.eye(16, dtype=F32), nl.lorenz96(16), np.zeros(16, F32),
+                      1e-1 * np.eye(16, dtype=F32), g, np.zeros(8, F32), R, nl.gaussian_log_prob(g, R))
+    y = simulate_on_device(bfa.ParamsNLSSM(*p[:8]), (16, 16, 8, 8), B, T, seed=4000, first=lo)
+    st = {"out": None}
+
+    def kernels():
+        st["out"] = bfa.bootstrap_particle_filter(p, y, N, np.array([0, 1], np.uint32), output="summary")
+
+    def summary():
+        return st["out"]["mean"].reshape(B, T * n)           # the (B, T, n) point estimates of SURVEY.md 2 (1.05 GB in total)
+
+    def finite():
+        return float(torch.isfinite(st["out"]["mean"]).all(dim=(1, 2)).float().mean())
+
+    prof, src = profiled("r02_pmc_bpf4096.json")
+    ipp = (prof or {}).get("valu_wave_inst_per_particle_step_x64")   # SQ_INSTS_VALU per launch / particle-steps per launch x 64 lanes
+    bps = 4 * m + 4 * (n + 3)
+
+    def roof(ms):
+        r = {"bound": "valu", "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+             "kernel": "bpf_scan_kernel<16,16,8,PPT=4,NW=16>", "bytes_per_step": bps, "particle_steps_per_s": N * B * T / (ms * 1e-3),
+             "note": "integer / fp32 VALU work (Threefry, canonical erf_inv / exp), no matrix products and ~100 B of HBM per step: the "
+                     "bound is VALU issue, 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction"}
+        if ipp:
+            r["achieved"] = ipp / 64.0 * N * B * T / (ms * 1e-3) / 1e9
+            r["valu_inst_per_particle_step"] = ipp
+            r["valu_inst_source"] = src
         else:
-            def step():
-                carry = None
-                for t0 in range(0, T, Tc):
-                    state["post"], carry = bfa.gaussian_sum_filter(p, y[:, t0:t0 + Tc], K, 1, initial_means=init, carry=carry,
-                                                                   out=state["post"], return_carry=True)
-            bytes_per_step, flop_per_step = 4 * m + 4 * K * (1 + 2 * n + 2 * n * n), 1.4e5
-            work = f"Gaussian-sum filter 32 components, Lorenz-96 state_dim=8 obs_dim=4, T={T} batch={B}, FULL5 in T-chunks of {Tc}"
-        kernel = "gsf_scan_kernel<8,4,NL=2,L96>"
-    elif args.config == "kalman64":     # configs[4] per GPU: n=64, m=32, T=2000, B=32768/8
-        from tests import common as cm
-        B, T, n, m, Tc = 4096, 2000, 64, 32, 100
-        a = cm.random_stable_lgssm(64, 32, seed=64)
-        a["Q"] = (1e-2 * np.eye(64)).astype(F32); a["R"] = (1e-1 * np.eye(32)).astype(F32)
-        p = cm.product_params(a)
-        y = torch.randn((B, T, m), device=dev)
-        init = torch.zeros((B, n), device=dev)
-        state = {"post": None}
+            r["achieved"] = None
+        return r
 
-        def step():
-            carry = None
-            for t0 in range(0, T, Tc):
-                state["post"], carry = bfa.kalman_filter(p, y[:, t0:t0 + Tc], initial_means=init, carry=carry,
-                                                         out=state["post"], return_carry=True)
-        bytes_per_step, flop_per_step = 4 * m + 4 * (1 + 2 * n + 2 * n * n), 2.0e6
-        work = f"Kalman filter state_dim=64 obs_dim=32 T={T} batch={B} (one GPU's share of 32768), FULL5 in T-chunks of {Tc}, fp32 MFMA path"
-        kernel = "kf_scan_mfma_kernel<64,32>"
-    else:                               # configs[3] per GPU: bootstrap PF N=4096, n=16, T=2000, B=8192/8
-        B, T, N, n, m = 1024, 2000, 4096, 16, 8
-        g = nl.pick_even(16); R = 0.5 * np.eye(8, dtype=F32)
-        p = bfa.ParamsBPF(8 * np.ones(16, F32), np.eye(16, dtype=F32), nl.lorenz96(16), np.zeros(16, F32),
-                          1e-1 * np.eye(16, dtype=F32), g, np.zeros(8, F32), R, nl.gaussian_log_prob(g, R))
-        y = 8.0 + torch.randn((B, T, m), device=dev)
+    return dict(kernels=kernels, summary=summary, finite=finite, units=B * T, total_units=Bt * T, scaling="strong", gather_rows=Bt,
+                roofline=roof,
+                workload=f"bootstrap particle filter {N} particles, Lorenz-96 state_dim=16 obs_dim=8, T={T} batch={Bt}, SUMMARY output, "
+                         "observations drawn from the model",
+                extra={"batch_total": Bt, "batch_this_rank": B, "T": T, "particles": N})
 
-        def step():
-            bfa.bootstrap_particle_filter(p, y, N, np.array([0, 1], np.uint32), output="summary")
-        bytes_per_step, flop_per_step = 4 * m + 4 * (n + 3), 2.0e3 * N
-        work = f"bootstrap particle filter {N} particles, Lorenz-96 state_dim=16 obs_dim=8, T={T} batch={B} (one GPU's share of 8192), SUMMARY output"
-        kernel = "bpf_scan_kernel<16,16,8,PPT=4,NW=16>"
-        note = ("integer / fp32 VALU work (Threefry + erf_inv), no matrix products: 'mfma' stands for the fp32 vector peak "
-                "(= the fp32 MFMA peak, 157 TFLOP/s); PMC SQ_ACTIVE_INST_VALU = 79 % of the SIMD cycles (profiles/r01_pmc_bpf4096.json)")
-    if args.config != "bpf4096":
-        note = None
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    rate = B * T * args.steps / el
-    gbs, tfs = bytes_per_step * rate / 1e9, flop_per_step * rate / 1e12
-    bound = "hbm" if gbs / HBM_PEAK_GBS > tfs / 157.3 else "mfma"
-    roof = ({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
-            if bound == "hbm" else
-            {"bound": "mfma", "achieved": tfs, "peak": 157.3, "unit": "TFLOP/s", "frac": tfs / 157.3})
-    roof.update({"traffic": None, "kernel": kernel, "bytes_per_step": bytes_per_step, "flop_per_step": flop_per_step,
-                 "hbm_GBs": gbs, "fp32_TFLOPs": tfs})
-    if note:
-        roof["note"] = note
-    print(json.dumps({"metric": "filter timesteps/sec (batch x T)", "value": rate, "unit": "timesteps/s", "n_gpus": 1,
-                      "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
-                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                      "config": {"workload": work}, "roofline": roof}), flush=True)
+
+MAKERS = {"kalman4": make_kalman4, "gsf32": make_gsf32, "bpf4096": make_bpf4096, "kalman64": make_kalman64}
 
 
 def main():
@@ -191,8 +292,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=65536)
-    ap.add_argument("--T", type=int, default=10000)
+    ap.add_argument("--batch", type=int, default=0, help="override the config's batch (per GPU for kalman4, total otherwise)")
+    ap.add_argument("--T", type=int, default=0)
     ap.add_argument("--layout", default="reference", choices=["reference", "batch_inner"])
     ap.add_argument("--emit-mode", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -200,73 +301,50 @@ def main():
                     help="gsf32 only: steps per launch (the posterior history of one chunk must fit HBM: 304 MB per step)")
     ap.add_argument("--mode", default="full5", choices=["full5", "collapsed"],
                     help="gsf32 only: full5 = the five posterior streams (T-chunked), collapsed = in-scan moment matching")
-    ap.add_argument("--config", default="kalman4", choices=["kalman4", "gsf32", "bpf4096", "kalman64"],
-                    help="kalman4 = BASELINE configs[1] (headline, default); gsf32 / bpf4096 / kalman64 = configs[2..4] "
-                         "at their per-GPU shapes (extra lines, not the headline)")
+    ap.add_argument("--config", default="kalman4", choices=sorted(MAKERS),
+                    help="kalman4 = BASELINE configs[1] (headline, default); gsf32 / bpf4096 / kalman64 = configs[2..4]")
     args = ap.parse_args()
-    if args.config != "kalman4":
-        return other_configs(args)
-
-    import torch
-    import bayesianfiltering_amd as bfa
-    from bayesianfiltering_amd import _lib
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.gpus != world and args.gpus > 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
+
+    import torch
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    dist = None
+    if world > 1:                      # the process group first: nothing else has touched the GPU yet
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
 
-    lib = _lib.require_gpu()
-    _lib.check(lib.bf_set_option(b"kf_emit_mode", args.emit_mode))
-
-    a = cv_model()
-    nl = bfa.nonlinearities
-    params = bfa.ParamsNLSSM(a["m0"], a["P0"], nl.linear_dynamics(a["A"], a["G"]), a["q0"], a["Q"],
-                             nl.linear_emission(a["H"], a["D"]), a["r0"], a["R"])
-    B, T, n, m = args.batch, args.T, 4, 2
-    y = simulate_on_device(params, B, T, seed=1000 + rank, device=device)
-    init = torch.zeros((B, n), device=device)
-
-    post = None
-    summary_local = torch.zeros((B, n + n * n), device=device)
-    summary_all = None
-
     from bayesianfiltering_amd import distributed as bdist
+    w = MAKERS[args.config](args, rank, world, device)
+
+    gathered = {"t": None}
 
     def step():
-        # one pass of the hot path over this rank's batch + the path's one exchange step:
-        # RCCL all-gather of the per-trajectory posterior summaries (final mean, covariance)
-        nonlocal post, summary_all
-        post = bfa.kalman_filter(params, y, initial_means=init, layout=args.layout, out=post)
+        # one pass of the hot path over this rank's trajectories + the path's one exchange step:
+        # RCCL all-gather of the per-trajectory posterior summaries
+        w["kernels"]()
         if world > 1:
-            summary_local[:, :n] = post.means[:, 0, -1]
-            summary_local[:, n:n + n * n] = post.covariances[:, 0, -1].reshape(B, n * n)
-            summary_all = bdist.all_gather_summaries(summary_local, world * B)
+            gathered["t"] = bdist.all_gather_summaries(w["summary"](), w["gather_rows"])
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
-        import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev[i][0].record()
-        post = bfa.kalman_filter(params, y, initial_means=init, layout=args.layout, out=post)
+        ev[i][0].record()               # the engine launches on torch's current stream: these events bracket its kernels
+        w["kernels"]()
         ev[i][1].record()
         if world > 1:
-            summary_local[:, :n] = post.means[:, 0, -1]
-            summary_local[:, n:n + n * n] = post.covariances[:, 0, -1].reshape(B, n * n)
-            summary_all = bdist.all_gather_summaries(summary_local, world * B)
+            gathered["t"] = bdist.all_gather_summaries(w["summary"](), w["gather_rows"])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -277,28 +355,36 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    fin = torch.tensor([w["finite"]() * w["units"]], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(fin)
+    finite_frac = float(fin.item()) / w["total_units"]
 
     if rank == 0:
-        bytes_per_step = int(lib.bf_bytes_per_step(n, m, 1, None))      # 4m + 4(1 + 2n + 2n^2) = 172
-        achieved = bytes_per_step * B * T / (kernel_ms * 1e-3) / 1e9
-        traffic = pmc_traffic(B, T, args.layout)
-        value = world * B * T * args.steps / elapsed
+        roof = w["roofline"](kernel_ms)
+        if roof.get("achieved") is not None:
+            roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["kernel_ms"] = kernel_ms
+        roof["traffic"] = None         # HBM bytes from PMC counters: not collected inside this run (see profiles/ for the rocprofv3 passes)
+        if args.config == "kalman4" and w["extra"]["batch_per_gpu"] == 65536 and w["T"] == 10000:
+            prof, src = profiled("r02_bench_%s_summary.json" % args.layout)
+            if prof and "pmc" in prof:
+                try:
+                    roof["traffic_profiled"] = {"bytes": (prof["pmc"]["WRITE_SIZE"]["mean_per_dispatch"] + prof["pmc"]["FETCH_SIZE"]["mean_per_dispatch"]) * 1024.0,
+                                                "source": src}
+                except KeyError:
+                    pass
         line = {
-            "metric": "filter timesteps/sec (batch x T)", "value": value, "unit": "timesteps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"batched Kalman filter state_dim=4 obs_dim=2 T={T} batch={B} per GPU, K=1, "
-                                   f"all five posterior streams (FULL5), layout={args.layout}",
-                       "batch_per_gpu": B, "T": T, "state_dim": n, "obs_dim": m,
+            "metric": "filter timesteps/sec (batch x T)", "value": w["total_units"] * args.steps / elapsed, "unit": "timesteps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": w["scaling"], "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": w["workload"], **w["extra"],
                        "parallelism": f"batch-sharded x{world}" + (" + RCCL all-gather of summaries" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "kf_scan_group_kernel<n=4,m=2>", "kernel_ms": kernel_ms,
-                         "bytes_per_step": bytes_per_step},
+            "finite_frac": finite_frac,
+            "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(a, T)
+        if args.config == "kalman4" and world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(w["a"], w["T"])
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -76,6 +76,11 @@ def bpf_small():
     out, dbg = go.bootstrap_particle_filter(p, ys, 64, key=key, debug=True)
     np.savez_compressed(os.path.join(OUT, "bpf_lorenz63_N64_T16.npz"), emissions=ys, key=key, weights=out["weights"],
                         particles=out["particles"], resampled=dbg["resampled"], ancestors=dbg["ancestors"], ess=dbg["ess"])
+    # the same run on the canonical fp32 arithmetic (oracle/fp32.py): the HIP engine must reproduce EVERY BIT of it
+    out, dbg = go.bootstrap_particle_filter(p, ys, 64, key=key, debug=True, arith="canonical")
+    np.savez_compressed(os.path.join(OUT, "bpf_lorenz63_N64_T16_canonical.npz"), emissions=ys, key=key, weights=out["weights"],
+                        particles=out["particles"], resampled=dbg["resampled"], ancestors=dbg["ancestors"], ess=dbg["ess"],
+                        pre_weights=dbg["pre_weights"])
 
 
 def rng_vectors():
