@@ -55,6 +55,7 @@ int launch_resample(const float* d_w, const uint32_t* d_keys, long long B, int N
 extern std::atomic<int> g_bpf_variant;
 extern std::atomic<int> g_bpf_hbm_mode;
 extern std::atomic<int> g_gsf_structured;
+extern std::atomic<int> g_kf_mfma_variant;
 static std::atomic<int> g_kf_emit_mode{-1};  // -1 = choose from the layout
 static std::atomic<int> g_kf_lanes{0};       // 0 = default lanes per trajectory for the (n, m) pair
 __global__ void canon_eval_kernel(int op, const float* __restrict__ in, long long n, float* __restrict__ out) {
@@ -124,6 +125,11 @@ int bf_set_option(const char* name, int value) {
   if (name && std::strcmp(name, "kf_lanes") == 0) {
     if (value < 0 || value > 64 || (value & (value - 1)) != 0) return bf::set_error(BF_EINVAL, "kf_lanes must be 0 or a power of two <= 64");
     bf::g_kf_lanes = value;
+    return BF_OK;
+  }
+  if (name && std::strcmp(name, "kf_mfma_variant") == 0) {
+    if (value < 1 || value > 3) return bf::set_error(BF_EINVAL, "kf_mfma_variant must be 1, 2 or 3");
+    bf::g_kf_mfma_variant = value;
     return BF_OK;
   }
   if (name && std::strcmp(name, "force_generic") == 0) {

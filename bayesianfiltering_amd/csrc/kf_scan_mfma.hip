@@ -27,12 +27,20 @@
 // the same linear system's, and the two factorizations agree to ~1e-6 relative for the
 // conditioned S of a filter (the parity budget is 1e-5); the log-likelihood uses the Cholesky
 // factor of the un-jittered S exactly like the reference (inference.py:104, :24).
+#include <cstdlib>
 #include "bf_common.hpp"
 #include "kf_math.hpp"
 #include "lane_group.hpp"
 #include "scan_common.hpp"
 
 namespace bf {
+
+static int mfma_variant_default() {  // BAYESFILT_MFMA_VARIANT=1|2|3 overrides the default for A/B runs of unmodified programs
+  const char* e = std::getenv("BAYESFILT_MFMA_VARIANT");
+  const int v = e ? std::atoi(e) : 2;
+  return (v >= 1 && v <= 3) ? v : 2;
+}
+std::atomic<int> g_kf_mfma_variant{mfma_variant_default()};  // bf_set_option "kf_mfma_variant": 3 = gain-free update, factorization by rank-1 MFMAs (default); 2 = gain-free, factorization in VALU registers; 1 = round 1's kernel
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using lds_f = __attribute__((address_space(3))) float;
@@ -220,7 +228,7 @@ __device__ __attribute__((noinline)) void invert_following(lds_f* Lc, lds_i* pro
       __builtin_amdgcn_s_sleep(BF_MFMA_POLL_SLEEP);  // a tight poll floods the LDS queue the factorizing waves live on
       seen = *(volatile lds_i*)progress;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");  // LDS only: a full fence would also drain the wave's output stores
   };
   auto load_col = [&](auto C, float* dst, float& d) {
     constexpr int c = decltype(C)::value;
@@ -462,6 +470,447 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
 #endif
 }
 
+
+// =======================================================================================================================
+// Measured on one MI355X, BASELINE configs[4] (B = 32 768, T = 2 000, all five streams in T-chunks of 100; bench.py
+// --config kalman64), same box, steps/s:   variant 1 (round 1) 3.28e7 | variant 2 3.54e7 | variant 3 3.07e7;
+// without output streams (B = 4 096, T = 100):           3.16e7 |           3.36e7 |           3.61e7.
+// Variant 3 has the shortest serial phase (3.7 us against 5.4 us per step, one workgroup per CU, scripts/mfma_phase_probe.py)
+// but its three elimination loops are inlined into the kernel body (out of line they cost more: accumulators cross the
+// call in registers both ways) and the 256-VGPR body then spills inside the phases that stream the outputs; variant 2
+// keeps its serial phase in two out-of-line functions with register allocations of their own and is the default.
+//
+// Variant 2 (default): the gain is never formed.  With L L^T = S + 1e-6 (every entry: the psd_solve jitter J = 1e-6 1 1^T),
+// W = L^-1 (H P), g = L^-1 1 and z = L^-1 v:
+//     K S K^T = X^T (S_j - J) X = W^T W - 1e-6 (W^T g)(W^T g)^T          (X = S_j^-1 H P = L^-T W)
+//     K v     = X^T v = W^T z
+// -- the same quantities as P - K S K^T and m + K (y - h(m)) of inference.py:102-103, to rounding.  That removes the
+// explicit inverse, the X = L^-T W and K S products and four of the nine barriers, and the whole serial phase fits one
+// wave's REGISTERS: lane r holds row r of S + 1e-6; by symmetry the multipliers L[k][j] of column j are lane j's own
+// row entries, broadcast with v_readlane (no LDS round trip per column), and every lane c = 0..63 carries column c of
+// H P through the forward substitution in the same loop, fed by the same broadcasts.  A second wave factorizes the
+// un-jittered S the same way for the log-likelihood (inference.py:104).  Per step:
+//   A  H P (waves 0,1; K = 64)                                  y, H m, v (wave 2)
+//   B  S = (H P) H^T + D R D^T, computed by waves 2 AND 3 (each needs it in registers; different SIMDs)
+//   C  wave 3: chol(S + 1e-6) fused with W, g, z; c = 1e-3 W^T g; m+ = m + W^T z     wave 2: chol(S), log-likelihood
+//   H  P+ = P - W^T W + c c^T (all waves; K = 32 + 2)
+//   I  A P+ (all waves; K = 64), m- = A m+ + G q0               J  P- = (A P+) A^T + G Q G^T
+#ifndef BF_MFMA_RDB
+#define BF_MFMA_RDB 8  // broadcasts issued ahead of their consumers
+#endif
+__device__ __forceinline__ float rdlane_u(float v, int l) {  // v_readlane_b32: lane l's value as a wave-uniform scalar
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+// wave 3: S (acc layout in `sc`, [32][33]) -> rows; chol(S + 1e-6); W = L^-1 (H P) -> sT rows 32..63; c, m+
+__device__ __attribute__((noinline)) void chol_w_rows(lds_f* sc, lds_f* sT, lds_f* sv, lds_f* mcur, lds_f* mnxt, lds_f* scv,
+                                                      int lane) {
+  constexpr int PP = 65, PS = 33;
+  const int r = lane & 31;
+  float a[32], w[32];
+  BF_UNROLL for (int k = 0; k < 32; ++k) a[k] = sc[r * PS + k] + 1e-6f;  // psd_solve's jitter on every entry (utils.py:258)
+  BF_UNROLL for (int i = 0; i < 32; ++i) w[i] = sT[i * PP + lane];       // column `lane` of H P
+  float rg = 1.0f, rz = sv[r];                                           // residuals of g = L^-1 1, z = L^-1 v (row r)
+  float acc_c = 0.f, acc_m = 0.f;
+  static_for<0, 32>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    const float rinv = rsqrt_newton(rdlane_u(a[j], j));   // 1 / L[j][j], wave-uniform
+    const float lj = a[j] * rinv;                         // L[r][j] (meaningful for r >= j)
+    const float wj = w[j] * rinv;                         // W[j][lane], final
+    const float gj = rdlane_u(rg, j) * rinv;              // g[j], z[j]: wave-uniform
+    const float zj = rdlane_u(rz, j) * rinv;
+    a[j] = lj;
+    w[j] = wj;
+    rg = fmaf(-lj, gj, rg);
+    rz = fmaf(-lj, zj, rz);
+    acc_c = fmaf(wj, gj, acc_c);                          // (W^T g)[lane], (W^T z)[lane]
+    acc_m = fmaf(wj, zj, acc_m);
+    const float t = lj * rinv;                            // a[r][j] / d_j
+    const float q = wj * rinv;
+    // L[k][j] sqrt(d_j) = a[k][j] = a[j][k] by symmetry: lane j's own entries, read BEFORE this step updates them.
+    // The broadcasts go out in batches of BF_MFMA_RDB ahead of the multiply-adds that consume them: a v_readlane's
+    // scalar result takes several issue slots to become readable, and back-to-back (readlane, fma) pairs stall on it.
+    static_for<0, (31 - j + BF_MFMA_RDB - 1) / BF_MFMA_RDB>([&](auto Cb) {
+      constexpr int k0 = j + 1 + decltype(Cb)::value * BF_MFMA_RDB;
+      constexpr int nk = (32 - k0) < BF_MFMA_RDB ? (32 - k0) : BF_MFMA_RDB;
+      float sb[BF_MFMA_RDB];
+      static_for<0, nk>([&](auto I) { sb[decltype(I)::value] = rdlane_u(a[k0 + decltype(I)::value], j); });
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, nk>([&](auto I) {
+        constexpr int k = k0 + decltype(I)::value;
+        a[k] = fmaf(-t, sb[decltype(I)::value], a[k]);
+        w[k] = fmaf(-q, sb[decltype(I)::value], w[k]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  });
+  BF_UNROLL for (int i = 0; i < 32; ++i) sT[(32 + i) * PP + lane] = w[i];
+  scv[lane] = acc_c * 1e-3f;                               // sqrt(1e-6) (W^T g): enters P+ as + c c^T
+  mnxt[lane] = mcur[lane] + acc_m;                         // filtered mean
+}
+
+// wave 2: chol(S) (no jitter), z = L^-1 v, log N(v; 0, S) -- inference.py:104, :24
+__device__ __attribute__((noinline)) float chol_loglik_rows(lds_f* sc, lds_f* sv, int lane) {
+  constexpr int PS = 33;
+  const int r = lane & 31;
+  float a[32];
+  BF_UNROLL for (int k = 0; k < 32; ++k) a[k] = sc[r * PS + k];
+  float rz = sv[r], quad = 0.f, rprod = 1.f;
+  static_for<0, 32>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    const float rinv = rsqrt_newton(rdlane_u(a[j], j));
+    const float lj = a[j] * rinv;
+    const float zj = rdlane_u(rz, j) * rinv;
+    rz = fmaf(-lj, zj, rz);
+    quad = fmaf(zj, zj, quad);
+    rprod *= rinv;
+    const float t = lj * rinv;
+    static_for<0, (31 - j + BF_MFMA_RDB - 1) / BF_MFMA_RDB>([&](auto Cb) {
+      constexpr int k0 = j + 1 + decltype(Cb)::value * BF_MFMA_RDB;
+      constexpr int nk = (32 - k0) < BF_MFMA_RDB ? (32 - k0) : BF_MFMA_RDB;
+      float sb[BF_MFMA_RDB];
+      static_for<0, nk>([&](auto I) { sb[decltype(I)::value] = rdlane_u(a[k0 + decltype(I)::value], j); });
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, nk>([&](auto I) { a[k0 + decltype(I)::value] = fmaf(-t, sb[decltype(I)::value], a[k0 + decltype(I)::value]); });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  });
+  // -sum log L_jj = log prod (1 / L_jj) (32 factors of O(1) stay in range)
+  return -0.5f * quad - 0.5f * 32.0f * 1.8378770664093453f + fast_log(rprod);
+}
+
+// ---- Variant 3: the factorization itself on the matrix cores.  In the accumulator layout of the 32x32 MFMA shapes a
+// lane holds 16 entries of ONE column of S; S is symmetric, so register r_j of the 32 lanes of half h_j (j = r & 3 +
+// 8 (r >> 2) + 4 h) is the whole pivot row j = the whole column j.  One right-looking elimination step -- S -= l l^T
+// with l = column j / sqrt(d_j) -- is then ONE v_mfma_f32_32x32x2_f32 whose two operands are that register (scaled,
+// masked to its half): no broadcast of multipliers at all, one v_readlane per column for the pivot.  The same step
+// applied to the right-hand sides H P (kept in the accumulators of the waves that produced them) is the forward
+// substitution W = L^-1 (H P): another MFMA per 32x32 tile, its operands the published columns of L (LDS, 128 bytes
+// per column) and the tile's own pivot rows.  A few dependent MFMAs replace ~2 300 VALU / v_readlane instructions.
+#ifndef BF_MFMA_PUB3
+#define BF_MFMA_PUB3 4  // columns per publication of the factorizing wave
+#endif
+#ifndef BF_MFMA_RHSB
+#define BF_MFMA_RHSB 8  // columns per batch of the forward-substituting waves (a multiple of BF_MFMA_PUB3)
+#endif
+
+// Two columns per MFMA (the instruction's K = 2): columns j and j + 1 (j even) live in the same half-wave; the 2 x 2
+// pivot block is resolved in vector registers (L[:, j], then a'[j+1][:] = a[j+1][:] - L[j+1][j] L[:, j], its pivot and
+// L[:, j+1]), one of the two operand columns crosses to the other half-wave (one cross-half shuffle), and ONE MFMA applies
+// the rank-2 update.  16 dependent MFMAs per factorization.  The first pivot of the NEXT pair is known before the MFMA
+// has finished: a[j+2][j+2] - L[j+2][j]^2 - L[j+2][j+1]^2 as two fmas in the matrix core's own order, so its reciprocal
+// square root is computed in the shadow of the MFMA.
+__device__ __forceinline__ float pair_operand(float c0, float c1, int h) {
+  // slice k = 0 (lanes 0..31) <- column c0, slice k = 1 (lanes 32..63) <- column c1.  Both columns live in half h and
+  // are ZERO in the other half, so one v_permlane32_swap (VALU; no LDS crossbar trip) assembles the operand:
+  // (a, b) -> a = [a.lo | b.lo], b = [a.hi | b.hi]
+  float a = c0, b = c1;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return h == 0 ? a : b;
+}
+__device__ __forceinline__ float both_halves(float v) {  // v (zero in one half) -> the same 32 values in both halves
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;   // a = [v.lo | v.lo], b = [v.hi | v.hi]; one of them is zero
+}
+// the 2 x 2 pivot block of the NEXT pair of columns, from its entries before the running MFMA's update (p..) and the
+// current pair's columns at its two rows (u = row j+2, v = row j+3): the fmas the matrix core applies to those entries,
+// in its order, so the scalars below equal what the accumulators will hold bit for bit
+struct PivotBlock {
+  float rinv0, s, rinv1;  // 1 / L[j][j], L[j+1][j], 1 / L[j+1][j+1]
+};
+__device__ __forceinline__ PivotBlock pivot_block(float p00, float p10, float p11, float u0, float u1, float v0, float v1) {
+  const float a00 = fmaf(-u1, u1, fmaf(-u0, u0, p00));
+  const float a10 = fmaf(-v1, u1, fmaf(-v0, u0, p10));
+  const float a11 = fmaf(-v1, v1, fmaf(-v0, v0, p11));
+  PivotBlock b;
+  b.rinv0 = rsqrt_newton(a00);
+  b.s = a10 * b.rinv0;
+  b.rinv1 = rsqrt_newton(fmaf(-b.s, b.s, a11));
+  return b;
+}
+
+// wave 3: chol(S + 1e-6); publishes L by columns (sL[32 j + i] = L[i][j], zeros above the diagonal), 1 / L[j][j] and the
+// number of finished columns
+__device__ __forceinline__ void eliminate_publish(f32x16& acc, lds_f* sL, lds_f* sRinv, lds_i* progress, int lane) {
+  const int lr = lane & 31, half = lane >> 5;
+  PivotBlock pb = pivot_block(rdlane_u(acc[0], 0), rdlane_u(acc[1], 0), rdlane_u(acc[1], 1), 0.f, 0.f, 0.f, 0.f);
+  static_for<0, 16>([&](auto Pp) {
+    constexpr int j = 2 * decltype(Pp)::value;
+    constexpr int h = (j >> 2) & 1, rj = (j & 3) + 4 * (j >> 3);
+    const float l0 = (half == h && lr >= j) ? acc[rj] * pb.rinv0 : 0.f;              // L[lr][j]
+    const float row1 = fmaf(-pb.s, l0, acc[rj + 1]);                                 // a'[j+1][lr]
+    const float l1 = (half == h && lr >= j + 1) ? row1 * pb.rinv1 : 0.f;             // L[lr][j+1]
+    float p00 = 1.f, p10 = 0.f, p11 = 1.f, u0 = 0.f, u1 = 0.f, v0 = 0.f, v1 = 0.f;
+    if constexpr (j < 30) {
+      constexpr int h2 = ((j + 2) >> 2) & 1, r2 = ((j + 2) & 3) + 4 * ((j + 2) >> 3);
+      p00 = rdlane_u(acc[r2], 32 * h2 + j + 2);                                      // the next block before this pair's update
+      p10 = rdlane_u(acc[r2 + 1], 32 * h2 + j + 2);
+      p11 = rdlane_u(acc[r2 + 1], 32 * h2 + j + 3);
+      u0 = rdlane_u(l0, 32 * h + j + 2);
+      u1 = rdlane_u(l1, 32 * h + j + 2);
+      v0 = rdlane_u(l0, 32 * h + j + 3);
+      v1 = rdlane_u(l1, 32 * h + j + 3);
+    }
+    if (half == h) {
+      sL[32 * j + lr] = l0;
+      sL[32 * (j + 1) + lr] = l1;
+    }
+    if (lane == 0) {
+      sRinv[j] = pb.rinv0;
+      sRinv[j + 1] = pb.rinv1;
+    }
+    if constexpr ((j + 2) % BF_MFMA_PUB3 == 0) {
+      wave_lds_order();
+      if (lane == 0) *progress = j + 2;
+    }
+    const float op = pair_operand(l0, l1, h);
+    acc = mfma2(-op, op, acc);                                                       // a[i][n] -= L[i][j] L[n][j] + L[i][j+1] L[n][j+1]
+    if constexpr (j < 30) pb = pivot_block(p00, p10, p11, u0, u1, v0, v1);           // in the shadow of the MFMA
+  });
+}
+
+// wave 2: chol(S) the same way, z = L^-1 v, log N(v; 0, S) -- inference.py:104, :24
+__device__ __forceinline__ float eliminate_loglik(f32x16& acc, lds_f* sv, int lane) {
+  const int lr = lane & 31, half = lane >> 5;
+  float rz = sv[lr], quad = 0.f, rprod = 1.f;
+  PivotBlock pb = pivot_block(rdlane_u(acc[0], 0), rdlane_u(acc[1], 0), rdlane_u(acc[1], 1), 0.f, 0.f, 0.f, 0.f);
+  static_for<0, 16>([&](auto Pp) {
+    constexpr int j = 2 * decltype(Pp)::value;
+    constexpr int h = (j >> 2) & 1, rj = (j & 3) + 4 * (j >> 3);
+    const float l0 = (half == h && lr >= j) ? acc[rj] * pb.rinv0 : 0.f;
+    const float row1 = fmaf(-pb.s, l0, acc[rj + 1]);
+    const float l1 = (half == h && lr >= j + 1) ? row1 * pb.rinv1 : 0.f;
+    const float r0 = pb.rinv0, r1 = pb.rinv1;
+    float p00 = 1.f, p10 = 0.f, p11 = 1.f, u0 = 0.f, u1 = 0.f, v0 = 0.f, v1 = 0.f;
+    if constexpr (j < 30) {
+      constexpr int h2 = ((j + 2) >> 2) & 1, r2 = ((j + 2) & 3) + 4 * ((j + 2) >> 3);
+      p00 = rdlane_u(acc[r2], 32 * h2 + j + 2);
+      p10 = rdlane_u(acc[r2 + 1], 32 * h2 + j + 2);
+      p11 = rdlane_u(acc[r2 + 1], 32 * h2 + j + 3);
+      u0 = rdlane_u(l0, 32 * h + j + 2);
+      u1 = rdlane_u(l1, 32 * h + j + 2);
+      v0 = rdlane_u(l0, 32 * h + j + 3);
+      v1 = rdlane_u(l1, 32 * h + j + 3);
+    }
+    const float op = pair_operand(l0, l1, h);
+    acc = mfma2(-op, op, acc);
+    if constexpr (j < 30) pb = pivot_block(p00, p10, p11, u0, u1, v0, v1);
+    // z = L^-1 v on full-wave copies of the two columns
+    const float f0 = both_halves(l0), f1 = both_halves(l1);
+    const float z0 = rdlane_u(rz, j) * r0;
+    rz = fmaf(-f0, z0, rz);
+    const float z1 = rdlane_u(rz, j + 1) * r1;
+    rz = fmaf(-f1, z1, rz);
+    quad = fmaf(z1, z1, fmaf(z0, z0, quad));
+    rprod *= r0 * r1;
+  });
+  return -0.5f * quad - 0.5f * 32.0f * 1.8378770664093453f + fast_log(rprod);
+}
+
+// waves 0, 1: forward substitution of their tile of H P (accumulators of phase A) behind the factorizing wave, two
+// rows per MFMA; W -> sT rows 32..63, c = 1e-3 W^T g and m+ = m + W^T z for their 32 columns
+__device__ __forceinline__ void eliminate_rhs(f32x16& acc, int c, lds_f* sL, lds_f* sRinv, lds_i* progress, lds_f* sT, lds_f* sv,
+                                              lds_f* mcur, lds_f* mnxt, lds_f* scv, int lane) {
+  constexpr int PP = 65;
+  const int lr = lane & 31, half = lane >> 5;
+  float rg = 1.0f, rz = sv[lr], acc_c = 0.f, acc_m = 0.f;
+  auto wait_for = [&](int cols) {  // wave-uniform; the producer always reaches 32
+    int seen = *(volatile lds_i*)progress;
+    while (seen < cols) {
+      __builtin_amdgcn_s_sleep(2);
+      seen = *(volatile lds_i*)progress;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");  // LDS only: a full fence would also drain the wave's output stores
+  };
+  // in batches of BF_MFMA_RHSB columns, a batch behind the factorizing wave: one poll and one round of LDS reads per batch
+  static_for<0, 32 / BF_MFMA_RHSB>([&](auto Bt) {
+    constexpr int j0 = decltype(Bt)::value * BF_MFMA_RHSB;
+    wait_for(j0 + BF_MFMA_RHSB);
+    float Lb[BF_MFMA_RHSB], rb[BF_MFMA_RHSB], sb[BF_MFMA_RHSB / 2];
+    static_for<0, BF_MFMA_RHSB>([&](auto I) {
+      Lb[decltype(I)::value] = sL[32 * (j0 + decltype(I)::value) + lr];   // L[lr][j], both halves
+      rb[decltype(I)::value] = sRinv[j0 + decltype(I)::value];
+    });
+    static_for<0, BF_MFMA_RHSB / 2>([&](auto I) {
+      constexpr int j = j0 + 2 * decltype(I)::value;
+      sb[decltype(I)::value] = sL[32 * j + j + 1];                         // L[j+1][j]
+    });
+    static_for<0, BF_MFMA_RHSB / 2>([&](auto I) {
+      constexpr int q = decltype(I)::value, j = j0 + 2 * q;
+      constexpr int h = (j >> 2) & 1, rj = (j & 3) + 4 * (j >> 3);
+      const float La = Lb[2 * q], Lc = Lb[2 * q + 1], ra = rb[2 * q], rc = rb[2 * q + 1];
+      const float W0 = acc[rj] * ra;                                       // W[j][32 c + lr] in the lanes of half h
+      const float W1 = fmaf(-sb[q], W0, acc[rj + 1]) * rc;                 // W[j+1][..]
+      if (half == h) {
+        sT[(32 + j) * PP + 32 * c + lr] = W0;
+        sT[(33 + j) * PP + 32 * c + lr] = W1;
+      }
+      const float W0m = (half == h) ? W0 : 0.f, W1m = (half == h) ? W1 : 0.f;
+      const float Bop = pair_operand(W0m, W1m, h);
+      const float Aop = half == 0 ? -La : -Lc;
+      acc = mfma2(Aop, Bop, acc);                                          // rhs[k][n] -= L[k][j] W[j][n] + L[k][j+1] W[j+1][n]
+      const float g0 = rdlane_u(rg, j) * ra, z0 = rdlane_u(rz, j) * ra;    // g = L^-1 1, z = L^-1 v
+      rg = fmaf(-La, g0, rg);
+      rz = fmaf(-La, z0, rz);
+      const float g1 = rdlane_u(rg, j + 1) * rc, z1 = rdlane_u(rz, j + 1) * rc;
+      rg = fmaf(-Lc, g1, rg);
+      rz = fmaf(-Lc, z1, rz);
+      acc_c = fmaf(W1m, g1, fmaf(W0m, g0, acc_c));
+      acc_m = fmaf(W1m, z1, fmaf(W0m, z0, acc_m));
+    });
+  });
+  acc_c += __shfl_xor(acc_c, 32, 64);
+  acc_m += __shfl_xor(acc_m, 32, 64);
+  if (lane < 32) {
+    scv[32 * c + lane] = acc_c * 1e-3f;                                // sqrt(1e-6) (W^T g): enters P+ as + c c^T
+    mnxt[32 * c + lane] = mcur[32 * c + lane] + acc_m;                 // filtered mean
+  }
+}
+
+template <int N, int M, int VAR>
+__global__ void __launch_bounds__(256, 2)
+kf_scan_mfma2_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView carry, OutViews out, long long B, long long T) {
+  static_assert(N == 64 && M == 32, "tile assignment is written for n = 64, m = 32");
+  constexpr int PP = N + 1, PS = M + 1;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(((tid >> 6) + (int)blockIdx.x) & 3);  // rotated roles (see variant 1)
+  const int ti = wave >> 1, tj = wave & 1;
+  const int lr = lane & 31, lk = lane >> 5;
+  const long long b = blockIdx.x;
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sP = lds;                 // [64][65]  current covariance
+  float* sT = sP + N * PP;         // [64][65]  rows 0..31: H P; rows 32..63: W; then A P+
+  float* sA = sT + N * PP;         // [64][65]  A
+  float* sH = sA + N * PP;         // [32][65]  H
+  float* sD = sH + M * PP;         // [32][33]  D R D^T
+  float* sc2 = sD + M * PS;        // [32][33]  S as wave 2 sees it (layout change through LDS)
+  float* sc3 = sc2 + M * PS;       // [32][33]  S as wave 3 sees it
+  float* sm = sc3 + M * PS;        // [64] mean
+  float* sm2 = sm + N;             // [64] mean (ping-pong)
+  float* sv = sm2 + N;             // [32] innovation
+  float* scv = sv + M;             // [64] 1e-3 W^T g
+
+  for (int e = tid; e < N * N; e += 256) sA[(e / N) * PP + (e % N)] = cst->A[e];
+  for (int e = tid; e < M * N; e += 256) sH[(e / N) * PP + (e % N)] = cst->H[e];
+  for (int e = tid; e < M * M; e += 256) sD[(e / M) * PS + (e % M)] = cst->DRD[e];
+  BF_UNROLL for (int r = 0; r < 16; ++r)
+    sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = carry.P_in[b * N * N + (32 * ti + c_row(r, lane)) * N + 32 * tj + lr];
+  if (tid < N) sm[tid] = carry.m_in[b * N + tid];
+  float w = carry.w_in ? carry.w_in[b] : 1.0f;
+  float ynext = (wave == 2 && lane < M) ? y.p[b * y.sB + lane * y.sE] : 0.f;
+  if (tid == 0) *reinterpret_cast<int*>(sc2 + 32) = 0;
+  __syncthreads();
+
+#ifdef BF_MFMA_PHASE_TIMERS
+  long long tacc[10] = {0};
+  long long tprev = wall_clock64();
+#endif
+  float* mcur = sm;
+  float* mnxt = sm2;
+  for (long long t = 0; t < T; ++t) {
+    // ================= phase A: H P (waves 0,1); innovation (wave 2)
+    f32x16 hp = {0};  // variant 3: the wave's tile of H P stays in its accumulators for the forward substitution
+    if (wave < 2) {
+      BF_UNROLL for (int s = 0; s < 32; ++s) hp = mfma2(sH[lr * PP + 2 * s + lk], sP[(2 * s + lk) * PP + 32 * tj + lr], hp);
+      BF_UNROLL for (int r = 0; r < 16; ++r) sT[c_row(r, lane) * PP + 32 * tj + lr] = hp[r];
+    } else if (wave == 2) {
+      const float yv = ynext;
+      const long long tn = t + 1 < T ? t + 1 : t;
+      if (lane < M) ynext = y.p[b * y.sB + tn * y.sT + lane * y.sE];  // prefetch
+      float s = 0.f;
+      BF_UNROLL for (int q = 0; q < 32; ++q) s = fmaf(sH[lr * PP + 2 * q + lk], mcur[2 * q + lk], s);
+      s += __shfl_xor(s, 32, 64);
+      if (lane < M) sv[lane] = yv - (s + cst->Dr0[lane]);
+    }
+    BF_TICK(0)
+    lds_barrier();
+    BF_TICK(1)
+    // ================= phases B + C (waves 2 and 3): S, its factorizations, W, c, m+
+    float ll = 0.f;
+    if (wave >= 2) {
+      f32x16 acc;
+      BF_UNROLL for (int r = 0; r < 16; ++r) acc[r] = sD[c_row(r, lane) * PS + lr];
+      BF_UNROLL for (int s = 0; s < 32; ++s) acc = mfma2(sT[lr * PP + 2 * s + lk], sH[lr * PP + 2 * s + lk], acc);
+      if constexpr (VAR == 2) {
+        float* sc = wave == 2 ? sc2 : sc3;
+        BF_UNROLL for (int r = 0; r < 16; ++r) sc[c_row(r, lane) * PS + lr] = acc[r];
+        wave_lds_order();
+        if (wave == 3) chol_w_rows((lds_f*)sc3, (lds_f*)sT, (lds_f*)sv, (lds_f*)mcur, (lds_f*)mnxt, (lds_f*)scv, lane);
+        else ll = chol_loglik_rows((lds_f*)sc2, (lds_f*)sv, lane);
+      } else {
+        if (wave == 3) {
+          BF_UNROLL for (int r = 0; r < 16; ++r) acc[r] += 1e-6f;   // psd_solve's jitter on every entry (utils.py:258)
+          eliminate_publish(acc, (lds_f*)sc3, (lds_f*)sc2, (lds_i*)(sc2 + 32), lane);
+        } else {
+          ll = eliminate_loglik(acc, (lds_f*)sv, lane);
+        }
+      }
+    } else if constexpr (VAR == 3) {
+      eliminate_rhs(hp, tj, (lds_f*)sc3, (lds_f*)sc2, (lds_i*)(sc2 + 32), (lds_f*)sT, (lds_f*)sv, (lds_f*)mcur, (lds_f*)mnxt,
+                    (lds_f*)scv, lane);
+    }
+    BF_TICK(2)
+    lds_barrier();
+    BF_TICK(3)
+    // ================= phase H: P+ = P - W^T W + c c^T (all waves; K = 32 + 2); emit filtered streams
+    f32x16 Pacc;
+    BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] = sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr];
+    BF_UNROLL for (int s = 0; s < 16; ++s)
+        Pacc = mfma2(-sT[(32 + 2 * s + lk) * PP + 32 * ti + lr], sT[(32 + 2 * s + lk) * PP + 32 * tj + lr], Pacc);
+    Pacc = mfma2(lk == 0 ? scv[32 * ti + lr] : 0.f, lk == 0 ? scv[32 * tj + lr] : 0.f, Pacc);
+    BF_UNROLL for (int r = 0; r < 16; ++r) sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = Pacc[r];
+    if (out.P.p) BF_UNROLL for (int r = 0; r < 16; ++r)
+        out.P.p[b * out.P.sB + t * out.P.sT + ((32 * ti + c_row(r, lane)) * N + 32 * tj + lr) * out.P.sE] = Pacc[r];
+    if (wave == 1 && out.m.p) out.m.p[b * out.m.sB + t * out.m.sT + lane * out.m.sE] = mnxt[lane];
+    if (VAR == 3 && wave == 3 && lane == 0) *reinterpret_cast<int*>(sc2 + 32) = 0;  // progress counter re-armed (three barriers ahead of its next use)
+    if (wave == 2 && lane == 0) {
+      w = reweight_single(ll, w);
+      if (out.w.p) out.w.p[b * out.w.sB + t * out.w.sT] = w;
+      if (out.ll.p) out.ll.p[b * out.ll.sB + t * out.ll.sT] = ll;
+    }
+    BF_TICK(4)
+    lds_barrier();
+    BF_TICK(5)
+    // ================= phase I: A P+ -> sT (all waves; K = 64); m- = A m+ + G q0 (waves 0, 3)
+    {
+      f32x16 acc = {0};
+      BF_UNROLL for (int s = 0; s < 32; ++s) acc = mfma2(sA[(32 * ti + lr) * PP + 2 * s + lk], sP[(2 * s + lk) * PP + 32 * tj + lr], acc);
+      BF_UNROLL for (int r = 0; r < 16; ++r) sT[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = acc[r];
+    }
+    if (wave == 0 || wave == 3) {
+      float s = 0.f;
+      BF_UNROLL for (int q = 0; q < 32; ++q) s = fmaf(sA[(32 * ti + lr) * PP + 2 * q + lk], mnxt[2 * q + lk], s);
+      s += __shfl_xor(s, 32, 64);
+      if (lane < 32) mcur[32 * ti + lane] = s + cst->Gq0[32 * ti + lane];  // predicted mean
+    }
+    BF_TICK(6)
+    lds_barrier();
+    BF_TICK(7)
+    // ================= phase J: P- = (A P+) A^T + G Q G^T (all waves; K = 64); emit predicted streams
+    BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] = cst->GQG[(32 * ti + c_row(r, lane)) * N + 32 * tj + lr];
+    BF_UNROLL for (int s = 0; s < 32; ++s) Pacc = mfma2(sT[(32 * ti + lr) * PP + 2 * s + lk], sA[(32 * tj + lr) * PP + 2 * s + lk], Pacc);
+    BF_UNROLL for (int r = 0; r < 16; ++r) sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = Pacc[r];
+    if (out.pP.p) BF_UNROLL for (int r = 0; r < 16; ++r)
+        out.pP.p[b * out.pP.sB + t * out.pP.sT + ((32 * ti + c_row(r, lane)) * N + 32 * tj + lr) * out.pP.sE] = Pacc[r];
+    if (wave == 2 && out.pm.p) out.pm.p[b * out.pm.sB + t * out.pm.sT + lane * out.pm.sE] = mcur[lane];
+    BF_TICK(8)
+    lds_barrier();
+    BF_TICK(9)
+  }
+
+  if (carry.P_out) BF_UNROLL for (int r = 0; r < 16; ++r)
+      carry.P_out[b * N * N + (32 * ti + c_row(r, lane)) * N + 32 * tj + lr] = sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr];
+  if (carry.m_out && tid < N) carry.m_out[b * N + tid] = mcur[tid];
+  if (carry.w_out && wave == 2 && lane == 0) carry.w_out[b] = w;
+#ifdef BF_MFMA_PHASE_TIMERS
+  __syncthreads();
+  if (b == 0 && lane == 0 && carry.P_out) for (int i = 0; i < 10; ++i) carry.P_out[wave * 16 + i] = (float)tacc[i];
+#endif
+}
+
 // ---------------------------------------------------------------------------------------
 int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
                    const bf_out_desc* out, hipStream_t stream) {
@@ -525,11 +974,19 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
   CarryView cv{carry->w_in, carry->m_in, carry->P_in, carry->w_out, carry->m_out, carry->P_out};
   OutViews ov{make_sview(out->weights), make_sview(out->means), make_sview(out->covs),
               make_sview(out->pred_means), make_sview(out->pred_covs), make_sview(out->loglik)};
-  const size_t lds_bytes = sizeof(float) * (size_t)(3 * N * (N + 1) + N * (M + 1) + 3 * M * (M + 1) + M * (N + 1) + 2 * N + 2 * M + 4);
-  auto kern = kf_scan_mfma_kernel<N, M>;
-  if (lds_bytes > 64 * 1024)
-    BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(256), lds_bytes, stream, d, yv, cv, ov, B, T);
+  if (g_kf_mfma_variant.load() == 1) {
+    const size_t lds_bytes = sizeof(float) * (size_t)(3 * N * (N + 1) + N * (M + 1) + 3 * M * (M + 1) + M * (N + 1) + 2 * N + 2 * M + 4);
+    auto kern = kf_scan_mfma_kernel<N, M>;
+    if (lds_bytes > 64 * 1024)
+      BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(256), lds_bytes, stream, d, yv, cv, ov, B, T);
+  } else {
+    const size_t lds_bytes = sizeof(float) * (size_t)(3 * N * (N + 1) + M * (N + 1) + 3 * M * (M + 1) + 3 * N + M);
+    auto kern = g_kf_mfma_variant.load() == 2 ? kf_scan_mfma2_kernel<N, M, 2> : kf_scan_mfma2_kernel<N, M, 3>;
+    if (lds_bytes > 64 * 1024)
+      BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(256), lds_bytes, stream, d, yv, cv, ov, B, T);
+  }
   BF_HIP_CHECK(hipGetLastError());
   return BF_OK;
 }
