@@ -52,10 +52,11 @@ class bf_model(C.Structure):
     _fields_ = [("dyn_id", C.c_int32), ("emi_id", C.c_int32), ("n", C.c_int32), ("dq", C.c_int32), ("m", C.c_int32),
                 ("dr", C.c_int32), ("dyn_theta", _FP), ("n_dyn_theta", C.c_int32), ("emi_theta", _FP),
                 ("n_emi_theta", C.c_int32), ("q0", _FP), ("r0", _FP), ("Q", _FP), ("R", _FP), ("flags", C.c_int32),
-                ("Q_steps", C.c_int32), ("R_steps", C.c_int32)]
+                ("Q_steps", C.c_int32), ("R_steps", C.c_int32), ("user", C.c_void_p)]
 
 
 BF_MODEL_PREDICT_FIRST, BF_MODEL_NO_JITTER, BF_MODEL_LEGACY_GSF_COV = 1, 2, 4
+BF_FN_USER = 100
 
 
 class bf_ukf_params(C.Structure):
@@ -106,6 +107,8 @@ SYMBOLS = {
     "bf_sample_ssm_f32": (C.c_int, [C.POINTER(bf_bpf_model), C.c_void_p, C.POINTER(bf_cstream), C.c_int64, C.c_int64,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "bf_resample_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "bf_user_model_create": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "bf_user_model_destroy": (None, [C.c_void_p]),
     "bf_canon_eval_f32": (C.c_int, [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "bf_random_normal_f32": (C.c_int, [C.POINTER(C.c_uint32), C.c_int64, _FP]),
     "bf_random_split": (C.c_int, [C.POINTER(C.c_uint32), C.c_int64, C.POINTER(C.c_uint32)]),

@@ -207,6 +207,7 @@ int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream*
   if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
   hipStream_t hs = static_cast<hipStream_t>(stream);
   auto generic = [&]() { return bf::launch_gsf_generic(model, y, u, B, T, K, carry, out, hs); };
+  if (model->user || model->dyn_id == BF_FN_USER || model->emi_id == BF_FN_USER) return generic();  // compiled from source
   if (bf::g_force_generic.load()) return generic();
   return bf::with_generic_fallback(
       bf::launch_gsf_ekf(model, y, u, B, T, K, carry, out, hs, bf::g_kf_emit_mode.load(), bf::g_kf_lanes.load()), generic);

@@ -1,0 +1,291 @@
+// user_model: dynamics / emission functions given as SOURCE TEXT at run time.
+//
+// The reference takes arbitrary Python callables f(x, q, u), h(x, r, u) (gaussfiltax/models.py:46-49) and differentiates
+// them with jacfwd (gaussfiltax/inference.py:328-329).  A Python callable cannot run inside a HIP kernel; what can cross
+// the C-ABI is the function's source.  bf_user_model_create compiles, with hiprtc, the run-time-dimension scan kernel
+// (generic_device.hpp, whose text is embedded in this library) together with the caller's
+//     template <class T> __device__ void dynamics(const T* x, const T* q, T u, const float* theta, T* out);
+//     template <class T> __device__ void emission(const T* x, const T* r, T u, const float* theta, T* out);
+// and the Jacobians come from forward-mode dual numbers (T = bfu::Dual), i.e. exactly what jacfwd computes: one lane per
+// seed direction.  Code objects are cached by source hash, in memory and on disk.  hiprtc is loaded lazily (dlopen), from
+// next to the HIP runtime the process already uses, so the library itself carries no link-time dependency on it.
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "bf_common.hpp"
+
+struct bf_user_model {
+  hipModule_t mod = nullptr;
+  hipFunction_t k64 = nullptr, k256 = nullptr;
+  int n = 0, dq = 0, m = 0, dr = 0;
+  bool has_dyn = false, has_emi = false;
+};
+
+namespace bf {
+
+extern const char* const kGenericDeviceSource;  // generic_device.hpp, embedded at build time (jit_sources.cpp)
+
+namespace {
+
+// ---- hiprtc, resolved at first use
+typedef struct _hiprtcProgram* hiprtcProgram;
+struct Rtc {
+  void* h = nullptr;
+  int (*CreateProgram)(hiprtcProgram*, const char*, const char*, int, const char**, const char**) = nullptr;
+  int (*CompileProgram)(hiprtcProgram, int, const char**) = nullptr;
+  int (*GetProgramLogSize)(hiprtcProgram, size_t*) = nullptr;
+  int (*GetProgramLog)(hiprtcProgram, char*) = nullptr;
+  int (*GetCodeSize)(hiprtcProgram, size_t*) = nullptr;
+  int (*GetCode)(hiprtcProgram, char*) = nullptr;
+  int (*DestroyProgram)(hiprtcProgram*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+Rtc g_rtc;
+std::mutex g_mu;
+std::map<std::string, bf_user_model*> g_models;  // by source hash: a model compiled once is shared (never freed while cached)
+
+bool load_rtc(std::string& why) {
+  if (g_rtc.h) return true;
+  std::vector<std::string> cand;
+  Dl_info info;
+  if (dladdr(reinterpret_cast<void*>(&hipModuleLoadData), &info) && info.dli_fname) {  // next to the runtime in use
+    std::string p(info.dli_fname);
+    const size_t slash = p.rfind('/');
+    if (slash != std::string::npos) cand.push_back(p.substr(0, slash + 1) + "libhiprtc.so");
+  }
+  cand.push_back("libhiprtc.so");
+  cand.push_back("libhiprtc.so.7");
+  cand.push_back("/opt/rocm/lib/libhiprtc.so");
+  for (const std::string& c : cand) {
+    void* h = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+      why += c + ": " + (dlerror() ? dlerror() : "?") + "; ";
+      continue;
+    }
+#define BF_RTC_SYM(F_) *reinterpret_cast<void**>(&g_rtc.F_) = dlsym(h, "hiprtc" #F_)
+    BF_RTC_SYM(CreateProgram); BF_RTC_SYM(CompileProgram); BF_RTC_SYM(GetProgramLogSize); BF_RTC_SYM(GetProgramLog);
+    BF_RTC_SYM(GetCodeSize); BF_RTC_SYM(GetCode); BF_RTC_SYM(DestroyProgram); BF_RTC_SYM(GetErrorString);
+#undef BF_RTC_SYM
+    if (g_rtc.CreateProgram && g_rtc.CompileProgram && g_rtc.GetCodeSize && g_rtc.GetCode && g_rtc.DestroyProgram) {
+      g_rtc.h = h;
+      return true;
+    }
+    why += c + ": hiprtc entry points missing; ";
+    dlclose(h);
+  }
+  return false;
+}
+
+uint64_t fnv1a(const std::string& s) {
+  uint64_t h = 1469598103934665603ull;
+  for (unsigned char c : s) h = (h ^ c) * 1099511628211ull;
+  return h;
+}
+
+// forward-mode dual numbers + the elementary functions a model may call, for float and Dual alike (namespace bfu: the
+// caller's source is compiled inside it, so unqualified sin / exp / sqrt ... resolve for both instantiations)
+const char* const kDualPrelude = R"BFSRC(
+namespace bfu {
+struct Dual {
+  float v, d;
+  __device__ Dual() : v(0.f), d(0.f) {}
+  __device__ Dual(float a) : v(a), d(0.f) {}
+  __device__ Dual(float a, float b) : v(a), d(b) {}
+};
+#pragma clang fp contract(off)
+__device__ inline Dual operator+(Dual a, Dual b) { return Dual(a.v + b.v, a.d + b.d); }
+__device__ inline Dual operator-(Dual a, Dual b) { return Dual(a.v - b.v, a.d - b.d); }
+__device__ inline Dual operator*(Dual a, Dual b) { return Dual(a.v * b.v, a.d * b.v + a.v * b.d); }
+__device__ inline Dual operator/(Dual a, Dual b) { const float q = a.v / b.v; return Dual(q, (a.d - q * b.d) / b.v); }
+__device__ inline Dual operator-(Dual a) { return Dual(-a.v, -a.d); }
+__device__ inline Dual operator+(Dual a) { return a; }
+__device__ inline Dual operator+(Dual a, float b) { return Dual(a.v + b, a.d); }
+__device__ inline Dual operator+(float a, Dual b) { return Dual(a + b.v, b.d); }
+__device__ inline Dual operator-(Dual a, float b) { return Dual(a.v - b, a.d); }
+__device__ inline Dual operator-(float a, Dual b) { return Dual(a - b.v, -b.d); }
+__device__ inline Dual operator*(Dual a, float b) { return Dual(a.v * b, a.d * b); }
+__device__ inline Dual operator*(float a, Dual b) { return Dual(a * b.v, a * b.d); }
+__device__ inline Dual operator/(Dual a, float b) { return Dual(a.v / b, a.d / b); }
+__device__ inline Dual operator/(float a, Dual b) { const float q = a / b.v; return Dual(q, -q * b.d / b.v); }
+__device__ inline Dual& operator+=(Dual& a, Dual b) { a = a + b; return a; }
+__device__ inline Dual& operator-=(Dual& a, Dual b) { a = a - b; return a; }
+__device__ inline Dual& operator*=(Dual& a, Dual b) { a = a * b; return a; }
+__device__ inline Dual& operator/=(Dual& a, Dual b) { a = a / b; return a; }
+__device__ inline bool operator<(Dual a, Dual b) { return a.v < b.v; }
+__device__ inline bool operator>(Dual a, Dual b) { return a.v > b.v; }
+__device__ inline bool operator<=(Dual a, Dual b) { return a.v <= b.v; }
+__device__ inline bool operator>=(Dual a, Dual b) { return a.v >= b.v; }
+__device__ inline float sin(float x) { return ::sinf(x); }
+__device__ inline float cos(float x) { return ::cosf(x); }
+__device__ inline float tan(float x) { return ::tanf(x); }
+__device__ inline float exp(float x) { return ::expf(x); }
+__device__ inline float log(float x) { return ::logf(x); }
+__device__ inline float sqrt(float x) { return ::sqrtf(x); }
+__device__ inline float tanh(float x) { return ::tanhf(x); }
+__device__ inline float atan(float x) { return ::atanf(x); }
+__device__ inline float atan2(float y, float x) { return ::atan2f(y, x); }
+__device__ inline float pow(float x, float p) { return ::powf(x, p); }
+__device__ inline float abs(float x) { return ::fabsf(x); }
+__device__ inline Dual sin(Dual x) { return Dual(::sinf(x.v), ::cosf(x.v) * x.d); }
+__device__ inline Dual cos(Dual x) { return Dual(::cosf(x.v), -::sinf(x.v) * x.d); }
+__device__ inline Dual tan(Dual x) { const float t = ::tanf(x.v); return Dual(t, (1.f + t * t) * x.d); }
+__device__ inline Dual exp(Dual x) { const float e = ::expf(x.v); return Dual(e, e * x.d); }
+__device__ inline Dual log(Dual x) { return Dual(::logf(x.v), x.d / x.v); }
+__device__ inline Dual sqrt(Dual x) { const float s = ::sqrtf(x.v); return Dual(s, x.d / (2.f * s)); }
+__device__ inline Dual tanh(Dual x) { const float t = ::tanhf(x.v); return Dual(t, (1.f - t * t) * x.d); }
+__device__ inline Dual atan(Dual x) { return Dual(::atanf(x.v), x.d / (1.f + x.v * x.v)); }
+__device__ inline Dual atan2(Dual y, Dual x) { const float r2 = x.v * x.v + y.v * y.v; return Dual(::atan2f(y.v, x.v), (x.v * y.d - y.v * x.d) / r2); }
+__device__ inline Dual pow(Dual x, float p) { const float w = ::powf(x.v, p - 1.f); return Dual(w * x.v, p * w * x.d); }
+__device__ inline Dual abs(Dual x) { return x.v < 0.f ? -x : x; }
+)BFSRC";
+
+std::string build_source(const char* dyn_src, const char* emi_src, int n, int dq, int m, int dr) {
+  std::string s;
+  s += "#define BF_JIT 1\n";
+  if (dyn_src) s += "#define BF_USER_DYN 1\n";
+  if (emi_src) s += "#define BF_USER_EMI 1\n";
+  s += "#define BF_N " + std::to_string(n) + "\n#define BF_DQ " + std::to_string(dq) + "\n#define BF_M " + std::to_string(m) +
+       "\n#define BF_DR " + std::to_string(dr) + "\n";
+  s += kDualPrelude;
+  s += "\n// ---- the caller's functions\n";
+  if (dyn_src) s += std::string(dyn_src) + "\n";
+  if (emi_src) s += std::string(emi_src) + "\n";
+  s += "}  // namespace bfu\n";
+  s += kGenericDeviceSource;
+  s += R"BFSRC(
+extern "C" __global__ void __launch_bounds__(64) bf_user_scan_64(bf::GenModel p, bf::CView y, bf::UViewG u, bf::CarryView carry,
+    bf::OutViews out, float* gm, float* gP, long long B, long long T, int K, int KP) {
+  bf::gsf_generic_body<64>(p, y, u, carry, out, gm, gP, B, T, K, KP);
+}
+extern "C" __global__ void __launch_bounds__(256) bf_user_scan_256(bf::GenModel p, bf::CView y, bf::UViewG u, bf::CarryView carry,
+    bf::OutViews out, float* gm, float* gP, long long B, long long T, int K, int KP) {
+  bf::gsf_generic_body<256>(p, y, u, carry, out, gm, gP, B, T, K, KP);
+}
+)BFSRC";
+  return s;
+}
+
+std::string cache_dir() {  // $BAYESFILT_CACHE_DIR, else .jit_cache next to this library
+  const char* e = std::getenv("BAYESFILT_CACHE_DIR");
+  std::string d;
+  if (e && *e) {
+    d = e;
+  } else {
+    Dl_info info;
+    d = ".";
+    if (dladdr(reinterpret_cast<void*>(&bf::set_error), &info) && info.dli_fname) {
+      const std::string p(info.dli_fname);
+      const size_t slash = p.rfind('/');
+      if (slash != std::string::npos) d = p.substr(0, slash);
+    }
+    d += "/.jit_cache";
+  }
+  mkdir(d.c_str(), 0755);
+  return d;
+}
+
+}  // namespace
+
+int launch_user_kernel(const bf_user_model* um, int nt, unsigned grid, size_t lds_bytes, hipStream_t stream, void** args) {
+  hipFunction_t f = nt == 64 ? um->k64 : um->k256;
+  if (lds_bytes > 64 * 1024) {
+    // module functions take the same attribute as host-side kernels; a runtime that refuses it reports the launch error below
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  }
+  BF_HIP_CHECK(hipModuleLaunchKernel(f, grid, 1, 1, (unsigned)nt, 1, 1, (unsigned)lds_bytes, stream, args, nullptr));
+  return BF_OK;
+}
+
+}  // namespace bf
+
+extern "C" {
+
+int bf_user_model_create(const char* dynamics_src, const char* emission_src, int32_t n, int32_t dq, int32_t m, int32_t dr,
+                         bf_user_model** model) {
+  using namespace bf;
+  if (!model || (!dynamics_src && !emission_src)) return set_error(BF_EINVAL, "bf_user_model_create: no source given");
+  if (n <= 0 || dq <= 0 || m <= 0 || dr <= 0 || n > 64 || dq > 64 || m > 64 || dr > 64)
+    return set_error(BF_EINVAL, "bf_user_model_create: dimensions must be in 1..64");
+  const std::string src = build_source(dynamics_src, emission_src, n, dq, m, dr);
+  char key[32];
+  std::snprintf(key, sizeof(key), "%016llx", (unsigned long long)fnv1a(src));
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_models.find(key);
+  if (it != g_models.end()) {
+    *model = it->second;
+    return BF_OK;
+  }
+  // ---- code object: disk cache, else hiprtc
+  std::vector<char> code;
+  const std::string path = cache_dir() + "/user_" + key + "_gfx950.co";
+  if (FILE* f = std::fopen(path.c_str(), "rb")) {
+    std::fseek(f, 0, SEEK_END);
+    const long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    if (sz > 0) {
+      code.resize((size_t)sz);
+      if (std::fread(code.data(), 1, (size_t)sz, f) != (size_t)sz) code.clear();
+    }
+    std::fclose(f);
+  }
+  if (code.empty()) {
+    std::string why;
+    if (!load_rtc(why)) return set_error(BF_EUNSUPPORTED, "hiprtc is not available: %.400s", why.c_str());
+    hiprtcProgram prog = nullptr;
+    int rc = g_rtc.CreateProgram(&prog, src.c_str(), "bf_user_model.hip", 0, nullptr, nullptr);
+    if (rc != 0) return set_error(BF_EHIP, "hiprtcCreateProgram failed (%d)", rc);
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+    rc = g_rtc.CompileProgram(prog, 4, opts);
+    if (rc != 0) {
+      size_t ls = 0;
+      std::string log;
+      if (g_rtc.GetProgramLogSize && g_rtc.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
+        log.resize(ls);
+        g_rtc.GetProgramLog(prog, &log[0]);
+      }
+      g_rtc.DestroyProgram(&prog);
+      // the first error lines are what the author of the source needs
+      const size_t pos = log.find("error");
+      return set_error(BF_EINVAL, "the model source does not compile: %.440s", (pos == std::string::npos ? log : log.substr(pos)).c_str());
+    }
+    size_t cs = 0;
+    rc = g_rtc.GetCodeSize(prog, &cs);
+    if (rc == 0 && cs > 0) {
+      code.resize(cs);
+      rc = g_rtc.GetCode(prog, code.data());
+    }
+    g_rtc.DestroyProgram(&prog);
+    if (rc != 0 || code.empty()) return set_error(BF_EHIP, "hiprtc returned no code object (%d)", rc);
+    if (FILE* f = std::fopen((path + ".tmp").c_str(), "wb")) {  // best effort
+      const bool ok = std::fwrite(code.data(), 1, code.size(), f) == code.size();
+      std::fclose(f);
+      if (ok) std::rename((path + ".tmp").c_str(), path.c_str());
+    }
+  }
+  bf_user_model* um = new bf_user_model;
+  um->n = n; um->dq = dq; um->m = m; um->dr = dr;
+  um->has_dyn = dynamics_src != nullptr;
+  um->has_emi = emission_src != nullptr;
+  hipError_t e = hipModuleLoadData(&um->mod, code.data());
+  if (e == hipSuccess) e = hipModuleGetFunction(&um->k64, um->mod, "bf_user_scan_64");
+  if (e == hipSuccess) e = hipModuleGetFunction(&um->k256, um->mod, "bf_user_scan_256");
+  if (e != hipSuccess) {
+    if (um->mod) (void)hipModuleUnload(um->mod);
+    delete um;
+    return set_error(BF_EHIP, "loading the compiled model failed: %s", hipGetErrorString(e));
+  }
+  g_models[key] = um;
+  *model = um;
+  return BF_OK;
+}
+
+void bf_user_model_destroy(bf_user_model* model) {
+  (void)model;  // compiled models are shared through the cache and live as long as the process
+}
+
+}  // extern "C"

@@ -256,7 +256,28 @@ class _Model:
         c.emi_theta, c.n_emi_theta = _fp(self.emi_theta), int(h.theta.size)
         c.q0, c.r0, c.Q, c.R = _fp(self.q0), _fp(self.r0), _fp(self.Q), _fp(self.R)
         c.Q_steps, c.R_steps = self.Q_steps, self.R_steps
+        # functions given as source text (nonlinearities.user_dynamics / user_emission): compiled once per source by hiprtc
+        dsrc = getattr(f, "source", None)
+        esrc = getattr(h, "source", None)
+        if dsrc is not None or esrc is not None:
+            c.user = _compile_user_model(dsrc, esrc, self.n, self.dq, self.m, self.dr)
         self.c = c
+
+
+_USER_MODELS = {}
+
+
+def _compile_user_model(dyn_src, emi_src, n, dq, m, dr):
+    """bf_user_model_create, memoised per (sources, dimensions); returns the opaque handle."""
+    key = (dyn_src, emi_src, n, dq, m, dr)
+    h = _USER_MODELS.get(key)
+    if h is None:
+        lib = _lib.require_gpu()
+        out = C.c_void_p()
+        _lib.check(lib.bf_user_model_create(dyn_src.encode() if dyn_src is not None else None,
+                                            emi_src.encode() if emi_src is not None else None, n, dq, m, dr, C.byref(out)))
+        h = _USER_MODELS[key] = out.value
+    return h
 
 
 def PRNGKey(seed: int):

@@ -208,12 +208,54 @@ def stoch_vol_log_prob(emission_function, covariance, r_eval=None):
     return StochVolLogProb(emission_function, covariance, r_eval)
 
 
+FN_USER = 100   # BF_FN_USER of include/bayesfilt.h: a function compiled at run time from source text
+
+
+class UserFunction(DeviceFunction):
+    """A dynamics / emission function OUTSIDE the registry, given as HIP C++ source text and compiled at run time
+    (hiprtc) into the scan kernel -- the engine's counterpart of the arbitrary Python callables the reference accepts
+    (gaussfiltax/models.py:46-49).  Its Jacobians come from forward-mode dual numbers, which is what the reference's
+    ``jacfwd`` computes (gaussfiltax/inference.py:328-329).  ``host_fn`` (optional) is a NumPy twin for use on the host;
+    the filters never call it."""
+
+    def __init__(self, kind, source, in_dim, out_dim, noise_dim, theta=(), host_fn=None, name="user"):
+        def _no_host(x, w, u):
+            raise NotImplementedError("this function exists as device source only (pass host_fn= for a NumPy twin)")
+        super().__init__(kind, FN_USER, in_dim, out_dim, noise_dim, theta, host_fn or _no_host, name)
+        self.source = str(source)
+
+
+def user_dynamics(source, state_dim, noise_dim=None, theta=(), host_fn=None, name="user_dynamics"):
+    """f(x, q, u) from source.  ``source`` defines::
+
+        template <class T> __device__ void dynamics(const T* x, const T* q, T u, const float* theta, T* out)
+
+    writing ``out[0 .. BF_N)``; ``BF_N``, ``BF_DQ``, ``BF_M``, ``BF_DR`` are compile-time constants, ``theta`` is this
+    function's parameter vector, and sin cos tan exp log sqrt tanh atan atan2 pow abs work for ``T``.  Example (the
+    Lorenz-63 map of docs/experiments/exp_lorentz63.py:37-41)::
+
+        template <class T> __device__ void dynamics(const T* x, const T* q, T u, const float* th, T* out) {
+          out[0] = th[3] * th[0] * (x[1] - x[0]) + x[0] + q[0];
+          out[1] = th[3] * (x[0] * th[1] - x[1] - x[0] * x[2]) + x[1] + q[1];
+          out[2] = th[3] * (x[0] * x[1] - th[2] * x[2]) + x[2] + q[2];
+        }
+    """
+    return UserFunction("dynamics", source, state_dim, state_dim, state_dim if noise_dim is None else noise_dim, theta, host_fn, name)
+
+
+def user_emission(source, state_dim, emission_dim, noise_dim=None, theta=(), host_fn=None, name="user_emission"):
+    """h(x, r, u) from source: ``template <class T> __device__ void emission(const T* x, const T* r, T u, const float*
+    theta, T* out)`` writing ``out[0 .. BF_M)`` (see :func:`user_dynamics`)."""
+    return UserFunction("emission", source, state_dim, emission_dim, emission_dim if noise_dim is None else noise_dim, theta,
+                        host_fn, name)
+
+
 def require_device_function(fn, kind, what):
     if not isinstance(fn, DeviceFunction) or fn.kind != kind:
         raise TypeError(
-            f"{what} must be a {kind} DeviceFunction from bayesianfiltering_amd.nonlinearities "
-            f"(got {type(fn).__name__}): Python callables cannot run inside the HIP kernels, and "
-            "there is no CPU fallback.")
+            f"{what} must be a {kind} DeviceFunction from bayesianfiltering_amd.nonlinearities -- a registry function or "
+            f"nonlinearities.user_{kind}(source, ...) -- (got {type(fn).__name__}): a Python callable cannot run inside "
+            "the HIP kernels, and there is no CPU fallback.")
     return fn
 
 

@@ -161,7 +161,29 @@ typedef struct bf_model {
   int32_t Q_steps, R_steps; /* 0 or 1 = constant; T = one covariance per step, the (T,d,d) arrays that
                                _get_params(..., 2, t) selects from (inference.py:21, :337-340).  Honoured by
                                bf_gsf_ekf_f32 (emissions with a constant H_r); the sampling kernels need 0 / 1. */
+  const struct bf_user_model* user; /* functions compiled from source (dyn_id / emi_id = BF_FN_USER), else NULL */
 } bf_model;
+
+/* ---- user-defined f / h ------------------------------------------------------------------------
+ * The reference accepts arbitrary Python callables f(x, q, u), h(x, r, u) (gaussfiltax/models.py:46-49) and takes their
+ * Jacobians with jacfwd (gaussfiltax/inference.py:328-329).  Here a function outside the registry is given as HIP C++
+ * SOURCE TEXT, written once for any scalar type:
+ *
+ *     template <class T> __device__ void dynamics(const T* x, const T* q, T u, const float* theta, T* out);   // out[BF_N]
+ *     template <class T> __device__ void emission(const T* x, const T* r, T u, const float* theta, T* out);   // out[BF_M]
+ *
+ * (BF_N, BF_DQ, BF_M, BF_DR are compile-time constants; sin cos tan exp log sqrt tanh atan atan2 pow abs are available
+ * for T; theta = bf_model.dyn_theta / emi_theta).  bf_user_model_create compiles it with hiprtc into the
+ * run-time-dimension scan kernel; values come from T = float, Jacobians w.r.t. state AND noise from forward-mode dual
+ * numbers (what jacfwd computes), F_q Q F_q^T / H_r R H_r^T are formed on the device every step.  Either source may be
+ * NULL (that side stays a registry function).  Compiled models are cached by source (memory + $BAYESFILT_CACHE_DIR,
+ * default .jit_cache next to the library); a source that does not compile returns BF_EINVAL with the compiler's first error in
+ * bf_last_error().  Use: set bf_model.user and dyn_id / emi_id = BF_FN_USER, then call bf_gsf_ekf_f32. */
+#define BF_FN_USER 100
+typedef struct bf_user_model bf_user_model;
+int bf_user_model_create(const char* dynamics_src, const char* emission_src, int32_t n, int32_t dq, int32_t m, int32_t dr,
+                         bf_user_model** model);
+void bf_user_model_destroy(bf_user_model* model);
 
 /* Hyper-parameters of the unscented transform -- ParamsUKF (inference.py:41-49): lambda =
  * alpha^2 (L + kappa) - L with L = state_dim + noise_dim of the augmented state. */

@@ -100,3 +100,21 @@ def test_struct_sizes_agree_with_a_c_compiler(tmp_path):
     sizes = dict(line.split() for line in out.strip().splitlines())
     for n in names:
         assert int(sizes[n]) == C.sizeof(getattr(_lib, n)), (n, sizes[n], C.sizeof(getattr(_lib, n)))
+
+
+def test_user_model_source_compiles_without_a_gpu():
+    """hiprtc needs no device to COMPILE: a well-formed source gets as far as loading the code object (BF_EHIP without a
+    GPU, BF_OK with one), a malformed one is refused with the compiler's message."""
+    import ctypes as C
+    from bayesianfiltering_amd import _lib
+    lib = _lib.load()
+    good = b"template <class T> __device__ void dynamics(const T* x, const T* q, T u, const float* th, T* out) { out[0] = sin(x[0]) * th[0] + q[0]; }"
+    h = C.c_void_p()
+    rc = lib.bf_user_model_create(good, None, 1, 1, 1, 1, C.byref(h))
+    assert rc in (_lib.BF_OK, _lib.BF_EHIP), lib.bf_last_error()
+    if rc == _lib.BF_EHIP:
+        assert b"loading the compiled model" in lib.bf_last_error()
+    bad = b"template <class T> __device__ void dynamics(const T* x, const T* q, T u, const float* th, T* out) { out[0] = undefined_fn(x[0]); }"
+    assert lib.bf_user_model_create(bad, None, 1, 1, 1, 1, C.byref(h)) == _lib.BF_EINVAL
+    assert b"undefined_fn" in lib.bf_last_error()
+    assert lib.bf_user_model_create(None, None, 1, 1, 1, 1, C.byref(h)) == _lib.BF_EINVAL

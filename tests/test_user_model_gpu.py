@@ -1,0 +1,205 @@
+"""User-defined f / h from SOURCE TEXT (bf_user_model_create: hiprtc + forward-mode dual numbers), the engine's
+counterpart of the arbitrary Python callables and `jacfwd` of the reference (gaussfiltax/models.py:46-49,
+gaussfiltax/inference.py:328-329):
+* source twins of registry functions (Lorenz-63, the growth model) against the registry functions themselves -- bit for
+  bit where the expressions are the same, to rounding where dual-number and hand-derived Jacobians differ in form;
+* a model OUTSIDE the registry (pendulum with state-dependent observation noise) against the oracle with analytic Jacobians."""
+import numpy as np
+import pytest
+
+from oracle import gaussfilt_oracle as go, models as om, threefry as otf
+from tests import common as cm
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+FIELDS = ("weights", "means", "covariances", "predicted_means", "predicted_covariances")
+
+L63_SRC = """
+template <class T> __device__ void dynamics(const T* x, const T* q, T u, const float* th, T* out) {
+  const float s = th[0], r = th[1], b = th[2], dt = th[3];
+  out[0] = dt * s * (x[1] - x[0]) + x[0] + q[0];
+  out[1] = dt * (x[0] * r - x[1] - x[0] * x[2]) + x[1] + q[1];
+  out[2] = dt * (x[0] * x[1] - b * x[2]) + x[2] + q[2];
+}
+"""
+QUAD_SRC = """
+template <class T> __device__ void emission(const T* x, const T* r, T u, const float* th, T* out) {
+  T s = x[0] * x[0];
+  for (int i = 1; i < BF_N; ++i) s = s + x[i] * x[i];
+  out[0] = th[0] * s + r[0];
+}
+"""
+GROWTH_SRC = """
+template <class T> __device__ void dynamics(const T* x, const T* q, T u, const float* th, T* out) {
+  out[0] = x[0] / 2.0f + 25.0f * x[0] / (1.0f + x[0] * x[0]) + u + q[0];
+}
+"""
+
+
+class _forced_generic:
+    def __enter__(self):
+        from bayesianfiltering_amd import _lib
+        self.lib = _lib.load()
+        _lib.check(self.lib.bf_set_option(b"force_generic", 1))
+
+    def __exit__(self, *exc):
+        self.lib.bf_set_option(b"force_generic", 0)
+
+
+def _bits(t):
+    return np.ascontiguousarray(t.cpu().numpy(), F32).view(np.uint32)
+
+
+def test_lorenz63_source_twin_matches_registry_bit_for_bit():
+    import bayesianfiltering_amd as bfa
+    nl = bfa.nonlinearities
+    K, T = 3, 40
+    Q, R = 0.1 * np.eye(3, dtype=F32), 1.0 * np.eye(1, dtype=F32)
+    m0, P0 = np.array([0.0, 1.0, 1.05], F32), np.eye(3, dtype=F32)
+    th = [10.0, 28.0, 2.667, 0.01]
+    reg = bfa.ParamsNLSSM(m0, P0, nl.lorenz63(*th), np.zeros(3, F32), Q, nl.quadratic(3, 0.05), np.zeros(1, F32), R)
+    usr = bfa.ParamsNLSSM(m0, P0, nl.user_dynamics(L63_SRC, 3, theta=th), np.zeros(3, F32), Q, nl.quadratic(3, 0.05), np.zeros(1, F32), R)
+    po = go.ParamsNLSSM(m0, P0, om.Lorenz63(), np.zeros(3, F32), Q, om.Quadratic(3, 0.05), np.zeros(1, F32), R)
+    ys = np.stack([go.sample_ssm(po, otf.PRNGKey(b), T)[1] for b in range(2)])
+    im = (m0 + 0.5 * np.random.default_rng(0).normal(size=(2, K, 3))).astype(F32)
+    with _forced_generic():     # the registry function through the SAME (run-time-dimension) kernel, built ahead of time
+        a, la = bfa.gaussian_sum_filter(reg, ys, K, 1, initial_means=im, return_loglik=True)
+    b, lb = bfa.gaussian_sum_filter(usr, ys, K, 1, initial_means=im, return_loglik=True)
+    for k in FIELDS:
+        assert np.array_equal(_bits(getattr(a, k)), _bits(getattr(b, k))), k
+    assert np.array_equal(_bits(la), _bits(lb))
+    # ... and the register kernel (default path of the registry function) and the oracle to rounding
+    c = bfa.gaussian_sum_filter(reg, ys, K, 1, initial_means=im)
+    for bb in range(2):
+        ref = go.gaussian_sum_filter(po, ys[bb], K, initial_means=im[bb])
+        for k in FIELDS:
+            assert cm.rel_err(getattr(b, k)[bb].cpu().numpy(), getattr(ref, k)) < 2e-5, k
+            assert cm.rel_err(getattr(b, k)[bb].cpu().numpy(), getattr(c, k)[bb].cpu().numpy()) < 2e-5, k
+    # user dynamics AND user emission together
+    usr2 = usr._replace(emission_function=nl.user_emission(QUAD_SRC, 3, 1, theta=[0.05]))
+    d = bfa.gaussian_sum_filter(usr2, ys, K, 1, initial_means=im)
+    for k in FIELDS:
+        assert cm.rel_err(getattr(d, k).cpu().numpy(), getattr(b, k).cpu().numpy()) < 1e-6, k
+
+
+def test_growth_source_twin_matches_registry():
+    """f3 of docs/notebooks/Experiment_TSP_2023.ipynb cell 2 (x/2 + 25 x/(1 + x^2) + u + q): same VALUES bit for bit; the
+    dual-number derivative 1/2 + 25 (1 + x^2 - 2 x^2) / (1 + x^2)^2 and the hand-derived 25 (1 - x^2) / (1 + x^2)^2 differ
+    in form, so covariances agree to rounding."""
+    import bayesianfiltering_amd as bfa
+    nl = bfa.nonlinearities
+    T, K = 60, 4
+    Q, R = 1.0 * np.eye(1, dtype=F32), 1.0 * np.eye(1, dtype=F32)
+    h = nl.linear_emission(0.8 * np.eye(1, dtype=F32))
+    reg = bfa.ParamsNLSSM(np.zeros(1, F32), np.eye(1, dtype=F32), nl.growth(), np.zeros(1, F32), Q, h, np.zeros(1, F32), R)
+    usr = reg._replace(dynamics_function=nl.user_dynamics(GROWTH_SRC, 1))
+    u = (8.0 * np.cos(1.2 * np.arange(T))).astype(F32)
+    po = go.ParamsNLSSM(np.zeros(1, F32), np.eye(1, dtype=F32), om.Growth(), np.zeros(1, F32), Q, om.Linear(0.8 * np.eye(1, dtype=F32)),
+                        np.zeros(1, F32), R)
+    ys = go.sample_ssm(po, otf.PRNGKey(3), T, u.reshape(T, 1))[1]
+    im = np.linspace(-1, 1, K, dtype=F32).reshape(K, 1)
+    a = bfa.gaussian_sum_filter(reg, ys, K, 1, u, initial_means=im)
+    b = bfa.gaussian_sum_filter(usr, ys, K, 1, u, initial_means=im)
+    ref = go.gaussian_sum_filter(po, ys, K, inputs=u.reshape(T, 1), initial_means=im)
+    for k in FIELDS:
+        assert cm.rel_err(getattr(b, k).cpu().numpy(), getattr(a, k).cpu().numpy()) < 2e-5, k
+        assert cm.rel_err(getattr(b, k).cpu().numpy(), getattr(ref, k)) < 5e-5, k
+
+
+PENDULUM_DYN = """
+template <class T> __device__ void dynamics(const T* x, const T* q, T u, const float* th, T* out) {
+  const float dt = th[0], g = th[1];
+  out[0] = x[0] + dt * x[1] + q[0];
+  out[1] = x[1] - dt * g * sin(x[0]) + (1.0f + 0.5f * cos(x[0])) * q[1];      // noise enters through a state-dependent gain
+}
+"""
+PENDULUM_EMI = """
+template <class T> __device__ void emission(const T* x, const T* r, T u, const float* th, T* out) {
+  out[0] = sin(x[0]) + exp(th[0] * x[1]) * r[0];                                // multiplicative observation noise
+}
+"""
+
+
+class _PendulumDyn(om.Fn):
+    def __init__(self, dt, g):
+        self.dt, self.g = F32(dt), F32(g)
+        self.out_dim = self.noise_dim = 2
+
+    def value(self, x, w, u):
+        return np.array([x[0] + self.dt * x[1] + w[0],
+                         x[1] - self.dt * self.g * np.sin(x[0]) + (F32(1) + F32(0.5) * np.cos(x[0])) * w[1]], F32)
+
+    def jac_x(self, x, w, u):
+        return np.array([[1, self.dt], [-self.dt * self.g * np.cos(x[0]) - F32(0.5) * np.sin(x[0]) * w[1], 1]], F32)
+
+    def jac_noise(self, x, w, u):
+        return np.array([[1, 0], [0, F32(1) + F32(0.5) * np.cos(x[0])]], F32)
+
+
+class _PendulumEmi(om.Fn):
+    def __init__(self, c):
+        self.c = F32(c)
+        self.out_dim = self.noise_dim = 1
+
+    def value(self, x, w, u):
+        return np.array([np.sin(x[0]) + np.exp(self.c * x[1]) * w[0]], F32)
+
+    def jac_x(self, x, w, u):
+        return np.array([[np.cos(x[0]), self.c * np.exp(self.c * x[1]) * w[0]]], F32)
+
+    def jac_noise(self, x, w, u):
+        return np.array([[np.exp(self.c * x[1])]], F32)
+
+
+@pytest.mark.parametrize("K", [1, 5])
+def test_model_outside_the_registry_against_the_oracle(K):
+    """A pendulum with state-dependent process- and observation-noise gains and non-zero noise biases: F_x, F_q, H_x, H_r
+    all come from dual numbers and F_q Q F_q^T / H_r R H_r^T are formed on the device every step."""
+    import bayesianfiltering_amd as bfa
+    nl = bfa.nonlinearities
+    T, B = 50, 3
+    Q = np.array([[1e-3, 2e-4], [2e-4, 2e-2]], F32)
+    R = 5e-2 * np.eye(1, dtype=F32)
+    q0, r0 = np.array([0.0, 0.05], F32), np.array([0.1], F32)
+    m0, P0 = np.array([1.0, 0.0], F32), 0.1 * np.eye(2, dtype=F32)
+    fo, ho = _PendulumDyn(0.05, 9.81), _PendulumEmi(0.2)
+    po = go.ParamsNLSSM(m0, P0, fo, q0, Q, ho, r0, R)
+    pp = bfa.ParamsNLSSM(m0, P0, nl.user_dynamics(PENDULUM_DYN, 2, theta=[0.05, 9.81], host_fn=lambda x, q, u: fo.value(x, q, u)), q0, Q,
+                         nl.user_emission(PENDULUM_EMI, 2, 1, theta=[0.2], host_fn=lambda x, r, u: ho.value(x, r, u)), r0, R)
+    ys = np.stack([go.sample_ssm(po, otf.PRNGKey(10 + b), T)[1] for b in range(B)])
+    im = (m0 + 0.3 * np.random.default_rng(1).normal(size=(B, K, 2))).astype(F32)
+    post, ll = bfa.gaussian_sum_filter(pp, ys, K, 1, initial_means=im, return_loglik=True)
+    for b in range(B):
+        ref, rll = go.gaussian_sum_filter(po, ys[b], K, initial_means=im[b], return_ll=True)
+        for k in FIELDS[1:]:
+            assert cm.rel_err(getattr(post, k)[b].cpu().numpy(), getattr(ref, k)) < 2e-5, (b, k)
+        assert np.max(np.abs(post.weights[b].cpu().numpy() - ref.weights)) < 5e-5
+        assert cm.rel_err(ll[b].cpu().numpy(), rll) < 5e-5
+    # the host twin is callable like a reference lambda
+    assert np.allclose(pp.dynamics_function(m0, q0, 0.0), fo.value(m0, q0, np.zeros(1, F32)))
+
+
+def test_user_model_errors_and_cache():
+    import time
+    import bayesianfiltering_amd as bfa
+    from bayesianfiltering_amd import _lib
+    nl = bfa.nonlinearities
+    R = np.eye(1, dtype=F32)
+    base = bfa.ParamsNLSSM(np.zeros(1, F32), np.eye(1, dtype=F32), nl.growth(), np.zeros(1, F32), np.eye(1, dtype=F32),
+                           nl.linear_emission(np.eye(1, dtype=F32)), np.zeros(1, F32), R)
+    ys = np.zeros((4, 1), F32)
+    bad = "template <class T> __device__ void dynamics(const T* x, const T* q, T u, const float* th, T* out) { out[0] = nosuchfn(x[0]); }"
+    with pytest.raises(_lib.BayesFiltError) as e:
+        bfa.gaussian_sum_filter(base._replace(dynamics_function=nl.user_dynamics(bad, 1)), ys, 1, initial_means=np.zeros((1, 1), F32))
+    assert e.value.code == _lib.BF_EINVAL and "nosuchfn" in str(e.value)
+    with pytest.raises(TypeError):                                    # a Python callable still cannot run on the device
+        bfa.gaussian_sum_filter(base._replace(dynamics_function=lambda x, q, u: x), ys, 1)
+    f = nl.user_dynamics(GROWTH_SRC, 1)
+    bfa.gaussian_sum_filter(base._replace(dynamics_function=f), ys, 1, initial_means=np.zeros((1, 1), F32))
+    t0 = time.perf_counter()
+    for _ in range(20):                                               # compiled once: later calls find the module
+        bfa.gaussian_sum_filter(base._replace(dynamics_function=nl.user_dynamics(GROWTH_SRC, 1)), ys, 1, initial_means=np.zeros((1, 1), F32))
+    assert time.perf_counter() - t0 < 2.0
+    # the particle / unscented / augmented kernels take registry functions only
+    with pytest.raises(_lib.BayesFiltError):
+        bfa.unscented_gaussian_sum_filter(base._replace(dynamics_function=f), bfa.ParamsUKF(1, 0, 0), ys, 1, initial_means=np.zeros((1, 1), F32))
