@@ -863,7 +863,7 @@ kf_scan_mfma2_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
     Pacc = mfma2(lk == 0 ? scv[32 * ti + lr] : 0.f, lk == 0 ? scv[32 * tj + lr] : 0.f, Pacc);
     BF_UNROLL for (int r = 0; r < 16; ++r) sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = Pacc[r];
     if (out.P.p) BF_UNROLL for (int r = 0; r < 16; ++r)
-        out.P.p[b * out.P.sB + t * out.P.sT + ((32 * ti + c_row(r, lane)) * N + 32 * tj + lr) * out.P.sE] = Pacc[r];
+        __builtin_nontemporal_store(Pacc[r], &out.P.p[b * out.P.sB + t * out.P.sT + ((32 * ti + c_row(r, lane)) * N + 32 * tj + lr) * out.P.sE]);
     if (wave == 1 && out.m.p) out.m.p[b * out.m.sB + t * out.m.sT + lane * out.m.sE] = mnxt[lane];
     if (VAR == 3 && wave == 3 && lane == 0) *reinterpret_cast<int*>(sc2 + 32) = 0;  // progress counter re-armed (three barriers ahead of its next use)
     if (wave == 2 && lane == 0) {
@@ -894,7 +894,7 @@ kf_scan_mfma2_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
     BF_UNROLL for (int s = 0; s < 32; ++s) Pacc = mfma2(sT[(32 * ti + lr) * PP + 2 * s + lk], sA[(32 * tj + lr) * PP + 2 * s + lk], Pacc);
     BF_UNROLL for (int r = 0; r < 16; ++r) sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = Pacc[r];
     if (out.pP.p) BF_UNROLL for (int r = 0; r < 16; ++r)
-        out.pP.p[b * out.pP.sB + t * out.pP.sT + ((32 * ti + c_row(r, lane)) * N + 32 * tj + lr) * out.pP.sE] = Pacc[r];
+        __builtin_nontemporal_store(Pacc[r], &out.pP.p[b * out.pP.sB + t * out.pP.sT + ((32 * ti + c_row(r, lane)) * N + 32 * tj + lr) * out.pP.sE]);
     if (wave == 2 && out.pm.p) out.pm.p[b * out.pm.sB + t * out.pm.sT + lane * out.pm.sE] = mcur[lane];
     BF_TICK(8)
     lds_barrier();

@@ -110,7 +110,17 @@ struct Tile {
     constexpr int RPI = 64 / CH;
     BF_UNROLL for (int i = 0; i < ITER; ++i) {
       char* base_i = dst_wave + (size_t)i * (size_t)RPI * (size_t)sB * 4;  // uniform
-      if (chunk_limit >= CH || (lane % CH) < chunk_limit) *reinterpret_cast<float4*>(base_i + lane_byte_off) = v[i];
+      // streaming output that this kernel never reads back: non-temporal stores (global_store_dwordx4 ... nt).  Measured on
+      // the headline launch (107 GB per launch, same box, bench.py): 19.65 ms with plain stores, 18.77 ms with nt.
+      if (chunk_limit >= CH || (lane % CH) < chunk_limit) {
+        typedef float nt_v4f __attribute__((ext_vector_type(4)));
+        const nt_v4f q = {v[i].x, v[i].y, v[i].z, v[i].w};
+#ifdef BF_KF_PLAIN_STORES
+        *reinterpret_cast<nt_v4f*>(base_i + lane_byte_off) = q;
+#else
+        __builtin_nontemporal_store(q, reinterpret_cast<nt_v4f*>(base_i + lane_byte_off));
+#endif
+      }
     }
   }
 };
