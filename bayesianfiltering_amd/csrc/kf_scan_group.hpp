@@ -54,10 +54,12 @@ struct GroupCfg {
   static constexpr int CPL = (NS + NL - 1) / NL;  // columns per lane
   static constexpr int CPW = 64 / NL;             // trajectories per wave
   static constexpr int EP = NS * NS;
-  // floats per staged row: 128-byte rows for the matrix streams, 64-byte rows for the rest
-  // (and never fewer than 64 float4 chunks per wave tile, so a flush is whole store instructions)
+  // floats per staged row: 128-byte rows (or the next multiple of a step that is also a multiple of 16 bytes) for the
+  // matrix streams, and never fewer than 64 float4 chunks per wave tile where that keeps a flush whole store instructions
+  static constexpr int lcm4(int e) { return e % 4 == 0 ? e : (e % 2 == 0 ? 2 * e : 4 * e); }
+  static constexpr int row_floats(int e, int want) { return ((want + lcm4(e) - 1) / lcm4(e)) * lcm4(e); }
   static constexpr int WMIN = 4 * NL;
-  static constexpr int WP = (EP >= 32 ? EP : 32) > WMIN ? (EP >= 32 ? EP : 32) : WMIN;
+  static constexpr int WP = row_floats(EP, (EP >= 32 ? EP : 32) > WMIN ? (EP >= 32 ? EP : 32) : WMIN);
   // (BF_KF_ROW_FLOATS: 128-byte rows for the mean / weight streams too when the occupancy target leaves the LDS
   // for it -- NL >= 2 runs 8 waves per CU; a 64-byte run is half a cache line and costs ~15 % of the HBM
   // write rate in scripts/store_pattern_bench.hip)
@@ -65,7 +67,7 @@ struct GroupCfg {
 #define BF_KF_WSM 32
 #endif
   static constexpr int WSM = (NL >= 2 && NS <= 4) ? BF_KF_WSM : 16;
-  static constexpr int WM = (NS >= WSM ? NS : WSM) > WMIN ? (NS >= WSM ? NS : WSM) : WMIN;
+  static constexpr int WM = row_floats(NS, (NS >= WSM ? NS : WSM) > WMIN ? (NS >= WSM ? NS : WSM) : WMIN);
   static constexpr int WW = WSM > WMIN ? WSM : WMIN;
   using TP = Tile<EP, WP, CPW, 4>;
   using TM = Tile<NS, WM, CPW, 4>;
@@ -76,7 +78,10 @@ struct GroupCfg {
   static constexpr int YTILE = CPW * YW;          // floats per block tile (DMA writes it in lane order)
   static constexpr int YDMA = (YTILE + 63) / 64;  // LDS-DMA instructions per block
   static constexpr int YBUF = YDMA * 64;          // floats reserved per buffer
-  static constexpr bool STAGED_OK = (NS == NL * CPL) && TP::OK && TM::OK && TW::OK;
+  // n = NL * CPL: every lane owns real columns; otherwise (n = 3, 5, 6, 7 with power-of-two lane groups) the padding
+  // lanes skip their LDS writes
+  static constexpr bool FULL_COLS = (NS == NL * CPL);
+  static constexpr bool STAGED_OK = TP::GOK && TM::GOK && TW::GOK;
 };
 
 template <int NS, int M, int NL, int MODE, bool TV>
@@ -242,10 +247,12 @@ kf_scan_group_kernel(KFConst<NS, M> c, const float* __restrict__ gqg_t, const fl
     w = reweight_single(ll, w);
 
     if constexpr (MODE == EMIT_STAGED) {
-      if (out.m.p) BF_UNROLL for (int cc = 0; cc < CPL; ++cc) lds[oM + putM + int(t % TM::TS) * NS + cc] = mj[cc];
+      if (out.m.p) BF_UNROLL for (int cc = 0; cc < CPL; ++cc)
+          if (Cfg::FULL_COLS || col_ok[cc]) lds[oM + putM + int(t % TM::TS) * NS + cc] = mj[cc];
       if (out.P.p) {
         const int o = oP + putP + int(t % TP::TS) * EP;
-        BF_UNROLL for (int i = 0; i < NS; ++i) BF_UNROLL for (int cc = 0; cc < CPL; ++cc) lds[o + i * NS + cc] = Pc[cc][i];
+        BF_UNROLL for (int i = 0; i < NS; ++i) BF_UNROLL for (int cc = 0; cc < CPL; ++cc)
+            if (Cfg::FULL_COLS || col_ok[cc]) lds[o + i * NS + cc] = Pc[cc][i];
       }
       if (jl == 0) {
         if (wscalar) {  // T is not a multiple of 4: the rows of the scalar streams are not 16-byte aligned, they go out one by one
@@ -302,10 +309,12 @@ kf_scan_group_kernel(KFConst<NS, M> c, const float* __restrict__ gqg_t, const fl
     }
 
     if constexpr (MODE == EMIT_STAGED) {
-      if (out.pm.p) BF_UNROLL for (int cc = 0; cc < CPL; ++cc) lds[opM + putM + int(t % TM::TS) * NS + cc] = mj[cc];
+      if (out.pm.p) BF_UNROLL for (int cc = 0; cc < CPL; ++cc)
+          if (Cfg::FULL_COLS || col_ok[cc]) lds[opM + putM + int(t % TM::TS) * NS + cc] = mj[cc];
       if (out.pP.p) {
         const int o = opP + putP + int(t % TP::TS) * EP;
-        BF_UNROLL for (int i = 0; i < NS; ++i) BF_UNROLL for (int cc = 0; cc < CPL; ++cc) lds[o + i * NS + cc] = Pc[cc][i];
+        BF_UNROLL for (int i = 0; i < NS; ++i) BF_UNROLL for (int cc = 0; cc < CPL; ++cc)
+            if (Cfg::FULL_COLS || col_ok[cc]) lds[o + i * NS + cc] = Pc[cc][i];
       }
     } else if (chain_ok) {
       BF_UNROLL for (int cc = 0; cc < CPL; ++cc) if (col_ok[cc]) {
@@ -481,7 +490,7 @@ static inline int launch_nml(const bf_lgssm* p, const bf_cstream* y, long long B
   if (force_mode == EMIT_STAGED && staged_ok && !lds_ok)
     return set_error(BF_EINVAL, "staged emitter: the enabled streams need more than 160 KiB of LDS at %d lanes per trajectory", NL);
   if (force_mode == EMIT_STAGED && !staged_ok)
-    return set_error(BF_EINVAL, "staged emitter needs the contiguous reference layout, 16-byte aligned rows and n in {1,2,4,8}");
+    return set_error(BF_EINVAL, "staged emitter needs the contiguous reference layout and 16-byte aligned rows");
 
   // time-varying covariances: per-step G Q_t G^T / D R_t D^T tables on the device
   // (stream-ordered upload through the constant cache: no host synchronisation, found again by content on the next call)
@@ -531,6 +540,8 @@ static inline int launch_nml(const bf_lgssm* p, const bf_cstream* y, long long B
       lds_per_wave += nP * Cfg::TP::FLOATS + nM * Cfg::TM::FLOATS + nWs * Cfg::TW::FLOATS;
       vm_younger = (Cfg::YS / Cfg::TP::TS) * nP * Cfg::TP::ITER + (Cfg::YS / Cfg::TM::TS) * nM * Cfg::TM::ITER +
                    (Cfg::YS / Cfg::TW::TS) * nWs * Cfg::TW::ITER;
+      // (masked-tail tiles: no lower bound is claimed, the observation block is awaited with vmcnt(0))
+      if (!(Cfg::TP::POW2 && Cfg::TM::POW2 && Cfg::TW::POW2)) vm_younger = 0;
     } else {
       vm_younger = Cfg::YS * (nM * Cfg::CPL + nP * N * Cfg::CPL + nW);
     }

@@ -82,44 +82,69 @@ __device__ __forceinline__ void wait_vm(int n) {
 template <int E, int W, int CPW, int PAD>
 struct Tile {
   static constexpr int TS = W / E;
-  static constexpr int CH = W / 4;
+  static constexpr int CH = W / 4;                     // 16-byte chunks per row
   static constexpr int PITCH = W + PAD;
   static constexpr int FLOATS = CPW * PITCH;
-  static constexpr int ITER = (CPW * CH) / 64;  // dwordx4 store instructions per flush
-  static constexpr bool OK = (W % E == 0) && (W % 4 == 0) && (PAD % 4 == 0) && ((CH & (CH - 1)) == 0) &&
-                             (CPW * CH >= 64) && ((CPW * CH) % 64 == 0);
+  static constexpr int NCHUNK = CPW * CH;              // chunks per tile
+  static constexpr int ITER = (NCHUNK + 63) / 64;      // dwordx4 store instructions per flush
+  // POW2: chunks per row a power of two and whole store instructions per flush -- lane -> (row, chunk) by shifts and
+  // one precomputed lane offset (the layout of n in {1, 2, 4, 8}).  Otherwise (n = 3, 5, 6, 7: rows of 36, 100, 196 ...
+  // floats) the same tile with chunk q = lane + 64 i -> row q / CH, chunk q % CH (constant divisions) and a masked tail.
+  static constexpr bool POW2 = ((CH & (CH - 1)) == 0) && (NCHUNK >= 64) && (NCHUNK % 64 == 0);
+  static constexpr bool GOK = (W % E == 0) && (W % 4 == 0) && (PAD % 4 == 0);
+  static constexpr bool OK = GOK && POW2;
 
   // lane-dependent byte offset of this lane's first chunk relative to the wave's base (the host
   // guarantees that the rows of one wave span less than 4 GiB, so 32 bits are enough)
   static __device__ __forceinline__ unsigned lane_off(int lane, long long sB) {
-    return (unsigned)((lane / CH) * sB * 4 + (lane % CH) * 16);
+    if constexpr (POW2) return (unsigned)((lane / CH) * sB * 4 + (lane % CH) * 16);
+    else return 0u;
   }
 
   static __device__ __forceinline__ void read(const float* tile, int lane, float4* v) {
-    constexpr int RPI = 64 / CH;
-    const int c = lane % CH;
-    const int r0 = lane / CH;
-    BF_UNROLL for (int i = 0; i < ITER; ++i)
-        v[i] = *reinterpret_cast<const float4*>(tile + (r0 + i * RPI) * PITCH + c * 4);
+    if constexpr (POW2) {
+      constexpr int RPI = 64 / CH;
+      const int c = lane % CH;
+      const int r0 = lane / CH;
+      BF_UNROLL for (int i = 0; i < ITER; ++i)
+          v[i] = *reinterpret_cast<const float4*>(tile + (r0 + i * RPI) * PITCH + c * 4);
+    } else {
+      BF_UNROLL for (int i = 0; i < ITER; ++i) {
+        const int q = lane + 64 * i;
+        const int qq = q < NCHUNK ? q : NCHUNK - 1;   // the tail lanes re-read the last chunk (never stored)
+        const int r = qq / CH, c = qq - r * CH;
+        v[i] = *reinterpret_cast<const float4*>(tile + r * PITCH + c * 4);
+      }
+    }
   }
 
   // dst_wave (wave-uniform): address of element (first trajectory of the wave, first step of the
   // row, e = 0).  Only chunks below chunk_limit are written (CH for a complete row).
+  // Streaming output that this kernel never reads back: non-temporal stores (global_store_dwordx4 ... nt).  Measured on
+  // the headline launch (107 GB per launch, same box, bench.py): 19.65 ms with plain stores, 18.77 ms with nt.
+  static __device__ __forceinline__ void store16(char* p, const float4& v) {
+    typedef float nt_v4f __attribute__((ext_vector_type(4)));
+    const nt_v4f q = {v.x, v.y, v.z, v.w};
+#ifdef BF_KF_PLAIN_STORES
+    *reinterpret_cast<nt_v4f*>(p) = q;
+#else
+    __builtin_nontemporal_store(q, reinterpret_cast<nt_v4f*>(p));
+#endif
+  }
   static __device__ __forceinline__ void write(const float4* v, int lane, char* dst_wave, unsigned lane_byte_off,
                                                long long sB, int chunk_limit) {
-    constexpr int RPI = 64 / CH;
-    BF_UNROLL for (int i = 0; i < ITER; ++i) {
-      char* base_i = dst_wave + (size_t)i * (size_t)RPI * (size_t)sB * 4;  // uniform
-      // streaming output that this kernel never reads back: non-temporal stores (global_store_dwordx4 ... nt).  Measured on
-      // the headline launch (107 GB per launch, same box, bench.py): 19.65 ms with plain stores, 18.77 ms with nt.
-      if (chunk_limit >= CH || (lane % CH) < chunk_limit) {
-        typedef float nt_v4f __attribute__((ext_vector_type(4)));
-        const nt_v4f q = {v[i].x, v[i].y, v[i].z, v[i].w};
-#ifdef BF_KF_PLAIN_STORES
-        *reinterpret_cast<nt_v4f*>(base_i + lane_byte_off) = q;
-#else
-        __builtin_nontemporal_store(q, reinterpret_cast<nt_v4f*>(base_i + lane_byte_off));
-#endif
+    if constexpr (POW2) {
+      constexpr int RPI = 64 / CH;
+      BF_UNROLL for (int i = 0; i < ITER; ++i) {
+        char* base_i = dst_wave + (size_t)i * (size_t)RPI * (size_t)sB * 4;  // uniform
+        if (chunk_limit >= CH || (lane % CH) < chunk_limit) store16(base_i + lane_byte_off, v[i]);
+      }
+    } else {
+      BF_UNROLL for (int i = 0; i < ITER; ++i) {
+        const int q = lane + 64 * i;
+        const int r = q / CH, c = q - r * CH;
+        const unsigned off = (unsigned)(r * sB * 4 + c * 16);     // < 4 GiB: see lane_off
+        if (q < NCHUNK && c < chunk_limit) store16(dst_wave + off, v[i]);
       }
     }
   }

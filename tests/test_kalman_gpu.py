@@ -174,3 +174,36 @@ def test_staged_path_with_rows_of_the_scalar_streams_unaligned(T):
         assert cm.rel_err(getattr(post, k).cpu().numpy(), ref[k]) < 1e-5, k
     assert np.allclose(post.weights.cpu().numpy(), 1.0)
     assert cm.rel_err(ll.cpu().numpy(), ref["loglik"]) < 3e-5
+
+
+@pytest.mark.parametrize("n,m", [(3, 1), (3, 2), (5, 2), (6, 3), (7, 4), (7, 1)])
+@pytest.mark.parametrize("T", [40, 37])
+def test_staged_stores_for_non_power_of_two_state_dims(n, m, T):
+    """The LDS time-transpose emitter (128-byte-plus rows, dwordx4 stores) for n = 3, 5, 6, 7: rows of 36 / 100 / 36 / 196
+    floats (a whole number of steps that is also a multiple of 16 bytes), padding lanes masked.  Forced on
+    (kf_emit_mode = 2 fails loudly if the layout is not eligible), compared bit for bit with the strided emitter and to
+    1e-5 with the oracle; ragged batch (the tail of the batch goes through the strided kernel) and, for T = 37, rows that
+    are not complete at the end."""
+    import torch
+    import bayesianfiltering_amd as bfa
+    from bayesianfiltering_amd import _lib
+    a = cm.random_stable_lgssm(n, m, seed=10 * n + m, bias=True)
+    B = 150
+    ys = cm.simulate_batch(a, B, T, seed=n)
+    init = np.tile(a["m0"], (B, 1))
+    p = cm.product_params(a)
+    lib = _lib.load()
+    try:
+        if (T * n) % 4 == 0 and (T * n * n) % 4 == 0:
+            _lib.check(lib.bf_set_option(b"kf_emit_mode", 2))
+        staged, lls = bfa.kalman_filter(p, ys, initial_means=init, return_loglik=True)
+        _lib.check(lib.bf_set_option(b"kf_emit_mode", 0))
+        strided, llt = bfa.kalman_filter(p, ys, initial_means=init, return_loglik=True)
+    finally:
+        lib.bf_set_option(b"kf_emit_mode", -1)
+    for k in bfa.FULL5:
+        assert torch.equal(getattr(staged, k), getattr(strided, k)), k
+    assert torch.equal(lls, llt)
+    ref = cm.oracle_kalman_batch(a, ys, init)
+    for k in FIELDS:
+        assert cm.rel_err(getattr(staged, k).cpu().numpy(), ref[k]) < 1e-5, k
