@@ -109,6 +109,7 @@ SYMBOLS = {
     "bf_resample_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "bf_user_model_create": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "bf_user_model_destroy": (None, [C.c_void_p]),
+    "bf_allgather_summaries": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "bf_canon_eval_f32": (C.c_int, [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "bf_random_normal_f32": (C.c_int, [C.POINTER(C.c_uint32), C.c_int64, _FP]),
     "bf_random_split": (C.c_int, [C.POINTER(C.c_uint32), C.c_int64, C.POINTER(C.c_uint32)]),

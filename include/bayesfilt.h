@@ -329,6 +329,15 @@ int bf_random_normal_f32(const uint32_t key[2], int64_t count, float* host_out);
 /* jax.random.split(key, num) -> num keys (2 words each) in a HOST buffer. */
 int bf_random_split(const uint32_t key[2], int64_t num, uint32_t* host_out);
 
+/* ---- multi-GPU: the path's one exchange step --------------------------------
+ * Trajectories are independent: the batch axis is sharded contiguously over the ranks (one process per GPU), every
+ * rank calls the bf_* entry points above on its own shard with no traffic during the scan, and the per-trajectory
+ * posterior summaries are exchanged once: d_send (this rank's `bytes` bytes, DEVICE) -> d_recv (world_size * bytes,
+ * rank-major, DEVICE) with one ncclAllGather on `stream` over the caller's communicator (`nccl_comm` = ncclComm_t as
+ * void*; RCCL over xGMI).  RCCL is loaded on first use.  The Python layer does the same through torch.distributed
+ * (bayesianfiltering_amd/distributed.py: backend "nccl" is RCCL). */
+int bf_allgather_summaries(const void* d_send, void* d_recv, size_t bytes, void* nccl_comm, void* stream);
+
 /* Bytes one (trajectory, timestep) moves for the streams enabled in `out`: the algorithmic
  * traffic figure of SURVEY.md 8(d)  (4m + 4K(1 + 2n + 2n^2) for all five streams). */
 int64_t bf_bytes_per_step(int32_t n, int32_t m, int32_t K, const bf_out_desc* out);

@@ -5,7 +5,7 @@
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/prof_r02
 mkdir -p $out
-what="${*:-headline others bpfpmc probes}"
+what="${*:-headline others bpfpmc mfmapmc probes}"
 cd /tmp && export TMPDIR=/tmp
 
 stats() {  # stats <dir> <dest csv>: the six heaviest kernels of a kernel-trace run
@@ -79,6 +79,25 @@ json.dump(s, open("$out/pmc_bpf4096.json", "w"), indent=1)
 print("VALU instructions per particle-step:", s["valu_wave_inst_per_particle_step_x64"])
 for k in ("SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"):
     if k in s["pmc"]: print(k, s["pmc"][k]["mean_per_dispatch"])
+PY
+fi
+
+if [[ $what == *mfmapmc* ]]; then
+  echo "== MFMA Kalman kernel SQ counters (configs[4] instance, B=4096, T=50, no output streams / FULL5)"
+  export PB=4096 PT=50
+  $root/scripts/pmc_any.sh mfma_r02 kf_scan_mfma scripts/mfma_probe.py > $out/mfma_pmc.log 2>&1
+  python3 - <<PY
+import json
+s = json.load(open("$root/gpurun_out/pmc_mfma_r02/summary.json"))
+p = s["pmc"]
+# SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+if "SQ_VALU_MFMA_BUSY_CYCLES" in p and "GRBM_GUI_ACTIVE" in p:
+    s["mfma_busy_frac_of_simd_cycles"] = p["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_dispatch"] / (1024.0 * p["GRBM_GUI_ACTIVE"]["mean_per_dispatch"] / 8.0)
+s["note"] = "mean over the dispatches of scripts/mfma_probe.py (FULL5, FILTERED and no-stream launches of B=4096, T=50)"
+json.dump(s, open("$out/pmc_kalman64.json", "w"), indent=1)
+print("MFMA busy fraction of SIMD-cycles:", s.get("mfma_busy_frac_of_simd_cycles"))
+for k in ("SQ_INSTS_MFMA", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VALU"):
+    if k in p: print(k, p[k]["mean_per_dispatch"])
 PY
 fi
 

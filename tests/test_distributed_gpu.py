@@ -78,3 +78,35 @@ def test_filter_sharded_single_rank_is_the_plain_call():
     post, gathered = bd.filter_sharded(lambda y: bfa.kalman_filter(p, y), ys, summary=lambda r: r.means[:, 0, -1])
     plain = bfa.kalman_filter(p, ys)
     assert torch.equal(gathered, plain.means[:, 0, -1]) and torch.equal(post.covariances, plain.covariances)
+
+
+def test_c_abi_allgather_over_an_rccl_communicator():
+    """bf_allgather_summaries on a communicator this test creates itself with ncclCommInitAll over the one
+    visible GPU -- world size 1, so the gather is a device copy, but the call goes through RCCL's ncclAllGather on the
+    caller's stream exactly as it does on eight ranks."""
+    import ctypes as C
+    import torch
+    from bayesianfiltering_amd import _lib
+    lib = _lib.require_gpu()
+    rccl = None
+    for cand in (os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so", "/opt/rocm/lib/librccl.so"):
+        try:
+            rccl = C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    assert rccl is not None
+    comm = C.c_void_p()
+    dev = (C.c_int * 1)(0)
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, dev) == 0
+    try:
+        send = torch.arange(1000, dtype=torch.float32, device="cuda") * 0.5
+        recv = torch.zeros_like(send)
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.bf_allgather_summaries(C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), send.numel() * 4, comm,
+                                              C.c_void_p(stream)))
+        torch.cuda.synchronize()
+        assert torch.equal(send, recv)
+        assert lib.bf_allgather_summaries(None, C.c_void_p(recv.data_ptr()), 4, comm, None) == _lib.BF_EINVAL
+    finally:
+        rccl.ncclCommDestroy(comm)
