@@ -52,7 +52,7 @@ fi
 
 if [[ $what == *others* ]]; then
   : > $out/other_configs.jsonl
-  for c in "gsf32" "gsf32 --mode collapsed" "kalman64" "bpf4096"; do
+  for c in "gsf32" "gsf32 --l96-mode as_written" "gsf32 --mode collapsed" "kalman64" "bpf4096"; do
     tag=$(echo $c | tr -d ' -' )
     echo "== $c"
     rocprofv3 --kernel-trace --stats --output-format csv -d $out/t_$tag -- python3 $root/bench.py --config $c --steps 3 --warmup 1 > $out/$tag.log 2>&1
