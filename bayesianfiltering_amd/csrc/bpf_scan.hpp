@@ -365,9 +365,12 @@ static inline int launch_bpf_dims(const bf_bpf_model* bp, const bf_cstream* y, c
   else if (NP <= 256) rc = launch_bpf_cfg<N, DQ, M, 1, 4>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
   else if (NP <= 1024) rc = launch_bpf_cfg<N, DQ, M, 1, 16>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
   else if (NP <= 4096) {
-    // two geometries for the largest capacity: 1024 threads x 4 particles (128-VGPR budget) or
-    // 512 threads x 8 particles (256-VGPR budget); variant 0 = 1024 x 4 is the default
-    // (measured at cfg4's shape: 1024 x 4 = 28.0 ms per 50 steps, 512 x 8 = 33.8 ms)
+    // two geometries for the largest capacity: 1024 threads x 4 particles (128-VGPR budget, variant 0) or
+    // 512 threads x 8 particles (256-VGPR budget, variant 1, the default).  With the canonical arithmetic of
+    // bf_canon_math.hpp (explicit log / exp / IEEE sqrt instead of single hardware instructions) the 128-VGPR geometry
+    // spills (465 VGPRs to scratch): measured at cfg4's shape, B = 1024, T = 200: 1024 x 4 = 97 ms, 512 x 8 = 88 ms
+    // (round 1, hardware transcendentals: 1024 x 4 was the faster one).  Out-of-line erf_inv and opaque model pointers
+    // cut the spills but lose more in calls and reloads (105 / 125 ms).
     if (g_bpf_variant == 1) rc = launch_bpf_cfg<N, DQ, M, 8, 8>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
     else rc = launch_bpf_cfg<N, DQ, M, 4, 16>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
   }

@@ -18,6 +18,7 @@
 // left-looking Cholesky, row per lane.  With K > 1 the components take turns in the LDS tile (their carried means /
 // covariances live in an HBM scratch that stays L2-resident) and the weight update runs once per step over all K in the
 // oracle's adjacent-pair tree order.  NT = 64 threads (one wave: the barriers are free) for n <= 16, 256 above.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "bf_common.hpp"
@@ -184,6 +185,16 @@ static int gen_fill(const bf_model* p, long long T, GenModel& g, std::vector<flo
   return BF_OK;
 }
 
+// one wave per workgroup (its barriers are free) up to this state / observation dimension, four waves above
+static int gen_nt64_max() {
+  static const int v = [] {
+    const char* e = std::getenv("BAYESFILT_GENERIC_NT64_MAX");
+    const int x = e ? std::atoi(e) : 32;
+    return x > 0 ? x : 32;
+  }();
+  return v;
+}
+
 int launch_user_kernel(const bf_user_model* um, int nt, unsigned grid, size_t lds_bytes, hipStream_t stream, void** args);
 
 int launch_gsf_generic(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int K,
@@ -242,12 +253,12 @@ int launch_gsf_generic(const bf_model* p, const bf_cstream* y, const bf_cstream*
   if (p->user) {  // the run-time build of the same kernel with the caller's functions compiled in (user_model.hip)
     int kp = KP;
     void* args[] = {&g, &yv, &uv, &cv, &ov, &gm, &gP, &B, &T, &K, &kp};
-    const int nt = (p->n <= 16 && p->m <= 16) ? 64 : 256;
+    const int nt = (p->n <= gen_nt64_max() && p->m <= gen_nt64_max()) ? 64 : 256;
     rc = launch_user_kernel(p->user, nt, (unsigned)B, lds_bytes, stream, args);
     if (scratch) (void)hipFreeAsync(scratch, stream);
     return rc;
   }
-  if (p->n <= 16 && p->m <= 16) {
+  if (p->n <= gen_nt64_max() && p->m <= gen_nt64_max()) {
     auto kern = gsf_generic_kernel<64>;
     if (lds_bytes > 64 * 1024) BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds_bytes, stream, g, yv, uv, cv, ov, gm, gP, B, T, K, KP);
