@@ -35,12 +35,12 @@
 
 namespace bf {
 
-static int mfma_variant_default() {  // BAYESFILT_MFMA_VARIANT=1|2|3 overrides the default for A/B runs of unmodified programs
+static int mfma_variant_default() {  // BAYESFILT_MFMA_VARIANT=1..4 overrides the default for A/B runs of unmodified programs
   const char* e = std::getenv("BAYESFILT_MFMA_VARIANT");
   const int v = e ? std::atoi(e) : 2;
-  return (v >= 1 && v <= 3) ? v : 2;
+  return (v >= 1 && v <= 4) ? v : 2;
 }
-std::atomic<int> g_kf_mfma_variant{mfma_variant_default()};  // bf_set_option "kf_mfma_variant": 3 = gain-free update, factorization by rank-1 MFMAs (default); 2 = gain-free, factorization in VALU registers; 1 = round 1's kernel
+std::atomic<int> g_kf_mfma_variant{mfma_variant_default()};  // bf_set_option "kf_mfma_variant": 2 = gain-free update, factorization in VALU registers (default); 3 = factorization by rank-2 MFMAs; 4 = variant 2 at three workgroups per CU (A in registers); 1 = round 1's kernel
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using lds_f = __attribute__((address_space(3))) float;
@@ -473,12 +473,19 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
 
 // =======================================================================================================================
 // Measured on one MI355X, BASELINE configs[4] (B = 32 768, T = 2 000, all five streams in T-chunks of 100; bench.py
-// --config kalman64), same box, steps/s:   variant 1 (round 1) 3.28e7 | variant 2 3.54e7 | variant 3 3.07e7;
-// without output streams (B = 4 096, T = 100):           3.16e7 |           3.36e7 |           3.61e7.
-// Variant 3 has the shortest serial phase (3.7 us against 5.4 us per step, one workgroup per CU, scripts/mfma_phase_probe.py)
-// but its three elimination loops are inlined into the kernel body (out of line they cost more: accumulators cross the
-// call in registers both ways) and the 256-VGPR body then spills inside the phases that stream the outputs; variant 2
-// keeps its serial phase in two out-of-line functions with register allocations of their own and is the default.
+// --config kalman64), same box, steps/s:   variant 1 (round 1) 3.28e7 | variant 2 3.73e7 | variant 3 3.69e7 | variant 4 3.1e7.
+// What moved variants 2 and 3 from 3.54e7 / 3.07e7 (first cut of this round) to these numbers:
+//   * no loop-invariant operand lives in registers across steps (per_step() below): the compiler had hoisted the sixteen
+//     64-bit store addresses of each output stream and the loads of G Q G^T out of the time loop and spilled them
+//     (62 / 87 VGPRs spilled -> 0 / 0);
+//   * the serial phase's elimination steps are packed (v_pk_fma_f32 on (row entry, right-hand-side entry) pairs):
+//     2 295 -> 1 668 vector instructions in chol_w_rows, which is issue bound (4 cycles per wave64 instruction);
+//   * roles placed by the hardware's wave placement rather than by blockIdx (+1 %, see the kernel).
+// Phase timers (scripts/mfma_phase_probe.py, us per step): alone on its CU a workgroup takes 9.9 (A 1.3, S 1.1,
+// factorization + W 3.6, H 1.0, I 1.5, J 1.3); with a second workgroup on the CU 14.1 per workgroup, i.e. 7.0 per step and
+// CU: the factorization stretches to 6.3 beside the other workgroup's phases although neither the vector nor the matrix
+// pipe is more than half busy on average.  A third workgroup per CU (variant 4: A and D R D^T read from L2 per step
+// to fit the LDS, 168 VGPRs) is slower, 7.5 us per step and CU: its global operand loads sit on the critical path.
 //
 // Variant 2 (default): the gain is never formed.  With L L^T = S + 1e-6 (every entry: the psd_solve jitter J = 1e-6 1 1^T),
 // W = L^-1 (H P), g = L^-1 1 and z = L^-1 v:
@@ -503,30 +510,28 @@ __device__ __forceinline__ float rdlane_u(float v, int l) {  // v_readlane_b32: 
 }
 
 // wave 3: S (acc layout in `sc`, [32][33]) -> rows; chol(S + 1e-6); W = L^-1 (H P) -> sT rows 32..63; c, m+
+// The function is VALU-issue bound (a wave64 instruction occupies the SIMD for 4 cycles; ~2 300 of them were the 3.8 us of
+// this phase), so entry k of the lane's row of S and entry k of its column of H P travel as ONE register pair and every
+// elimination step is one v_pk_fma_f32 on (a[k], w[k]) with the broadcast multiplier as its scalar operand -- the same
+// fmas in the same order as the unpacked form, half the instructions.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __attribute__((noinline)) void chol_w_rows(lds_f* sc, lds_f* sT, lds_f* sv, lds_f* mcur, lds_f* mnxt, lds_f* scv,
                                                       int lane) {
   constexpr int PP = 65, PS = 33;
   const int r = lane & 31;
-  float a[32], w[32];
-  BF_UNROLL for (int k = 0; k < 32; ++k) a[k] = sc[r * PS + k] + 1e-6f;  // psd_solve's jitter on every entry (utils.py:258)
-  BF_UNROLL for (int i = 0; i < 32; ++i) w[i] = sT[i * PP + lane];       // column `lane` of H P
-  float rg = 1.0f, rz = sv[r];                                           // residuals of g = L^-1 1, z = L^-1 v (row r)
-  float acc_c = 0.f, acc_m = 0.f;
+  f32x2 aw[32];  // .x: row r of S + 1e-6 (psd_solve's jitter on every entry, utils.py:258); .y: column `lane` of H P
+  BF_UNROLL for (int k = 0; k < 32; ++k) aw[k] = f32x2{sc[r * PS + k] + 1e-6f, sT[k * PP + lane]};
+  f32x2 rgz = f32x2{1.0f, sv[r]};  // residuals of g = L^-1 1, z = L^-1 v (row r)
+  f32x2 acc_cm = f32x2{0.f, 0.f};  // (W^T g)[lane], (W^T z)[lane]
   static_for<0, 32>([&](auto J) {
     constexpr int j = decltype(J)::value;
-    const float rinv = rsqrt_newton(rdlane_u(a[j], j));   // 1 / L[j][j], wave-uniform
-    const float lj = a[j] * rinv;                         // L[r][j] (meaningful for r >= j)
-    const float wj = w[j] * rinv;                         // W[j][lane], final
-    const float gj = rdlane_u(rg, j) * rinv;              // g[j], z[j]: wave-uniform
-    const float zj = rdlane_u(rz, j) * rinv;
-    a[j] = lj;
-    w[j] = wj;
-    rg = fmaf(-lj, gj, rg);
-    rz = fmaf(-lj, zj, rz);
-    acc_c = fmaf(wj, gj, acc_c);                          // (W^T g)[lane], (W^T z)[lane]
-    acc_m = fmaf(wj, zj, acc_m);
-    const float t = lj * rinv;                            // a[r][j] / d_j
-    const float q = wj * rinv;
+    const float rinv = rsqrt_newton(rdlane_u(aw[j].x, j));            // 1 / L[j][j], wave-uniform
+    const f32x2 lw = aw[j] * rinv;                                     // L[r][j] (meaningful for r >= j), W[j][lane] (final)
+    const f32x2 gz = f32x2{rdlane_u(rgz.x, j), rdlane_u(rgz.y, j)} * rinv;  // g[j], z[j]: wave-uniform
+    aw[j] = lw;
+    rgz = __builtin_elementwise_fma(f32x2{-lw.x, -lw.x}, gz, rgz);
+    acc_cm = __builtin_elementwise_fma(f32x2{lw.y, lw.y}, gz, acc_cm);
+    const f32x2 ntq = -(lw * rinv);                                    // -a[r][j] / d_j, -w[j] / d_j
     // L[k][j] sqrt(d_j) = a[k][j] = a[j][k] by symmetry: lane j's own entries, read BEFORE this step updates them.
     // The broadcasts go out in batches of BF_MFMA_RDB ahead of the multiply-adds that consume them: a v_readlane's
     // scalar result takes several issue slots to become readable, and back-to-back (readlane, fma) pairs stall on it.
@@ -534,44 +539,54 @@ __device__ __attribute__((noinline)) void chol_w_rows(lds_f* sc, lds_f* sT, lds_
       constexpr int k0 = j + 1 + decltype(Cb)::value * BF_MFMA_RDB;
       constexpr int nk = (32 - k0) < BF_MFMA_RDB ? (32 - k0) : BF_MFMA_RDB;
       float sb[BF_MFMA_RDB];
-      static_for<0, nk>([&](auto I) { sb[decltype(I)::value] = rdlane_u(a[k0 + decltype(I)::value], j); });
+      static_for<0, nk>([&](auto I) { sb[decltype(I)::value] = rdlane_u(aw[k0 + decltype(I)::value].x, j); });
       __builtin_amdgcn_sched_barrier(0);
       static_for<0, nk>([&](auto I) {
         constexpr int k = k0 + decltype(I)::value;
-        a[k] = fmaf(-t, sb[decltype(I)::value], a[k]);
-        w[k] = fmaf(-q, sb[decltype(I)::value], w[k]);
+        aw[k] = __builtin_elementwise_fma(ntq, f32x2{sb[decltype(I)::value], sb[decltype(I)::value]}, aw[k]);
       });
       __builtin_amdgcn_sched_barrier(0);
     });
   });
-  BF_UNROLL for (int i = 0; i < 32; ++i) sT[(32 + i) * PP + lane] = w[i];
-  scv[lane] = acc_c * 1e-3f;                               // sqrt(1e-6) (W^T g): enters P+ as + c c^T
-  mnxt[lane] = mcur[lane] + acc_m;                         // filtered mean
+  BF_UNROLL for (int i = 0; i < 32; ++i) sT[(32 + i) * PP + lane] = aw[i].y;
+  scv[lane] = acc_cm.x * 1e-3f;                            // sqrt(1e-6) (W^T g): enters P+ as + c c^T
+  mnxt[lane] = mcur[lane] + acc_cm.y;                      // filtered mean
 }
 
 // wave 2: chol(S) (no jitter), z = L^-1 v, log N(v; 0, S) -- inference.py:104, :24
+// Packed like chol_w_rows, here two neighbouring entries of the row per register pair and two broadcasts per scalar pair.
 __device__ __attribute__((noinline)) float chol_loglik_rows(lds_f* sc, lds_f* sv, int lane) {
   constexpr int PS = 33;
   const int r = lane & 31;
-  float a[32];
-  BF_UNROLL for (int k = 0; k < 32; ++k) a[k] = sc[r * PS + k];
+  f32x2 ap[16];  // (a[2 i], a[2 i + 1]) of row r
+  BF_UNROLL for (int i = 0; i < 16; ++i) ap[i] = f32x2{sc[r * PS + 2 * i], sc[r * PS + 2 * i + 1]};
   float rz = sv[r], quad = 0.f, rprod = 1.f;
   static_for<0, 32>([&](auto J) {
     constexpr int j = decltype(J)::value;
-    const float rinv = rsqrt_newton(rdlane_u(a[j], j));
-    const float lj = a[j] * rinv;
+    const float ajj = (j & 1) ? ap[j / 2].y : ap[j / 2].x;
+    const float rinv = rsqrt_newton(rdlane_u(ajj, j));
+    const float lj = ajj * rinv;
     const float zj = rdlane_u(rz, j) * rinv;
     rz = fmaf(-lj, zj, rz);
     quad = fmaf(zj, zj, quad);
     rprod *= rinv;
-    const float t = lj * rinv;
-    static_for<0, (31 - j + BF_MFMA_RDB - 1) / BF_MFMA_RDB>([&](auto Cb) {
-      constexpr int k0 = j + 1 + decltype(Cb)::value * BF_MFMA_RDB;
-      constexpr int nk = (32 - k0) < BF_MFMA_RDB ? (32 - k0) : BF_MFMA_RDB;
-      float sb[BF_MFMA_RDB];
-      static_for<0, nk>([&](auto I) { sb[decltype(I)::value] = rdlane_u(a[k0 + decltype(I)::value], j); });
+    const float nt = -(lj * rinv);
+    // pairs i >= (j + 1) / 2; for even j the first pair is (a[j], a[j + 1]) and its .x -- the finished column entry,
+    // never read again -- is updated along with the live .y
+    constexpr int i_first = (j + 1) / 2;
+    static_for<0, (16 - i_first + BF_MFMA_RDB / 2 - 1) / (BF_MFMA_RDB / 2)>([&](auto Cb) {
+      constexpr int i0 = i_first + decltype(Cb)::value * (BF_MFMA_RDB / 2);
+      constexpr int ni = (16 - i0) < BF_MFMA_RDB / 2 ? (16 - i0) : BF_MFMA_RDB / 2;
+      f32x2 sb[BF_MFMA_RDB / 2];
+      static_for<0, ni>([&](auto I) {
+        constexpr int i = i0 + decltype(I)::value;
+        sb[decltype(I)::value] = f32x2{rdlane_u(ap[i].x, j), rdlane_u(ap[i].y, j)};
+      });
       __builtin_amdgcn_sched_barrier(0);
-      static_for<0, nk>([&](auto I) { a[k0 + decltype(I)::value] = fmaf(-t, sb[decltype(I)::value], a[k0 + decltype(I)::value]); });
+      static_for<0, ni>([&](auto I) {
+        constexpr int i = i0 + decltype(I)::value;
+        ap[i] = __builtin_elementwise_fma(f32x2{nt, nt}, sb[decltype(I)::value], ap[i]);
+      });
       __builtin_amdgcn_sched_barrier(0);
     });
   });
@@ -768,14 +783,59 @@ __device__ __forceinline__ void eliminate_rhs(f32x16& acc, int c, lds_f* sL, lds
   }
 }
 
+// Loop-invariant operands are NOT to be kept in registers across steps: the compiler hoists the 16 + 16 + 32 loads of
+// G Q G^T, D R D^T and A and the sixteen 64-bit store addresses of every output stream out of the time loop, and then
+// spills them (106 scratch stores ahead of the loop, ~90 reloads per step at three workgroups per CU).  A wave-uniform
+// base laundered through an empty asm once per step keeps each access a (scalar base + lane offset + immediate) form.
+typedef __attribute__((address_space(1))) float gl_f;              // global memory: the laundered pointer must not decay to a flat one
+typedef const __attribute__((address_space(1))) float gl_cf;
+__device__ __forceinline__ int opaque_szero() {  // the scalar-register sibling of opaque_zero(): addresses stay wave-uniform
+  int z = 0;
+  asm volatile("" : "+s"(z));
+  return z;
+}
+__device__ __forceinline__ gl_f* per_step(float* p) { return (gl_f*)p + opaque_szero(); }
+__device__ __forceinline__ gl_cf* per_step(const float* p) { return (gl_cf*)p + opaque_szero(); }
+// one 32x32 accumulator tile (pi, pj) of a [N][N] stream entry at (b, t)
+template <int N>
+__device__ __forceinline__ void store_tile(const SView& sv, long long b, long long t, int pi, int pj, int lane, const f32x16& acc) {
+  if (!sv.p) return;
+  const int lr = lane & 31, lk = lane >> 5;
+  gl_f* base = per_step(sv.p + b * sv.sB + t * sv.sT);
+  const unsigned e0 = (unsigned)((32 * pi + 4 * lk) * N + 32 * pj + lr);
+  if (sv.sE == 1) {
+    BF_UNROLL for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(acc[r], base + (e0 + ((r & 3) + 8 * (r >> 2)) * N));
+  } else {
+    const long long sE = sv.sE + (long long)opaque_szero();  // the sixteen 64-bit products below are per-step work too, not pre-loop registers
+    const unsigned e0s = e0 + (unsigned)opaque_zero();
+    BF_UNROLL for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(acc[r], base + (long long)(e0s + ((r & 3) + 8 * (r >> 2)) * N) * sE);
+  }
+}
+
 template <int N, int M, int VAR>
-__global__ void __launch_bounds__(256, 2)
-kf_scan_mfma2_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView carry, OutViews out, long long B, long long T) {
+__global__ void __launch_bounds__(256, VAR == 4 ? 3 : 2)
+kf_scan_mfma2_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView carry, OutViews out, long long B, long long T,
+                     int rot_mode) {
   static_assert(N == 64 && M == 32, "tile assignment is written for n = 64, m = 32");
   constexpr int PP = N + 1, PS = M + 1;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(((tid >> 6) + (int)blockIdx.x) & 3);  // rotated roles (see variant 1)
+  // Which wave plays which role.  The two factorizing roles (2, 3) are VALU-issue bound -- one wave64 instruction per 4
+  // cycles of their SIMD -- so they want the other workgroup's MFMA-only roles (0, 1) as SIMD partners, not its
+  // factorizations.  Placement as measured (scripts/probes/hwid_probe.hip): the waves of a workgroup go round the SIMDs
+  // in the order 0, 2, 1, 3 from wave 0's SIMD k, the second workgroup of a CU (b + 256, wave slot 1) starts one SIMD
+  // further on, and blockIdx-rotated roles give both the same rotation: A's factorization of S + 1e-6 then shares a SIMD
+  // with B's factorization of S.  Taking the rotation from where the hardware put wave 0 (HW_ID: SIMD, wave slot s) puts
+  // role r at position (r + 2 s) & 3 of that order: the heavy roles of the two workgroups sit on disjoint SIMD pairs.
+  // Any rotation is a valid assignment of roles; only the speed depends on it.
+  __shared__ int s_rot;
+  if (tid == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID: wave slot [3:0], SIMD [5:4]
+    const unsigned k = (hw >> 4) & 3, pos = ((k & 1) << 1) | (k >> 1);
+    s_rot = rot_mode == 0 ? (int)blockIdx.x : (int)(pos + 2 * (hw & 15));
+  }
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(((tid >> 6) + s_rot) & 3);
   const int ti = wave >> 1, tj = wave & 1;
   const int lr = lane & 31, lk = lane >> 5;
   const long long b = blockIdx.x;
@@ -783,19 +843,24 @@ kf_scan_mfma2_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* sP = lds;                 // [64][65]  current covariance
   float* sT = sP + N * PP;         // [64][65]  rows 0..31: H P; rows 32..63: W; then A P+
-  float* sA = sT + N * PP;         // [64][65]  A
-  float* sH = sA + N * PP;         // [32][65]  H
-  float* sD = sH + M * PP;         // [32][33]  D R D^T
-  float* sc2 = sD + M * PS;        // [32][33]  S as wave 2 sees it (layout change through LDS)
+  // Variant 4 (three workgroups per CU): A is read from the constant block into 32 registers per wave and step (its MFMA
+  // operand for BOTH products, see phase J), D R D^T likewise, which brings the workgroup under a third of the CU's LDS.
+  constexpr bool AREG = VAR == 4;
+  float* sA = sT + N * PP;                     // [64][65]  A   (not in variant 4)
+  float* sH = sA + (AREG ? 0 : N * PP);        // [32][65]  H
+  float* sD = sH + M * PP;                     // [32][33]  D R D^T   (not in variant 4)
+  float* sc2 = sD + (AREG ? 0 : M * PS);       // [32][33]  S as wave 2 sees it (layout change through LDS)
   float* sc3 = sc2 + M * PS;       // [32][33]  S as wave 3 sees it
   float* sm = sc3 + M * PS;        // [64] mean
   float* sm2 = sm + N;             // [64] mean (ping-pong)
   float* sv = sm2 + N;             // [32] innovation
   float* scv = sv + M;             // [64] 1e-3 W^T g
 
-  for (int e = tid; e < N * N; e += 256) sA[(e / N) * PP + (e % N)] = cst->A[e];
+  if constexpr (!AREG) {
+    for (int e = tid; e < N * N; e += 256) sA[(e / N) * PP + (e % N)] = cst->A[e];
+    for (int e = tid; e < M * M; e += 256) sD[(e / M) * PS + (e % M)] = cst->DRD[e];
+  }
   for (int e = tid; e < M * N; e += 256) sH[(e / N) * PP + (e % N)] = cst->H[e];
-  for (int e = tid; e < M * M; e += 256) sD[(e / M) * PS + (e % M)] = cst->DRD[e];
   BF_UNROLL for (int r = 0; r < 16; ++r)
     sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = carry.P_in[b * N * N + (32 * ti + c_row(r, lane)) * N + 32 * tj + lr];
   if (tid < N) sm[tid] = carry.m_in[b * N + tid];
@@ -805,7 +870,7 @@ kf_scan_mfma2_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
   __syncthreads();
 
 #ifdef BF_MFMA_PHASE_TIMERS
-  long long tacc[10] = {0};
+  long long tacc[12] = {0};
   long long tprev = wall_clock64();
 #endif
   float* mcur = sm;
@@ -832,12 +897,18 @@ kf_scan_mfma2_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
     float ll = 0.f;
     if (wave >= 2) {
       f32x16 acc;
-      BF_UNROLL for (int r = 0; r < 16; ++r) acc[r] = sD[c_row(r, lane) * PS + lr];
+      if constexpr (AREG) {
+        gl_cf* drd = per_step(cst->DRD);
+        BF_UNROLL for (int r = 0; r < 16; ++r) acc[r] = drd[c_row(r, lane) * M + lr];
+      } else {
+        BF_UNROLL for (int r = 0; r < 16; ++r) acc[r] = sD[c_row(r, lane) * PS + lr];
+      }
       BF_UNROLL for (int s = 0; s < 32; ++s) acc = mfma2(sT[lr * PP + 2 * s + lk], sH[lr * PP + 2 * s + lk], acc);
-      if constexpr (VAR == 2) {
+      if constexpr (VAR == 2 || VAR == 4) {
         float* sc = wave == 2 ? sc2 : sc3;
         BF_UNROLL for (int r = 0; r < 16; ++r) sc[c_row(r, lane) * PS + lr] = acc[r];
         wave_lds_order();
+        BF_TICK(10)
         if (wave == 3) chol_w_rows((lds_f*)sc3, (lds_f*)sT, (lds_f*)sv, (lds_f*)mcur, (lds_f*)mnxt, (lds_f*)scv, lane);
         else ll = chol_loglik_rows((lds_f*)sc2, (lds_f*)sv, lane);
       } else {
@@ -857,13 +928,19 @@ kf_scan_mfma2_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
     BF_TICK(3)
     // ================= phase H: P+ = P - W^T W + c c^T (all waves; K = 32 + 2); emit filtered streams
     f32x16 Pacc;
+    // variant 4: A[32 ti + lr][2 s + lk], the wave's operand of A in phases I and J, fetched (L2-resident, 16 KB shared by
+    // every workgroup) a phase ahead of its use and dropped before the factorization: nothing long-lived in registers
+    float aop[AREG ? 32 : 1];
+    if constexpr (AREG) {
+      gl_cf* arow = per_step(cst->A) + ((32 * ti + lr) * N + lk);
+      BF_UNROLL for (int q = 0; q < 32; ++q) aop[q] = arow[2 * q];
+    }
     BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] = sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr];
     BF_UNROLL for (int s = 0; s < 16; ++s)
         Pacc = mfma2(-sT[(32 + 2 * s + lk) * PP + 32 * ti + lr], sT[(32 + 2 * s + lk) * PP + 32 * tj + lr], Pacc);
     Pacc = mfma2(lk == 0 ? scv[32 * ti + lr] : 0.f, lk == 0 ? scv[32 * tj + lr] : 0.f, Pacc);
     BF_UNROLL for (int r = 0; r < 16; ++r) sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = Pacc[r];
-    if (out.P.p) BF_UNROLL for (int r = 0; r < 16; ++r)
-        __builtin_nontemporal_store(Pacc[r], &out.P.p[b * out.P.sB + t * out.P.sT + ((32 * ti + c_row(r, lane)) * N + 32 * tj + lr) * out.P.sE]);
+    store_tile<N>(out.P, b, t, ti, tj, lane, Pacc);
     if (wave == 1 && out.m.p) out.m.p[b * out.m.sB + t * out.m.sT + lane * out.m.sE] = mnxt[lane];
     if (VAR == 3 && wave == 3 && lane == 0) *reinterpret_cast<int*>(sc2 + 32) = 0;  // progress counter re-armed (three barriers ahead of its next use)
     if (wave == 2 && lane == 0) {
@@ -877,12 +954,13 @@ kf_scan_mfma2_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
     // ================= phase I: A P+ -> sT (all waves; K = 64); m- = A m+ + G q0 (waves 0, 3)
     {
       f32x16 acc = {0};
-      BF_UNROLL for (int s = 0; s < 32; ++s) acc = mfma2(sA[(32 * ti + lr) * PP + 2 * s + lk], sP[(2 * s + lk) * PP + 32 * tj + lr], acc);
+      BF_UNROLL for (int s = 0; s < 32; ++s)
+          acc = mfma2(AREG ? aop[s] : sA[(32 * ti + lr) * PP + 2 * s + lk], sP[(2 * s + lk) * PP + 32 * tj + lr], acc);
       BF_UNROLL for (int r = 0; r < 16; ++r) sT[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = acc[r];
     }
     if (wave == 0 || wave == 3) {
       float s = 0.f;
-      BF_UNROLL for (int q = 0; q < 32; ++q) s = fmaf(sA[(32 * ti + lr) * PP + 2 * q + lk], mnxt[2 * q + lk], s);
+      BF_UNROLL for (int q = 0; q < 32; ++q) s = fmaf(AREG ? aop[q] : sA[(32 * ti + lr) * PP + 2 * q + lk], mnxt[2 * q + lk], s);
       s += __shfl_xor(s, 32, 64);
       if (lane < 32) mcur[32 * ti + lane] = s + cst->Gq0[32 * ti + lane];  // predicted mean
     }
@@ -890,11 +968,17 @@ kf_scan_mfma2_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
     lds_barrier();
     BF_TICK(7)
     // ================= phase J: P- = (A P+) A^T + G Q G^T (all waves; K = 64); emit predicted streams
-    BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] = cst->GQG[(32 * ti + c_row(r, lane)) * N + 32 * tj + lr];
-    BF_UNROLL for (int s = 0; s < 32; ++s) Pacc = mfma2(sT[(32 * ti + lr) * PP + 2 * s + lk], sA[(32 * tj + lr) * PP + 2 * s + lk], Pacc);
-    BF_UNROLL for (int r = 0; r < 16; ++r) sP[(32 * ti + c_row(r, lane)) * PP + 32 * tj + lr] = Pacc[r];
-    if (out.pP.p) BF_UNROLL for (int r = 0; r < 16; ++r)
-        __builtin_nontemporal_store(Pacc[r], &out.pP.p[b * out.pP.sB + t * out.pP.sT + ((32 * ti + c_row(r, lane)) * N + 32 * tj + lr) * out.pP.sE]);
+    // Variant 4: the wave computes tile (tj, ti) instead of (ti, tj): its B operand A^T[k][32 ti + lr] = A[32 ti + lr][k]
+    // is then the same 32 registers that were its A operand in phase I.
+    {
+      const int pi = AREG ? tj : ti, pj = AREG ? ti : tj;
+      gl_cf* gqg = per_step(cst->GQG);
+      BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] = gqg[(32 * pi + c_row(r, lane)) * N + 32 * pj + lr];
+      BF_UNROLL for (int s = 0; s < 32; ++s)
+          Pacc = mfma2(sT[(32 * pi + lr) * PP + 2 * s + lk], AREG ? aop[s] : sA[(32 * pj + lr) * PP + 2 * s + lk], Pacc);
+      BF_UNROLL for (int r = 0; r < 16; ++r) sP[(32 * pi + c_row(r, lane)) * PP + 32 * pj + lr] = Pacc[r];
+      store_tile<N>(out.pP, b, t, pi, pj, lane, Pacc);
+    }
     if (wave == 2 && out.pm.p) out.pm.p[b * out.pm.sB + t * out.pm.sT + lane * out.pm.sE] = mcur[lane];
     BF_TICK(8)
     lds_barrier();
@@ -907,7 +991,7 @@ kf_scan_mfma2_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
   if (carry.w_out && wave == 2 && lane == 0) carry.w_out[b] = w;
 #ifdef BF_MFMA_PHASE_TIMERS
   __syncthreads();
-  if (b == 0 && lane == 0 && carry.P_out) for (int i = 0; i < 10; ++i) carry.P_out[wave * 16 + i] = (float)tacc[i];
+  if (b == 0 && lane == 0 && carry.P_out) for (int i = 0; i < 12; ++i) carry.P_out[wave * 16 + i] = (float)tacc[i];
 #endif
 }
 
@@ -981,11 +1065,14 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
       BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(256), lds_bytes, stream, d, yv, cv, ov, B, T);
   } else {
-    const size_t lds_bytes = sizeof(float) * (size_t)(3 * N * (N + 1) + M * (N + 1) + 3 * M * (M + 1) + 3 * N + M);
-    auto kern = g_kf_mfma_variant.load() == 2 ? kf_scan_mfma2_kernel<N, M, 2> : kf_scan_mfma2_kernel<N, M, 3>;
+    const int var = g_kf_mfma_variant.load();
+    const size_t lds_bytes = var == 4 ? sizeof(float) * (size_t)(2 * N * (N + 1) + M * (N + 1) + 2 * M * (M + 1) + 3 * N + M)
+                                      : sizeof(float) * (size_t)(3 * N * (N + 1) + M * (N + 1) + 3 * M * (M + 1) + 3 * N + M);
+    auto kern = var == 2 ? kf_scan_mfma2_kernel<N, M, 2> : var == 3 ? kf_scan_mfma2_kernel<N, M, 3> : kf_scan_mfma2_kernel<N, M, 4>;
     if (lds_bytes > 64 * 1024)
       BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(256), lds_bytes, stream, d, yv, cv, ov, B, T);
+    static const int rot_mode = [] { const char* e = std::getenv("BAYESFILT_MFMA_ROT"); return e ? std::atoi(e) : 1; }();
+    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(256), lds_bytes, stream, d, yv, cv, ov, B, T, rot_mode);
   }
   BF_HIP_CHECK(hipGetLastError());
   return BF_OK;

@@ -19,6 +19,6 @@ for fields in ((), bfa.FULL5):
     carry = post[-1]
     P = carry.covariances.reshape(B, -1)[0].cpu().numpy()
     # variant 1: nine phases; variants 2 / 3: (compute, barrier wait) of the five phases A, B+C, H, I, J -- ticks of 10 ns
-    names = ["A", "B", "C", "E", "F", "G", "H", "I", "J", "-"] if os.environ.get("PV", "3") == "1" else ["A", "wA", "BC", "wBC", "H", "wH", "I", "wI", "J", "wJ"]
+    names = ["A", "B", "C", "E", "F", "G", "H", "I", "J", "-"] if os.environ.get("PV", "3") == "1" else ["A", "wA", "BC", "wBC", "H", "wH", "I", "wI", "J", "wJ", "S", "-"]
     for w in range(4):
-        print("role", w, " ".join(f"{names[i]}={P[w*16+i]/T:7.0f}" for i in range(10)), " total/step", P[w*16:w*16+10].sum() / T)
+        print("role", w, " ".join(f"{names[i]}={P[w*16+i]/T:7.0f}" for i in range(len(names))), " total/step", P[w*16:w*16+len(names)].sum() / T)
