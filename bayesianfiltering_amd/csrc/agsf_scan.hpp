@@ -142,15 +142,18 @@ __device__ __forceinline__ void optimal_resampling_lanes(float w, int l, int MP,
 template <int N, int M>
 struct EkfNodes {
   using Arg = EkfModel<N, M>;  // by value, in the kernel arguments
-  static __device__ __forceinline__ void predict(const Arg& mdl, float* m, float* P, float u0) {
+  // tq / tr: this step's F_q Q_t F_q^T / H_r R_t H_r^T when the covariances are (T, d, d) (inference.py:658-661), else NULL
+  static constexpr int TVQ = N * N, TVR = M * M;  // floats per step in the tables
+  static __device__ __forceinline__ void predict(const Arg& mdl, float* m, float* P, float u0, const float* tq) {
     float F[N * N], fx[N];
     dyn_linearize<N, M>(mdl, m, u0, F, fx);
-    predict_cov<N>(F, mdl.GQG, P);  // F P F^T + F_q Q F_q^T
+    predict_cov<N>(F, tq ? tq : mdl.GQG, P);  // F P F^T + F_q Q F_q^T
     BF_UNROLL for (int i = 0; i < N; ++i) m[i] = fx[i];
   }
-  static __device__ __forceinline__ float condition(const Arg& mdl, float* m, float* P, const float* yv, float u0) {
+  static __device__ __forceinline__ float condition(const Arg& mdl, float* m, float* P, const float* yv, float u0, const float* tr) {
     float H[M * N], hx[M], HrRHr[M * M], v[M];
     emi_linearize<N, M>(mdl, m, u0, H, hx, HrRHr);
+    if (tr) BF_UNROLL for (int i = 0; i < M * M; ++i) HrRHr[i] = tr[i];
     BF_UNROLL for (int a = 0; a < M; ++a) v[a] = yv[a] - hx[a];
     return condition_on<N, M>(H, HrRHr, v, m, P);
   }
@@ -158,9 +161,13 @@ struct EkfNodes {
 template <int N, int DQ, int M, int DR>
 struct UkfNodes {
   using Arg = const UkfModel<N, DQ, M, DR>*;  // device-resident
-  static __device__ __forceinline__ void predict(Arg mdl, float* m, float* P, float u0) { ukf_predict(*mdl, m, P, u0); }
-  static __device__ __forceinline__ float condition(Arg mdl, float* m, float* P, const float* yv, float u0) {
-    return ukf_condition_on(*mdl, m, P, yv, u0);
+  // tq / tr: sqrtm(Q_t) / sqrtm(R_t) of the step, or NULL
+  static constexpr int TVQ = DQ * DQ, TVR = DR * DR;
+  static __device__ __forceinline__ void predict(Arg mdl, float* m, float* P, float u0, const float* tq) {
+    ukf_predict(*mdl, m, P, u0, tq ? tq : mdl->sQ);
+  }
+  static __device__ __forceinline__ float condition(Arg mdl, float* m, float* P, const float* yv, float u0, const float* tr) {
+    return ukf_condition_on(*mdl, m, P, yv, u0, tr ? tr : mdl->sR);
   }
 };
 
@@ -175,7 +182,8 @@ struct AgsfOut {
 template <int N, int M, class NODES, int NW>
 __global__ void __launch_bounds__(NW == 1 ? 256 : 64 * NW)
 agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, AgsfOut out, long long B, long long T, int N0, int N1,
-                 int N2, int MP, float a0, float a1, uint32_t key0, uint32_t key1, int variant, int carry_records) {
+                 int N2, int MP, float a0, float a1, uint32_t key0, uint32_t key1, int variant, int carry_records,
+                 const float* __restrict__ tvq, const float* __restrict__ tvr) {
   constexpr int EP = N * N;
   constexpr int REC = N + EP;  // one component record in LDS: mean, covariance
   constexpr int NT = NW == 1 ? 256 : 64 * NW;
@@ -275,7 +283,7 @@ agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, A
         mz[i] = rec[i] + s;       // z = m + chol(P - Delta) eps
         if (variant != 0 && mz[i] != mz[i]) mz[i] = rec[i];  // jnp.where(isnan(new_means), mean, new_means)  containers.py:84
       }
-      NODES::predict(mdl, mz, Dl, u0);  // the node (z, Delta) through the dynamics
+      NODES::predict(mdl, mz, Dl, u0, tvq ? tvq + t * NODES::TVQ : nullptr);  // the node (z, Delta) through the dynamics
       BF_UNROLL for (int i = 0; i < EP; ++i) P[i] = Dl[i];
     }
     // ---- s-sample of the leaf and its update (:711-737)
@@ -294,7 +302,7 @@ agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, A
         ms[i] = mz[i] + s;
         if (variant != 0 && ms[i] != ms[i]) ms[i] = mz[i];        // containers.py:121
       }
-      ll = NODES::condition(mdl, ms, Lam, yv, u0);  // the leaf (s, Lambda) conditioned on y
+      ll = NODES::condition(mdl, ms, Lam, yv, u0, tvr ? tvr + t * NODES::TVR : nullptr);  // the leaf (s, Lambda) conditioned on y
       BF_UNROLL for (int i = 0; i < N; ++i) mz[i] = ms[i];
       BF_UNROLL for (int i = 0; i < EP; ++i) P[i] = Lam[i];
     }
@@ -403,7 +411,8 @@ agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, A
 template <int N, int M, class NODES, int NW>
 static inline int launch_agsf_geom(typename NODES::Arg arg, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
                                    const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry,
-                                   const bf_out_desc* out, int* d_leaf_idx, int variant, int MP, hipStream_t stream) {
+                                   const bf_out_desc* out, int* d_leaf_idx, int variant, int MP, const float* d_tvq, const float* d_tvr,
+                                   hipStream_t stream) {
   constexpr int REC = N + N * N;
   constexpr int NT = NW == 1 ? 256 : 64 * NW;
   const int carry_records = NW == 1 ? 256 : ((nc[0] + 3) & ~3);
@@ -420,7 +429,7 @@ static inline int launch_agsf_geom(typename NODES::Arg arg, const bf_cstream* y,
     BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   const int tpb = NT / MP;
   hipLaunchKernelGGL(kern, dim3((unsigned)((B + tpb - 1) / tpb)), dim3(NT), lds_bytes, stream, arg, yv, uv, cv, ov, B, T, nc[0],
-                     nc[1], nc[2], MP, opt[0], opt[1], key[0], key[1], variant, carry_records);
+                     nc[1], nc[2], MP, opt[0], opt[1], key[0], key[1], variant, carry_records, d_tvq, d_tvr);
   BF_HIP_CHECK(hipGetLastError());
   return BF_OK;
 }
@@ -428,7 +437,8 @@ static inline int launch_agsf_geom(typename NODES::Arg arg, const bf_cstream* y,
 template <int N, int M, class NODES>
 static inline int launch_agsf_nodes(typename NODES::Arg arg, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
                                     const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry,
-                                    const bf_out_desc* out, int* d_leaf_idx, int variant, hipStream_t stream) {
+                                    const bf_out_desc* out, int* d_leaf_idx, int variant, const float* d_tvq, const float* d_tvr,
+                                    hipStream_t stream) {
   const long long Mleaf = (long long)nc[0] * nc[1] * nc[2];
   if (Mleaf > 1024)
     return set_error(BF_EUNSUPPORTED, "augmented Gaussian-sum filter: %lld leaves per trajectory exceed one workgroup (1024)", Mleaf);
@@ -438,7 +448,7 @@ static inline int launch_agsf_nodes(typename NODES::Arg arg, const bf_cstream* y
     return set_error(BF_EUNSUPPORTED, "optimal resampling sorts inside one wave: %lld leaves exceed 64", Mleaf);
   if (out->pred_means.ptr || out->pred_covs.ptr || out->coll_mean.ptr || out->coll_cov.ptr || out->loglik.ptr)
     return set_error(BF_EINVAL, "the augmented filter emits weights, means and covariances only (inference.py:771-775)");
-#define BF_GEOM(NW_) return launch_agsf_geom<N, M, NODES, NW_>(arg, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, variant, MP, stream)
+#define BF_GEOM(NW_) return launch_agsf_geom<N, M, NODES, NW_>(arg, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, variant, MP, d_tvq, d_tvr, stream)
   if (MP <= 64) BF_GEOM(1);
   if constexpr (N <= 4) {  // the multi-wave geometries are built for the small state dimensions only (build time, LDS)
     if (MP <= 256) {
@@ -458,10 +468,15 @@ static inline int launch_agsf(const bf_model* p, const bf_cstream* y, const bf_c
                               const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry,
                               const bf_out_desc* out, int* d_leaf_idx, int variant, hipStream_t stream) {
   EkfModel<N, M> e;
-  int rc = fill_model<N, M>(p, e);
+  std::vector<float> tvq, tvr;
+  int rc = fill_model<N, M>(p, e, &tvq, &tvr);
   if (rc != BF_OK) return rc;
   if (p->flags != 0) return set_error(BF_EUNSUPPORTED, "legacy-class flags do not apply to the augmented filter");
-  return launch_agsf_nodes<N, M, EkfNodes<N, M>>(e, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, variant, stream);
+  if ((p->Q_steps > 1 && p->Q_steps != T) || (p->R_steps > 1 && p->R_steps != T))
+    return set_error(BF_EINVAL, "time-varying covariances need one matrix per step (Q_steps / R_steps = T = %lld)", T);
+  const float *d_tvq = nullptr, *d_tvr = nullptr;
+  if ((rc = upload_table(tvq, stream, &d_tvq)) != BF_OK || (rc = upload_table(tvr, stream, &d_tvr)) != BF_OK) return rc;
+  return launch_agsf_nodes<N, M, EkfNodes<N, M>>(e, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, variant, d_tvq, d_tvr, stream);
 }
 
 // unscented nodes (speedy_unscented_agsf / unscented_agsf, inference.py:966-1156 / 813-965)
@@ -471,13 +486,19 @@ static inline int launch_uagsf(const bf_model* p, const bf_ukf_params* up, const
                                const bf_out_desc* out, int* d_leaf_idx, int variant, hipStream_t stream) {
   UkfModel<N, DQ, M, DR> h;
   std::memset(&h, 0, sizeof(h));  // the constant cache compares contents
-  int rc = fill_ukf_model<N, DQ, M, DR>(p, up, h);
+  std::vector<float> tvsq, tvsr;
+  int rc = fill_ukf_model<N, DQ, M, DR>(p, up, h, &tvsq, &tvsr);
   if (rc != BF_OK) return rc;
+  if ((p->Q_steps > 1 && p->Q_steps != T) || (p->R_steps > 1 && p->R_steps != T))
+    return set_error(BF_EINVAL, "time-varying covariances need one matrix per step (Q_steps / R_steps = T = %lld)", T);
   const void* dv = nullptr;
   rc = device_constants(&h, sizeof(h), stream, &dv);
   if (rc != BF_OK) return rc;
   const UkfModel<N, DQ, M, DR>* d_mdl = static_cast<const UkfModel<N, DQ, M, DR>*>(dv);
-  return launch_agsf_nodes<N, M, UkfNodes<N, DQ, M, DR>>(d_mdl, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, variant, stream);
+  const float *d_tvq = nullptr, *d_tvr = nullptr;
+  if ((rc = upload_table(tvsq, stream, &d_tvq)) != BF_OK || (rc = upload_table(tvsr, stream, &d_tvr)) != BF_OK) return rc;
+  return launch_agsf_nodes<N, M, UkfNodes<N, DQ, M, DR>>(d_mdl, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, variant, d_tvq, d_tvr,
+                                                         stream);
 }
 
 }  // namespace bf

@@ -238,7 +238,7 @@ int bf_agsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream
   if (model->n <= 0 || model->m <= 0 || model->dq <= 0 || model->dr <= 0)
     return bf::set_error(BF_EINVAL, "non-positive model dimension");
   if (!model->Q || !model->R) return bf::set_error(BF_EINVAL, "Q and R are required");
-  if (model->Q_steps > 1 || model->R_steps > 1) return bf::set_error(BF_EUNSUPPORTED, "time-varying Q/R are not supported by the augmented filter");
+  if (model->Q_steps < 1 || model->R_steps < 1) return bf::set_error(BF_EINVAL, "Q_steps / R_steps must be >= 1");
   if (!y->ptr) return bf::set_error(BF_EINVAL, "observations pointer is NULL");
   if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
   return bf::launch_agsf_ekf(model, y, u, B, T, num_components, key, opt_args, carry, out, leaf_idx, variant,

@@ -133,9 +133,12 @@ __device__ __forceinline__ void ukf_emi(const UkfModel<N, DQ, M, DR>& p, const f
   }
 }
 
-// _ukf_condition_on_nonadditive (inference.py:198-224): m, P <- posterior; returns the log-likelihood
+// _ukf_condition_on_nonadditive (inference.py:198-224): m, P <- posterior; returns the log-likelihood.
+// sR: sqrtm of this step's emission noise covariance (mdl.sR, or row t of the per-step table when R is (T, dr, dr):
+// inference.py:416 picks R_t before the step, :206-209 take the square root of blockdiag(P, R_t))
 template <int N, int DQ, int M, int DR>
-__device__ __forceinline__ float ukf_condition_on(const UkfModel<N, DQ, M, DR>& mdl, float* m, float* P, const float* yv, float u0) {
+__device__ __forceinline__ float ukf_condition_on(const UkfModel<N, DQ, M, DR>& mdl, float* m, float* P, const float* yv, float u0,
+                                                  const float* sR) {
   constexpr int EP = N * N;
   float ll;
 
@@ -172,7 +175,7 @@ __device__ __forceinline__ float ukf_condition_on(const UkfModel<N, DQ, M, DR>& 
       }
       BF_UNROLL for (int j = 0; j < DR; ++j) {
         float r[DR], dx[N], yy[M];
-        BF_UNROLL for (int i = 0; i < DR; ++i) r[i] = mdl.r0[i] + cs * mdl.sR[j * DR + i];
+        BF_UNROLL for (int i = 0; i < DR; ++i) r[i] = mdl.r0[i] + cs * sR[j * DR + i];
         BF_UNROLL for (int i = 0; i < N; ++i) dx[i] = 0.f;
         if constexpr (eval) {
           ukf_emi(mdl, m, r, u0, yy);
@@ -226,9 +229,9 @@ __device__ __forceinline__ float ukf_condition_on(const UkfModel<N, DQ, M, DR>& 
   return ll;
 }
 
-// _ukf_predict_nonadditive (inference.py:146-174): m, P <- predicted mean and covariance
+// _ukf_predict_nonadditive (inference.py:146-174): m, P <- predicted mean and covariance.  sQ: sqrtm(Q_t), as sR above
 template <int N, int DQ, int M, int DR>
-__device__ __forceinline__ void ukf_predict(const UkfModel<N, DQ, M, DR>& mdl, float* m, float* P, float u0) {
+__device__ __forceinline__ void ukf_predict(const UkfModel<N, DQ, M, DR>& mdl, float* m, float* P, float u0, const float* sQ) {
   constexpr int EP = N * N;
 
   float sP[EP];
@@ -259,7 +262,7 @@ __device__ __forceinline__ void ukf_predict(const UkfModel<N, DQ, M, DR>& mdl, f
       BF_UNROLL for (int j = 0; j < DQ; ++j) {
         float q[DQ], xx[N];
         if constexpr (eval) {
-          BF_UNROLL for (int i = 0; i < DQ; ++i) q[i] = mdl.q0[i] + cs * mdl.sQ[j * DQ + i];
+          BF_UNROLL for (int i = 0; i < DQ; ++i) q[i] = mdl.q0[i] + cs * sQ[j * DQ + i];
           ukf_dyn(mdl, m, q, u0, xx);
           if constexpr (STORE) BF_UNROLL for (int i = 0; i < N; ++i) img[pt * N + i] = xx[i];
         } else {
@@ -289,7 +292,8 @@ __device__ __forceinline__ void ukf_predict(const UkfModel<N, DQ, M, DR>& mdl, f
 template <int N, int DQ, int M, int DR>
 __global__ void __launch_bounds__(256)
 ugsf_scan_kernel(const UkfModel<N, DQ, M, DR>* __restrict__ mdlp, CView y, const float* __restrict__ uptr, long long u_sB,
-                 long long u_sT, CarryView carry, OutViews out, long long B, long long T, int K, int KP) {
+                 long long u_sT, CarryView carry, OutViews out, long long B, long long T, int K, int KP,
+                 const float* __restrict__ tvsq, const float* __restrict__ tvsr) {
   const UkfModel<N, DQ, M, DR>& mdl = *mdlp;
   constexpr int EP = N * N;
   const int tid = threadIdx.x;
@@ -332,7 +336,7 @@ ugsf_scan_kernel(const UkfModel<N, DQ, M, DR>* __restrict__ mdlp, CView y, const
     float ll;
 
     // ================= _ukf_condition_on_nonadditive (inference.py:198-224)
-    ll = ukf_condition_on(mdl, m, P, yv, u0);
+    ll = ukf_condition_on(mdl, m, P, yv, u0, tvsr ? tvsr + t * (DR * DR) : mdl.sR);
 
     // ================= reweight (inference.py:424-427)
     {
@@ -350,7 +354,7 @@ ugsf_scan_kernel(const UkfModel<N, DQ, M, DR>* __restrict__ mdlp, CView y, const
     }
 
     // ================= _ukf_predict_nonadditive (inference.py:146-174)
-    ukf_predict(mdl, m, P, u0);
+    ukf_predict(mdl, m, P, u0, tvsq ? tvsq + t * (DQ * DQ) : mdl.sQ);
     if (chain_ok) {
       if (out.pm.p) BF_UNROLL for (int i = 0; i < N; ++i) out.pm.p[b * out.pm.sB + k * out.pm.sK + t * out.pm.sT + i * out.pm.sE] = m[i];
       if (out.pP.p) BF_UNROLL for (int i = 0; i < EP; ++i) out.pP.p[b * out.pP.sB + k * out.pP.sK + t * out.pP.sT + i * out.pP.sE] = P[i];
@@ -410,11 +414,25 @@ static inline void host_sym_sqrt(const float* A, int n, float* out) {
     }
 }
 
+// per-step table -> device (stream-ordered upload through the constant cache, const_cache.hip); empty = NULL
+static inline int upload_table(const std::vector<float>& v, hipStream_t stream, const float** d_out) {
+  *d_out = nullptr;
+  if (v.empty()) return BF_OK;
+  const void* dv = nullptr;
+  const int rc = device_constants(v.data(), sizeof(float) * v.size(), stream, &dv);
+  if (rc != BF_OK) return rc;
+  *d_out = static_cast<const float*>(dv);
+  return BF_OK;
+}
+
+// tvsq / tvsr: filled with sqrtm(Q_t) / sqrtm(R_t), one matrix per step, when p->Q_steps / p->R_steps > 1
+// (inference.py:414-417: the step's covariances are picked by _get_params before the unscented transforms)
 template <int N, int DQ, int M, int DR>
-static inline int fill_ukf_model(const bf_model* p, const bf_ukf_params* up, UkfModel<N, DQ, M, DR>& e) {
+static inline int fill_ukf_model(const bf_model* p, const bf_ukf_params* up, UkfModel<N, DQ, M, DR>& e,
+                                 std::vector<float>* tvsq = nullptr, std::vector<float>* tvsr = nullptr) {
   std::memset(&e, 0, sizeof(e));
-  if (p->Q_steps > 1 || p->R_steps > 1)
-    return set_error(BF_EUNSUPPORTED, "time-varying Q/R are not supported by the unscented filter");
+  if ((p->Q_steps > 1 && !tvsq) || (p->R_steps > 1 && !tvsr))
+    return set_error(BF_EUNSUPPORTED, "time-varying Q/R are not supported on this path");
   if (p->flags != 0) return set_error(BF_EUNSUPPORTED, "legacy-class flags do not apply to the unscented filter");
   e.dyn_id = p->dyn_id;
   e.emi_id = p->emi_id;
@@ -481,6 +499,14 @@ static inline int fill_ukf_model(const bf_model* p, const bf_ukf_params* up, Ukf
   for (int i = 0; i < DR; ++i) e.r0[i] = p->r0 ? p->r0[i] : 0.f;
   host_sym_sqrt(p->Q, DQ, e.sQ);
   host_sym_sqrt(p->R, DR, e.sR);
+  if (p->Q_steps > 1) {
+    tvsq->resize((size_t)p->Q_steps * DQ * DQ);
+    for (int t = 0; t < p->Q_steps; ++t) host_sym_sqrt(p->Q + (size_t)t * DQ * DQ, DQ, tvsq->data() + (size_t)t * DQ * DQ);
+  }
+  if (p->R_steps > 1) {
+    tvsr->resize((size_t)p->R_steps * DR * DR);
+    for (int t = 0; t < p->R_steps; ++t) host_sym_sqrt(p->R + (size_t)t * DR * DR, DR, tvsr->data() + (size_t)t * DR * DR);
+  }
   auto consts = [&](int L, float& c, float& ws, float& w0, float& wc) {
     const float a2 = up->alpha * up->alpha;
     const float lam = a2 * ((float)L + up->kappa) - (float)L;  // inference.py:163, :206
@@ -499,8 +525,11 @@ static inline int launch_ugsf(const bf_model* p, const bf_ukf_params* up, const 
                               long long T, int K, const bf_carry* carry, const bf_out_desc* out, hipStream_t stream) {
   UkfModel<N, DQ, M, DR> h;
   std::memset(&h, 0, sizeof(h));  // the constant cache compares contents
-  int rc = fill_ukf_model<N, DQ, M, DR>(p, up, h);
+  std::vector<float> tvsq, tvsr;
+  int rc = fill_ukf_model<N, DQ, M, DR>(p, up, h, &tvsq, &tvsr);
   if (rc != BF_OK) return rc;
+  if ((p->Q_steps > 1 && p->Q_steps != T) || (p->R_steps > 1 && p->R_steps != T))
+    return set_error(BF_EINVAL, "time-varying covariances need one matrix per step (Q_steps / R_steps = T = %lld)", T);
   int KP = 1;
   while (KP < K) KP <<= 1;
   if (KP > 256) return set_error(BF_EUNSUPPORTED, "unscented Gaussian-sum filter: %d components exceed one workgroup (256 lanes)", K);
@@ -510,13 +539,15 @@ static inline int launch_ugsf(const bf_model* p, const bf_ukf_params* up, const 
   rc = device_constants(&h, sizeof(h), stream, &dv);
   if (rc != BF_OK) return rc;
   const UkfModel<N, DQ, M, DR>* d_mdl = static_cast<const UkfModel<N, DQ, M, DR>*>(dv);
+  const float *d_tvsq = nullptr, *d_tvsr = nullptr;
+  if ((rc = upload_table(tvsq, stream, &d_tvsq)) != BF_OK || (rc = upload_table(tvsr, stream, &d_tvsr)) != BF_OK) return rc;
   CView yv{y->ptr, y->sB, y->sT, y->sE};
   CarryView cv{carry->w_in, carry->m_in, carry->P_in, carry->w_out, carry->m_out, carry->P_out};
   OutViews ov{make_sview(out->weights), make_sview(out->means), make_sview(out->covs),
               make_sview(out->pred_means), make_sview(out->pred_covs), make_sview(out->loglik)};
   const int tpb = 256 / KP;
   hipLaunchKernelGGL((ugsf_scan_kernel<N, DQ, M, DR>), dim3((unsigned)((B + tpb - 1) / tpb)), dim3(256), 0, stream, d_mdl, yv,
-                     (u && u->ptr) ? u->ptr : nullptr, u ? u->sB : 0, u ? u->sT : 0, cv, ov, B, T, K, KP);
+                     (u && u->ptr) ? u->ptr : nullptr, u ? u->sB : 0, u ? u->sT : 0, cv, ov, B, T, K, KP, d_tvsq, d_tvsr);
   BF_HIP_CHECK(hipGetLastError());
   return BF_OK;
 }

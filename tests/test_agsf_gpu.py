@@ -220,3 +220,51 @@ def test_trees_wider_than_a_wave(nc, unscented):
         assert np.array_equal(aux["leaf_indices"][b].cpu().numpy(), raux["leaf_indices"]), b
         for k in ("means", "covariances"):
             assert cm.rel_err(getattr(post, k)[b].cpu().numpy(), getattr(ref, k)) < 3e-5, (b, k)
+
+
+@pytest.mark.parametrize("nodes", ["extended", "unscented"])
+def test_time_varying_covariances(nodes):
+    """(T, d, d) noise covariances in the augmented filters (inference.py:658-661, :1004-1007): per-step Q_t / R_t at
+    every node of the tree, extended-Kalman and unscented nodes; the drawn leaves stay bit-exact."""
+    bfa, nl = _nl()
+    rng = np.random.default_rng(9)
+    T, nc = 20, (3, 2, 3)
+    mu0 = np.array([2.0, 0.3, 3.0, -0.2], F32)
+    S0 = np.diag([0.1, 0.005, 0.1, 0.01]).astype(F32)
+    Q, R = 1e-3 * np.eye(2, dtype=F32), np.diag([1e-3, 1e-2]).astype(F32)
+
+    def table(base):
+        out = []
+        for t in range(T):
+            w = rng.normal(size=base.shape) * 0.3
+            out.append(base * (0.5 + rng.uniform()) + 0.2 * np.mean(np.diag(base)) * (w @ w.T))
+        return np.stack(out).astype(F32)
+
+    Qt, Rt = table(Q), table(R)
+    inputs = np.array([1] * 7 + [0] * 6 + [2] * 7, F32)
+    po = go.ParamsNLSSM(mu0, S0, om.ManeuverBOT(), np.zeros(2, F32), Qt, om.BearingRange(), np.zeros(2, F32), Rt)
+    pp = bfa.ParamsNLSSM(mu0, S0, nl.maneuver_bot(), np.zeros(2, F32), Qt, nl.bearing_range(), np.zeros(2, F32), Rt)
+    ys = go.sample_ssm(po._replace(dynamics_noise_covariance=Q, emission_noise_covariance=R), otf.PRNGKey(4), T,
+                       inputs.reshape(T, 1))[1]
+    init = (mu0 + 0.05 * rng.normal(size=(nc[0], 4))).astype(F32)
+    if nodes == "extended":
+        ref, raux = go.speedy_augmented_gaussian_sum_filter(po, ys, nc, otf.PRNGKey(3), 1, (0.1, 0.1), inputs.reshape(T, 1),
+                                                            initial_means=init, debug=True)
+        post, aux = bfa.speedy_augmented_gaussian_sum_filter(pp, ys, nc, otf.PRNGKey(3), 1, (0.1, 0.1), inputs,
+                                                             initial_means=init, return_leaf_indices=True)
+        const, _ = bfa.speedy_augmented_gaussian_sum_filter(pp._replace(dynamics_noise_covariance=Q, emission_noise_covariance=R),
+                                                            ys, nc, otf.PRNGKey(3), 1, (0.1, 0.1), inputs, initial_means=init,
+                                                            return_leaf_indices=True)
+    else:
+        ref, raux = go.speedy_unscented_agsf(po, go.ParamsUKF(1, 0, 0), ys, nc, otf.PRNGKey(3), 1, (0.1, 0.1), inputs.reshape(T, 1),
+                                             initial_means=init, debug=True)
+        post, aux = bfa.speedy_unscented_agsf(pp, bfa.ParamsUKF(1, 0, 0), ys, nc, otf.PRNGKey(3), 1, (0.1, 0.1), inputs,
+                                              initial_means=init, return_leaf_indices=True)
+        const, _ = bfa.speedy_unscented_agsf(pp._replace(dynamics_noise_covariance=Q, emission_noise_covariance=R),
+                                             bfa.ParamsUKF(1, 0, 0), ys, nc, otf.PRNGKey(3), 1, (0.1, 0.1), inputs,
+                                             initial_means=init, return_leaf_indices=True)
+    _compare(post, aux, ref, _oracle_leaf_indices(raux["pre_weights"], nc[0]), tol=3e-5)
+    assert cm.rel_err(const.covariances.cpu().numpy(), ref.covariances) > 1e-3  # the tables are not ignored
+    with pytest.raises(bfa.BayesFiltError):  # one matrix per step
+        bfa.speedy_augmented_gaussian_sum_filter(pp._replace(dynamics_noise_covariance=Qt[:5]), ys, nc, otf.PRNGKey(3), 1,
+                                                 (0.1, 0.1), inputs, initial_means=init)

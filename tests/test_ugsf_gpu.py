@@ -153,8 +153,8 @@ def test_errors():
         bfa.unscented_gaussian_sum_filter(pp, bfa.ParamsUKF(0.0, 2, 0), ys, 2)
     with pytest.raises(bfa.BayesFiltError):    # more components than one workgroup holds
         bfa.unscented_gaussian_sum_filter(pp, bfa.ParamsUKF(1, 0, 0), ys, 300)
-    Qt = np.stack([a["Q"]] * 6)
-    with pytest.raises(bfa.BayesFiltError):    # constant covariances only
+    Qt = np.stack([a["Q"]] * 5)
+    with pytest.raises(bfa.BayesFiltError):    # time-varying covariances: one matrix per step
         bfa.unscented_gaussian_sum_filter(pp._replace(dynamics_noise_covariance=Qt), bfa.ParamsUKF(1, 0, 0), ys, 2)
 
 
@@ -167,3 +167,56 @@ def test_golden_bearings_only_fixture(golden_dir):
     post = bfa.unscented_gaussian_sum_filter(pp, bfa.ParamsUKF(*d["uparams"]), d["emissions"], 4, 1, d["inputs"],
                                              initial_means=d["initial_means"])
     _check(post, d, tol=2e-5)
+
+
+def test_time_varying_covariances():
+    """(T, d, d) noise covariances: the step's Q_t / R_t are picked by _get_params (inference.py:411-417) before
+    the unscented transforms, whose sigma points then use sqrtm(blockdiag(P, R_t)) / sqrtm(blockdiag(P, Q_t)).
+    Linear model (the extended filter with the same tables is a second reference), non-diagonal tables, the
+    bearings-only model with a non-identity F_q, and the multiplicative-noise emission."""
+    bfa, nl = _nl()
+    rng = np.random.default_rng(5)
+    T, B, K = 22, 3, 3
+    a = cm.cv_model_arrays()
+    po, pp = cm.oracle_params(a), cm.product_params(a)
+
+    def spd_table(base, T):
+        d = base.shape[0]
+        out = []
+        for t in range(T):
+            w = rng.normal(size=(d, d)) * 0.3
+            out.append(base * (0.5 + rng.uniform()) + 0.2 * np.mean(np.diag(base)) * (w @ w.T))
+        return np.stack(out).astype(F32)
+
+    Qt, Rt = spd_table(a["Q"], T), spd_table(a["R"], T)
+    ys = np.stack([go.sample_ssm(po, otf.PRNGKey(b), T)[1] for b in range(B)])
+    init = rng.normal(size=(B, K, 4)).astype(F32)
+    up = (1.0, 0.0, 0.0)
+    for kw in ({"dynamics_noise_covariance": Qt, "emission_noise_covariance": Rt}, {"dynamics_noise_covariance": Qt},
+               {"emission_noise_covariance": Rt}):
+        ref, ref_ll = _oracle_batch(po._replace(**kw), go.ParamsUKF(*up), ys, K, init)
+        post, ll = bfa.unscented_gaussian_sum_filter(pp._replace(**kw), bfa.ParamsUKF(*up), ys, K, 1, initial_means=init,
+                                                     return_loglik=True)
+        _check(post, ref, tol=3e-5)
+        assert cm.rel_err(ll.cpu().numpy(), ref_ll) < 5e-5
+        ekf = bfa.gaussian_sum_filter(pp._replace(**kw), ys, K, 1, initial_means=init)
+        for k in FIELDS:
+            assert cm.rel_err(getattr(post, k).cpu().numpy(), getattr(ekf, k).cpu().numpy()) < 1e-4, k
+    # and they matter: the constant-covariance posterior is a different one
+    const = bfa.unscented_gaussian_sum_filter(pp, bfa.ParamsUKF(*up), ys, K, 1, initial_means=init)
+    assert cm.rel_err(const.covariances.cpu().numpy(), ref["covariances"]) > 1e-2
+
+    # multiplicative emission noise with a per-step R (no constant H_r needed here: R only enters the sigma points)
+    T2, K2 = 20, 4
+    Phi = 0.8 * np.eye(2, dtype=F32)
+    Q, R = 0.5 * np.eye(2, dtype=F32), 1e-1 * np.eye(2, dtype=F32)
+    Rt2 = spd_table(R, T2)
+    inputs = np.array([0] * 10 + [1] * 10, F32)
+    r0 = np.array([0.1, -0.2], F32)
+    po2 = go.ParamsNLSSM(np.zeros(2, F32), np.eye(2, dtype=F32), om.Linear(Phi), np.zeros(2, F32), Q, om.StochVol(2), r0, Rt2)
+    pp2 = bfa.ParamsNLSSM(np.zeros(2, F32), np.eye(2, dtype=F32), nl.linear_dynamics(Phi), np.zeros(2, F32), Q,
+                          nl.stoch_vol(2), r0, Rt2)
+    ys2 = go.sample_ssm(po2._replace(emission_noise_covariance=R), otf.PRNGKey(3), T2, inputs.reshape(T2, 1))[1]
+    init2 = rng.normal(size=(K2, 2)).astype(F32)
+    ref2 = go.unscented_gaussian_sum_filter(po2, go.ParamsUKF(1, 0, 0), ys2, K2, initial_means=init2, inputs=inputs.reshape(T2, 1))
+    _check(bfa.unscented_gaussian_sum_filter(pp2, bfa.ParamsUKF(1, 0, 0), ys2, K2, 1, inputs, initial_means=init2), ref2, tol=3e-5)
