@@ -38,12 +38,41 @@ optimal_resample_kernel(const float* __restrict__ w, long long B, int M, int MP,
   }
 }
 
+// more than 64 weights: one trajectory per workgroup of NW waves (optimal_resampling_block)
+template <int NW>
+__global__ void __launch_bounds__(64 * NW)
+optimal_resample_block_kernel(const float* __restrict__ w, long long B, int M, int N, uint32_t k0, uint32_t k1, int* __restrict__ idx,
+                              float* __restrict__ wout) {
+  __shared__ float scratch[4 * 64 * NW];
+  __shared__ float red[64];
+  const int l = threadIdx.x;
+  const long long b = blockIdx.x;
+  const float wl = l < M ? w[b * M + l] : 0.f;
+  int io;
+  float wo;
+  optimal_resampling_block<NW>(wl, M, N, k0, k1, scratch, red, io, wo);
+  if (l < N) {
+    idx[b * N + l] = io;
+    wout[b * N + l] = wo;
+  }
+}
+
 int launch_optimal_resample(const float* d_w, const uint32_t key[2], long long B, int M, int N, int* d_idx, float* d_wout,
                             hipStream_t stream) {
   int MP = 1;
   while (MP < M) MP <<= 1;
-  if (MP > 64) return set_error(BF_EUNSUPPORTED, "optimal resampling: %d weights exceed one wave (64)", M);
+  if (MP > 1024) return set_error(BF_EUNSUPPORTED, "optimal resampling: %d weights exceed one workgroup (1024)", M);
   if (N < 1 || N > M) return set_error(BF_EINVAL, "optimal resampling: need 1 <= N <= M");
+  if (MP > 64) {
+    if (MP <= 256)
+      hipLaunchKernelGGL(optimal_resample_block_kernel<4>, dim3((unsigned)B), dim3(256), 0, stream, d_w, B, M, N, key[0], key[1], d_idx,
+                         d_wout);
+    else
+      hipLaunchKernelGGL(optimal_resample_block_kernel<16>, dim3((unsigned)B), dim3(1024), 0, stream, d_w, B, M, N, key[0], key[1],
+                         d_idx, d_wout);
+    BF_HIP_CHECK(hipGetLastError());
+    return BF_OK;
+  }
   const int tpb = 256 / MP;
   hipLaunchKernelGGL(optimal_resample_kernel, dim3((unsigned)((B + tpb - 1) / tpb)), dim3(256), 0, stream, d_w, B, M, MP, N, key[0],
                      key[1], d_idx, d_wout);

@@ -137,6 +137,152 @@ __device__ __forceinline__ void optimal_resampling_lanes(float w, int l, int MP,
   w_out = __shfl(fw, seg0 + srcl, 64) / ftot;
 }
 
+
+// ---- the same building blocks for one trajectory per workgroup of NW waves (thread l = threadIdx.x holds element l of
+// MP = 64 NW; `red` is 64 floats of LDS scratch: [0, 16) reductions, [16, 32) scan totals, [32, 48) integer sums)
+template <int NW, class OP>
+__device__ __forceinline__ float block_tree_reduce(float v, float* red, OP op) {  // adjacent-pair tree over the 64 NW elements
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int off = 1; off < 64; off <<= 1) v = op(v, __shfl_xor(v, off, 64));
+  lds_barrier();
+  if (lane == 0) red[wave] = v;
+  lds_barrier();
+  float r = red[lane < NW ? lane : 0];
+  for (int off = 1; off < NW; off <<= 1) r = op(r, __shfl_xor(r, off, 64));
+  return __shfl(r, 0, 64);
+}
+// inclusive cumulative sum in lax.associative_scan order (Brent-Kung) over the 64 NW elements: wave up-sweep, scan of
+// the wave totals, wave down-sweep
+template <int NW>
+__device__ __forceinline__ float block_cumsum_assoc(float c, float* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  BF_UNROLL for (int d = 0; d < 6; ++d) {
+    const float o = __shfl_up(c, 1 << d, 64);
+    if (((lane + 1) & ((2 << d) - 1)) == 0) c += o;
+  }
+  lds_barrier();
+  if (lane == 63) red[16 + wave] = c;
+  lds_barrier();
+  float r = (lane < NW) ? red[16 + lane] : 0.f;
+  BF_UNROLL for (int d = 0; (1 << d) < NW; ++d) {
+    const float o = __shfl_up(r, 1 << d, 64);
+    if (lane < NW && ((lane + 1) & ((2 << d) - 1)) == 0) r += o;
+  }
+  BF_UNROLL for (int d = 4; d >= 1; --d) {
+    if ((1 << d) <= NW) {
+      const float o = __shfl_up(r, 1 << (d - 1), 64);
+      if (lane < NW && lane >= (1 << d) && ((lane + 1) & ((1 << d) - 1)) == (1 << (d - 1))) r += o;
+    }
+  }
+  const float mine = __shfl(r, wave, 64);
+  const float prev = __shfl(r, wave > 0 ? wave - 1 : 0, 64);
+  const float excl_wave = wave > 0 ? prev : 0.f;
+  if (lane == 63) c = mine;
+  BF_UNROLL for (int d = 6; d >= 1; --d) {
+    const float o = __shfl_up(c, 1 << (d - 1), 64);
+    if (((lane + 1) & ((1 << d) - 1)) == (1 << (d - 1))) c += (lane >= (1 << (d - 1))) ? o : excl_wave;
+  }
+  return c;
+}
+
+// optimal_resampling (utils.py:216-244) for M <= 64 NW weights held one per thread by a whole workgroup -- the reference's
+// own test runs augmented_gaussian_sum_filter_optimal on a [5, 5, 5] tree, 125 leaves (docs/tests/test_inference.py:89-92).
+// Same steps and the same arithmetic orders as optimal_resampling_lanes; the sort's far exchanges, the running sums, the
+// table look-ups and the gathers go through `scratch` (4 * 64 NW floats of LDS).  Every thread of the workgroup calls it.
+template <int NW>
+__device__ __forceinline__ void optimal_resampling_block(float w, int M, int N, uint32_t k0, uint32_t k1, float* scratch, float* red,
+                                                         int& idx_out, float& w_out) {
+  constexpr int MP = 64 * NW;
+  const int l = threadIdx.x, lane = l & 63, wave = l >> 6;
+  float* s_v = scratch;                                  // sorted weights; later the final indices
+  int* s_i = reinterpret_cast<int*>(scratch + MP);       // sorted indices
+  float* s_a = scratch + 2 * MP;                         // thresholds ps; later the final weights
+  float* s_b = scratch + 3 * MP;                         // cumulative resampling weights
+  // ---- stable ascending sort of (w, l): bitonic network, partners within a wave by shuffle, beyond it through LDS
+  float sv = l < M ? w : __builtin_inff();
+  int si = l;
+  for (int k = 2; k <= MP; k <<= 1)
+    for (int j = k >> 1; j >= 1; j >>= 1) {
+      float ov;
+      int oi;
+      if (j < 64) {
+        ov = __shfl_xor(sv, j, 64);
+        oi = __shfl_xor(si, j, 64);
+      } else {
+        lds_barrier();
+        s_v[l] = sv;
+        s_i[l] = si;
+        lds_barrier();
+        ov = s_v[l ^ j];
+        oi = s_i[l ^ j];
+      }
+      const bool up = (l & k) == 0;
+      const bool lower = (l & j) == 0;
+      const bool other_less = (ov < sv) || (ov == sv && oi < si);
+      const bool take = (lower == up) ? other_less : !other_less;
+      sv = take ? ov : sv;
+      si = take ? oi : si;
+    }
+  lds_barrier();
+  s_v[l] = sv;
+  s_i[l] = si;
+  lds_barrier();
+  // ---- running sums in index order (a broadcast read per term)
+  float cum = 0.f;
+  for (int c = 0; c < M; ++c) {
+    const float vc = s_v[c];
+    cum = (c <= l) ? cum + vc : cum;
+  }
+  // ---- threshold
+  const int ind = M - 1 - l;
+  const float sw_next = s_v[l + 1 < MP ? l + 1 : l];
+  const bool cand = ind >= 1 && ind <= N - 1 && l < M;
+  const float psv = cum / (float)(N - ind);
+  const bool pred = cand && (sv < psv) && (psv < sw_next);
+  s_a[l] = psv;
+  int Lsum = pred ? ind : 0;
+  for (int off = 1; off < 64; off <<= 1) Lsum += __shfl_xor(Lsum, off, 64);
+  int* red_i = reinterpret_cast<int*>(red + 32);
+  lds_barrier();
+  if (lane == 0) red_i[wave] = Lsum;
+  lds_barrier();
+  Lsum = 0;
+  BF_UNROLL for (int q = 0; q < NW; ++q) Lsum += red_i[q];
+  const int Ll = Lsum >= 1 && Lsum <= N - 1 ? Lsum : 1;
+  const float p_at = s_a[M - 1 - Ll];
+  const float p = Lsum == 0 ? 1.0f / (float)N : p_at;
+  // ---- resample among the weights below p
+  const bool below = l < M && sv < p;
+  float rw = below ? sv : 0.f;
+  const float tot = block_tree_reduce<NW>(rw, red, [](float a, float b) { return a + b; });
+  rw = rw / tot;
+  const float c = block_cumsum_assoc<NW>(rw, red);
+  s_b[l] = c;
+  lds_barrier();
+  const float ctot = s_b[M - 1];
+  const float u = bits_to_unit(threefry_bits(k0, k1, (uint32_t)(l < M ? l : 0), (uint32_t)M));
+  const float r = ctot * (1.0f - u);
+  int lo = 0, hi = M;  // first index with cdf[idx] >= r
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (s_b[mid] < r) lo = mid + 1; else hi = mid;
+  }
+  const int ridx = (r != r) ? M - 1 : (lo < M - 1 ? lo : M - 1);
+  const int unsort = s_i[ridx];
+  const int fidx = below ? unsort : si;
+  const float fw = below ? p : sv;
+  // ---- the last N sorted positions are the output
+  const bool top = l >= M - N && l < M;
+  const float ftot = block_tree_reduce<NW>(top ? fw : 0.f, red, [](float a, float b) { return a + b; });
+  lds_barrier();
+  reinterpret_cast<int*>(s_v)[l] = fidx;
+  s_a[l] = fw;
+  lds_barrier();
+  const int srcl = M - N + (l < N ? l : 0);
+  idx_out = reinterpret_cast<int*>(s_v)[srcl];
+  w_out = s_a[srcl] / ftot;
+}
+
 // What a tree node does with its Gaussian: the extended-Kalman pair _predict / _condition_on
 // (inference.py:51-105) or the unscented pair (:146-174, :198-224) of speedy_unscented_agsf (:966-1156).
 template <int N, int M>
@@ -207,6 +353,7 @@ agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, A
   float* cdfbuf = carrybuf + carry_records * REC;  // [NT]               cumulative leaf weights
   float* wbuf = cdfbuf + NT;                     // [carry_records]      weights of the carried components
   float* red = wbuf + carry_records;             // [64]                 cross-wave scratch (NW > 1)
+  float* optbuf = red + 64;                      // [4 NT]               optimal_resampling_block's tables (NW > 1)
 
   // ---- the two standard-normal vectors of this leaf (same at every step: the reference's key is never advanced)
   float ez[N], es[N];
@@ -328,33 +475,7 @@ agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, A
         }
       }
     } else {
-      // the same Brent-Kung order over 64 NW leaves: wave up-sweep, scan of the wave totals, wave down-sweep
-      BF_UNROLL for (int d = 0; d < 6; ++d) {
-        const float o = __shfl_up(c, 1 << d, 64);
-        if (((lane + 1) & ((2 << d) - 1)) == 0) c += o;
-      }
-      lds_barrier();
-      if (lane == 63) red[16 + wave] = c;
-      lds_barrier();
-      float r = (lane < NW) ? red[16 + lane] : 0.f;
-      BF_UNROLL for (int d = 0; (1 << d) < NW; ++d) {
-        const float o = __shfl_up(r, 1 << d, 64);
-        if (lane < NW && ((lane + 1) & ((2 << d) - 1)) == 0) r += o;
-      }
-      BF_UNROLL for (int d = 4; d >= 1; --d) {
-        if ((1 << d) <= NW) {
-          const float o = __shfl_up(r, 1 << (d - 1), 64);
-          if (lane < NW && lane >= (1 << d) && ((lane + 1) & ((1 << d) - 1)) == (1 << (d - 1))) r += o;
-        }
-      }
-      const float mine = __shfl(r, wave, 64);
-      const float prev = __shfl(r, wave > 0 ? wave - 1 : 0, 64);
-      const float excl_wave = wave > 0 ? prev : 0.f;
-      if (lane == 63) c = mine;
-      BF_UNROLL for (int d = 6; d >= 1; --d) {
-        const float o = __shfl_up(c, 1 << (d - 1), 64);
-        if (((lane + 1) & ((1 << d) - 1)) == (1 << (d - 1))) c += (lane >= (1 << (d - 1))) ? o : excl_wave;
-      }
+      c = block_cumsum_assoc<NW>(c, red);  // the same Brent-Kung order over 64 NW leaves
     }
     lds_barrier();  // previous step's readers of leafbuf / cdfbuf are done
     cdfbuf[tid] = c;
@@ -372,6 +493,10 @@ agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, A
       const U32x2 kz = threefry_split(key0, key1, 0u, 2u);
       const U32x2 ko = threefry_split(kz.x, kz.y, 0u, 2u);
       optimal_resampling_lanes(w, l, MP, Mleaf, N0, ko.x, ko.y, idx, wnew);
+    } else if (NW > 1 && variant == 2) {
+      const U32x2 kz = threefry_split(key0, key1, 0u, 2u);
+      const U32x2 ko = threefry_split(kz.x, kz.y, 0u, 2u);
+      if constexpr (NW > 1) optimal_resampling_block<NW>(w, Mleaf, N0, ko.x, ko.y, optbuf, red, idx, wnew);
     } else if (l < N0) {
       const float* cd = cdfbuf + slot * MP;
       const float r = cd[Mleaf - 1] * (1.0f - udraw);
@@ -416,7 +541,7 @@ static inline int launch_agsf_geom(typename NODES::Arg arg, const bf_cstream* y,
   constexpr int REC = N + N * N;
   constexpr int NT = NW == 1 ? 256 : 64 * NW;
   const int carry_records = NW == 1 ? 256 : ((nc[0] + 3) & ~3);
-  const size_t lds_bytes = sizeof(float) * ((size_t)NT * REC + (size_t)carry_records * REC + NT + carry_records + 64);
+  const size_t lds_bytes = sizeof(float) * ((size_t)NT * REC + (size_t)carry_records * REC + NT + carry_records + 64 + (NW > 1 ? 4 * NT : 0));
   if (lds_bytes > 160 * 1024)
     return set_error(BF_EUNSUPPORTED, "augmented Gaussian-sum filter: %d leaves and %d components of dimension %d exceed the 160 KiB LDS",
                      nc[0] * nc[1] * nc[2], nc[0], N);
@@ -444,8 +569,6 @@ static inline int launch_agsf_nodes(typename NODES::Arg arg, const bf_cstream* y
     return set_error(BF_EUNSUPPORTED, "augmented Gaussian-sum filter: %lld leaves per trajectory exceed one workgroup (1024)", Mleaf);
   int MP = 1;
   while (MP < Mleaf) MP <<= 1;
-  if (variant == 2 && MP > 64)
-    return set_error(BF_EUNSUPPORTED, "optimal resampling sorts inside one wave: %lld leaves exceed 64", Mleaf);
   if (out->pred_means.ptr || out->pred_covs.ptr || out->coll_mean.ptr || out->coll_cov.ptr || out->loglik.ptr)
     return set_error(BF_EINVAL, "the augmented filter emits weights, means and covariances only (inference.py:771-775)");
 #define BF_GEOM(NW_) return launch_agsf_geom<N, M, NODES, NW_>(arg, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, variant, MP, d_tvq, d_tvr, stream)

@@ -467,7 +467,7 @@ def speedy_augmented_gaussian_sum_filter(params, emissions, num_components, rng_
     that holds ``'leaf_indices'`` (T, N0) when ``return_leaf_indices`` (the reference's per-step debugging
     outputs -- Deltas, Lambdas, Jacobians, gains -- are not materialised) and ``'carry'`` when
     ``return_carry``.  ``initial_means`` (N0, n) overrides the fixed ``MVN(m0, P0).sample(N0, PRNGKey(0))``
-    draw (:799).  N0 * N1 * N2 <= 64.
+    draw (:799).  N0 * N1 * N2 <= 64 in general, <= 1024 for state_dim <= 4 (one workgroup per trajectory).
     """
     torch = _torch()
     lib = _lib.require_gpu()
@@ -593,7 +593,7 @@ def augmented_gaussian_sum_filter_optimal(params, emissions, num_components, rng
 
 def optimal_resampling(weights, N: int, key, device="cuda"):
     """``utils.optimal_resampling(weights, N, key)`` (utils.py:216-244) on the device: weights (M,) or (B, M) with
-    M <= 64 -> (indices (N,), weights (N,)) or batched."""
+    M <= 1024 -> (indices (N,), weights (N,)) or batched."""
     torch = _torch()
     lib = _lib.require_gpu()
     w = _dev_f32(weights, device).contiguous()

@@ -223,7 +223,7 @@ int bf_ugsf_ukf_f32(const bf_model* model, const bf_ukf_params* uparams, const b
  * never advanced: the same normals at every step).  The carry holds N0 components per trajectory;
  * out: weights / means / covs with K = N0 (the other streams must be unset).  leaf_idx: optional
  * DEVICE int32 [B][T][N0], the leaf each carried component was drawn from.  N0*N1*N2 <= 64 in general,
- * <= 1024 for state_dim <= 4 (one workgroup per trajectory), <= 64 for variant 2.
+ * <= 1024 for state_dim <= 4 (one workgroup per trajectory; every variant).
  * variant: 0 = the speedy filter's two shared normal arrays (:672-688, :716-726); 1 = the branches of
  * augmented_gaussian_sum_filter (inference.py:458-620) through containers._branches_from_tree1/2
  * (containers.py:63-140): one key per node, jr.multivariate_normal per node, NaN samples replaced by the mean;
@@ -241,7 +241,7 @@ int bf_agsf_ukf_f32(const bf_model* model, const bf_ukf_params* uparams, const b
                     const bf_carry* carry, const bf_out_desc* out, int32_t* leaf_idx, int32_t variant, void* stream);
 
 /* utils.optimal_resampling(weights, N, key) (utils.py:216-244, Fearnhead & Clifford) for B weight vectors of
- * length M <= 64: d_weights [B][M] -> d_idx [B][N] (indices into the M particles), d_weights_out [B][N]. */
+ * length M <= 1024 (one wave segment per vector up to 64, one workgroup beyond): d_weights [B][M] -> d_idx [B][N] (indices into the M particles), d_weights_out [B][N]. */
 int bf_optimal_resample_f32(const float* d_weights, const uint32_t key[2], int64_t B, int32_t M, int32_t N, int32_t* d_idx,
                             float* d_weights_out, void* stream);
 

@@ -147,10 +147,12 @@ def test_unscented_nodes(which):
     _compare(post, aux, ref, _oracle_leaf_indices(raux["pre_weights"], nc[0]), tol=3e-5)
 
 
-@pytest.mark.parametrize("M,N", [(8, 3), (12, 4), (50, 2), (30, 5), (64, 8), (5, 5), (7, 1)])
+@pytest.mark.parametrize("M,N", [(8, 3), (12, 4), (50, 2), (30, 5), (64, 8), (5, 5), (7, 1),
+                                 (65, 64), (125, 5), (100, 10), (256, 3), (257, 17), (1000, 20), (1024, 1024)])
 def test_optimal_resampling_matches_oracle(M, N):
     """utils.optimal_resampling (utils.py:216-244) on the device: indices bit-exact, weights to fp32 rounding,
-    for flat, peaked and tied weight vectors."""
+    for flat, peaked and tied weight vectors.  More than 64 weights: one workgroup per vector (sort exchanges,
+    running sums and look-ups through LDS)."""
     bfa, nl = _nl()
     rng = np.random.default_rng(M * 100 + N)
     ws = [rng.dirichlet(np.ones(M)), rng.dirichlet(0.05 * np.ones(M)), np.ones(M) / M,
@@ -166,9 +168,11 @@ def test_optimal_resampling_matches_oracle(M, N):
     assert tuple(i1.shape) == (N,) and np.array_equal(i1.cpu().numpy(), idx[0].cpu().numpy())
 
 
-@pytest.mark.parametrize("nc", [(2, 5, 5), (4, 2, 3)])
+@pytest.mark.parametrize("nc", [(2, 5, 5), (4, 2, 3), (5, 5, 5), (3, 10, 10)])
 def test_optimal_variant(nc):
-    """augmented_gaussian_sum_filter_optimal (inference.py:1157-1300): unequal carried weights."""
+    """augmented_gaussian_sum_filter_optimal (inference.py:1157-1300): unequal carried weights.  [5, 5, 5] is the tree
+    of the reference's own test (docs/tests/test_inference.py:89-92): 125 leaves, one 256-thread workgroup per
+    trajectory; [3, 10, 10] needs 1024 threads."""
     bfa, nl = _nl()
     a = cm.cv_model_arrays()
     po, pp = cm.oracle_params(a), cm.product_params(a)

@@ -94,19 +94,19 @@ def test_augmented_gaussian_sum_filter():                                # :84-8
 
 
 def test_augmented_gaussian_sum_filter_optimal():                        # :89-92
+    """The reference's own tree, num_components = [5, 5, 5]: 125 leaves, one 256-thread workgroup per trajectory."""
     bfa, po, pp = _params(25e-6)
     ys = _data(bfa, pp)
-    post, aux = bfa.augmented_gaussian_sum_filter_optimal(pp, ys, [5, 2, 2], opt_args=(0.1, 0.1), inputs=INPUTS)
-    _finite_shapes(post, 5)                 # the reference's [5, 5, 5] is 125 leaves; one wave holds 64
+    post, aux = bfa.augmented_gaussian_sum_filter_optimal(pp, ys, [5, 5, 5], opt_args=(0.1, 0.1), inputs=INPUTS)
+    _finite_shapes(post, 5)
     bfa, po, pp = _params(1e-2)
     ys = _data(bfa, pp).cpu().numpy()
-    ref, raux = go.augmented_gaussian_sum_filter_optimal(po, ys, [5, 2, 2], opt_args=(0.1, 0.1), inputs=INPUTS.reshape(T, 1),
-                                                         debug=True)
-    post, aux = bfa.augmented_gaussian_sum_filter_optimal(pp, ys, [5, 2, 2], opt_args=(0.1, 0.1), inputs=INPUTS,
-                                                          return_leaf_indices=True)
-    assert np.array_equal(aux["leaf_indices"].cpu().numpy(), raux["leaf_indices"])
-    for k in ("means", "covariances"):
-        assert cm.rel_err(getattr(post, k).cpu().numpy(), getattr(ref, k)) < 5e-5, k
+    for nc in ([5, 5, 5], [5, 2, 2]):
+        ref, raux = go.augmented_gaussian_sum_filter_optimal(po, ys, nc, opt_args=(0.1, 0.1), inputs=INPUTS.reshape(T, 1), debug=True)
+        post, aux = bfa.augmented_gaussian_sum_filter_optimal(pp, ys, nc, opt_args=(0.1, 0.1), inputs=INPUTS, return_leaf_indices=True)
+        assert np.array_equal(aux["leaf_indices"].cpu().numpy(), raux["leaf_indices"]), nc
+        for k in ("means", "covariances"):
+            assert cm.rel_err(getattr(post, k).cpu().numpy(), getattr(ref, k)) < 5e-5, (nc, k)
 
 
 def test_unscented_gaussian_sum_filter():                                # :94-98
