@@ -25,6 +25,7 @@
 // increment, resampled flag) -- the full history of cfg4 is 4.6 TB and does not fit HBM.
 #pragma once
 #include <cstring>
+#include <cstdlib>
 #include "bf_common.hpp"
 #include "kf_math.hpp"
 #include "scan_common.hpp"
@@ -117,18 +118,25 @@ __device__ __forceinline__ void resample_indices(const float* wn, const bool* va
   const float total = cdf[NP - 1];
   float u_sys = 0.f;
   if (resampler == 1) u_sys = bits_to_unit(threefry_bits(kc.x, kc.y, 0u, 1u));
+  float r[PPT];
   BF_UNROLL for (int p = 0; p < PPT; ++p) {
     const uint32_t i = (uint32_t)(tid * PPT + p);
-    float r;
-    if (resampler == 1) r = (((float)i + u_sys) / (float)NP) * total;
-    else r = total * (1.0f - bits_to_unit(threefry_bits(kc.x, kc.y, valid[p] ? i : 0u, (uint32_t)NP)));
-    int lo = 0, hi = NP;  // first index with cdf[idx] >= r
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (cdf[mid] < r) lo = mid + 1; else hi = mid;
-    }
-    anc[p] = lo < NP - 1 ? lo : NP - 1;
+    if (resampler == 1) r[p] = (((float)i + u_sys) / (float)NP) * total;
+    else r[p] = total * (1.0f - bits_to_unit(threefry_bits(kc.x, kc.y, valid[p] ? i : 0u, (uint32_t)NP)));
   }
+  // first index with cdf[idx] >= r (searchsorted side='left').  The CDF is non-decreasing and the slots beyond NP hold
+  // its total (>= r), so the lower bound over the CAP = 2^k slots is the same index; found by the fixed-trip probe
+  // sequence below instead of a bisection loop per draw: no data-dependent branches, and the PPT searches of a thread
+  // advance together, so their LDS reads (random addresses, ~100 cycles each) overlap instead of queueing.
+  constexpr int CAP = 64 * NW * PPT;
+  int pos[PPT];
+  BF_UNROLL for (int p = 0; p < PPT; ++p) pos[p] = 0;
+  for (int step = CAP >> 1; step >= 1; step >>= 1) {
+    float probe[PPT];
+    BF_UNROLL for (int p = 0; p < PPT; ++p) probe[p] = cdf[pos[p] + step - 1];
+    BF_UNROLL for (int p = 0; p < PPT; ++p) pos[p] += (probe[p] < r[p]) ? step : 0;
+  }
+  BF_UNROLL for (int p = 0; p < PPT; ++p) anc[p] = pos[p] < NP - 1 ? pos[p] : NP - 1;
 }
 
 // NaN-propagating maximum (jnp.max semantics)
@@ -225,6 +233,12 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
       const uint32_t i = valid[p] ? (uint32_t)(tid * PPT + p) : 0u;
       const U32x2 ki = threefry_split(k0, k1, i + 1u, (uint32_t)NP + 1u);
       float q[DQ], xn[N];
+      // the model is re-read (scalar loads through the constant cache) for every particle instead of being held: hoisted
+      // out of the time loop its matrices occupy several hundred scalar registers, which spill through vector lanes and
+      // from there to scratch (1024 x 4 geometry: 492 -> 82 spilled VGPRs, 52 -> 42 ms at cfg4's shape, B = 1024, T = 100)
+      int zoff = 0;
+      asm volatile("" : "+s"(zoff));
+      const BpfModel<N, DQ, M>& mdl = mdlp[zoff];
       draw_dynamics_noise<N, DQ, M>(mdl, ki, q);
       dyn_value<N, DQ, M>(mdl, x[p], q, u0, xn);
       BF_UNROLL for (int d = 0; d < N; ++d) x[p][d] = xn[d];
@@ -254,9 +268,16 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
       // ---- utils.py:207-214: keys = split(key, 2); idx = choice(keys[0], N, (N,), p = w); next_key = keys[1]
       const U32x2 kc = threefry_split(nk.x, nk.y, 0u, 2u);
       const U32x2 kn = threefry_split(nk.x, nk.y, 1u, 2u);
-      resample_indices<PPT, NW>(wn, valid, NP, kc, resampler, cdf, red, anc);
-      // gather through LDS, DCH dimensions per pass
-      BF_UNROLL for (int d0 = 0; d0 < N; d0 += DCH) {
+      // gather through LDS, DCH dimensions per pass.  The first pass is staged BEFORE the ancestors are drawn: those
+      // DCH x PPT state registers are then dead while the CDF, the uniforms and the searches run (the 128-VGPR geometry
+      // spilled them to scratch and reloaded them here)
+      lds_barrier();
+      BF_UNROLL for (int p = 0; p < PPT; ++p) BF_UNROLL for (int d = 0; d < DCH; ++d)
+          if (d < N) tile[d * CAP + tid * PPT + p] = x[p][d];
+      resample_indices<PPT, NW>(wn, valid, NP, kc, resampler, cdf, red, anc);  // (its barriers publish the tile)
+      BF_UNROLL for (int p = 0; p < PPT; ++p) BF_UNROLL for (int d = 0; d < DCH; ++d)
+          if (d < N) x[p][d] = tile[d * CAP + anc[p]];
+      BF_UNROLL for (int d0 = DCH; d0 < N; d0 += DCH) {
         lds_barrier();
         BF_UNROLL for (int p = 0; p < PPT; ++p) BF_UNROLL for (int d = 0; d < DCH; ++d)
             if (d0 + d < N) tile[d * CAP + tid * PPT + p] = x[p][d0 + d];
@@ -365,12 +386,13 @@ static inline int launch_bpf_dims(const bf_bpf_model* bp, const bf_cstream* y, c
   else if (NP <= 256) rc = launch_bpf_cfg<N, DQ, M, 1, 4>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
   else if (NP <= 1024) rc = launch_bpf_cfg<N, DQ, M, 1, 16>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
   else if (NP <= 4096) {
-    // two geometries for the largest capacity: 1024 threads x 4 particles (128-VGPR budget, variant 0) or
-    // 512 threads x 8 particles (256-VGPR budget, variant 1, the default).  With the canonical arithmetic of
-    // bf_canon_math.hpp (explicit log / exp / IEEE sqrt instead of single hardware instructions) the 128-VGPR geometry
-    // spills (465 VGPRs to scratch): measured at cfg4's shape, B = 1024, T = 200: 1024 x 4 = 97 ms, 512 x 8 = 88 ms
-    // (round 1, hardware transcendentals: 1024 x 4 was the faster one).  Out-of-line erf_inv and opaque model pointers
-    // cut the spills but lose more in calls and reloads (105 / 125 ms).
+    // two geometries for the largest capacity: 1024 threads x 4 particles (128-VGPR budget, variant 0, the default) or
+    // 512 threads x 8 particles (256-VGPR budget, variant 1).  Measured at cfg4's shape (B = 1024, T = 100, every step
+    // resamples): 1024 x 4 = 41.9 ms, 512 x 8 = 50.8 ms; without the per-particle re-read of the model (see the kernel)
+    // 52.3 / 44.4 ms -- the 128-VGPR geometry was the one that spilled.  Of the 42 ms, 29 are propagation + weights
+    // (ess_threshold = 0) and 13 the resampling branch, two thirds of it the two gather passes through the LDS tile
+    // (scripts/bpf_probe.py).  A rolled particle loop (registers rotated by one particle per trip, 16 KB of code instead
+    // of 130 KB) is slower, 44 / 78 ms: the unrolled trips overlap each other's dependent Threefry / erf_inv chains.
     if (g_bpf_variant == 1) rc = launch_bpf_cfg<N, DQ, M, 8, 8>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
     else rc = launch_bpf_cfg<N, DQ, M, 4, 16>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
   }

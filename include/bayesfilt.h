@@ -132,7 +132,7 @@ int bf_device_count(void);
  *   "gsf_structured": 1 (default) lets bf_gsf_ekf_f32 use the structure-aware kernel instances
  *                   (banded Lorenz-96 Jacobian, selection emission) when the model qualifies;
  *                   0 forces the dense generic instances.
- *   "bpf_variant":  workgroup geometry of the 4096-particle instance: 1 (default) = 512 threads x 8 particles, 0 = 1024 x 4.
+ *   "bpf_variant":  workgroup geometry of the 4096-particle instance: 0 (default) = 1024 threads x 4 particles, 1 = 512 x 8.
  *   "bpf_hbm_mode": particle counts beyond the in-register capacities: 0 (default) = choose by batch
  *                   size, 1 = one workgroup per trajectory, 2 = one workgroup per 1024-particle chunk
  *                   (six launches per step; same results bit for bit). */

@@ -15,7 +15,7 @@ for rep in range(int(os.environ.get("PREP", 4))):
     _lib.require_gpu().bf_set_option(b"bpf_variant", rep % 2)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    out = bfa.bootstrap_particle_filter(p, y, N, np.array([0, 1], np.uint32), output="summary")
+    out = bfa.bootstrap_particle_filter(p, y, N, np.array([0, 1], np.uint32), None, float(os.environ.get("PESS", 0.5)), resampler=os.environ.get("PRES", "multinomial"), output="summary")
     e.record(); torch.cuda.synchronize()
     ms = s.elapsed_time(e)
     print(f"variant={rep % 2} B={B} T={T} N={N}: {ms:8.2f} ms  {B*T/ms/1e3:8.3f} Mstep/s  {B*T*N/ms/1e6:8.2f} G particle-steps/s  resampled {out['resampled'].mean().item():.2f}", flush=True)
