@@ -25,6 +25,7 @@
 // increment, resampled flag) -- the full history of cfg4 is 4.6 TB and does not fit HBM.
 #pragma once
 #include <cstring>
+#include <type_traits>
 #include <cstdlib>
 #include "bf_common.hpp"
 #include "kf_math.hpp"
@@ -139,6 +140,45 @@ __device__ __forceinline__ void resample_indices(const float* wn, const bool* va
   BF_UNROLL for (int p = 0; p < PPT; ++p) anc[p] = pos[p] < NP - 1 ? pos[p] : NP - 1;
 }
 
+// Sum over the 64 lanes of a wave, total in lane 63: six DPP adds on the vector ALU (quad permutes, rotations inside the
+// 16-lane rows, the two row broadcasts) instead of six ds_bpermute round trips through the LDS crossbar.  Not the
+// adjacent-pair tree order: for sums whose rounding is not pinned by the oracle (the weighted-mean summary).
+__device__ __forceinline__ float wave_sum_dpp_lane63(float v) {
+  auto dpp = [](float x, auto ctrl, auto rowmask) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value,
+                                                                 decltype(rowmask)::value, 0xf, false));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{});   // quad_perm [1, 0, 3, 2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{});   // quad_perm [2, 3, 0, 1]
+  v += dpp(v, std::integral_constant<int, 0x124>{}, std::integral_constant<int, 0xf>{});  // row_ror:4
+  v += dpp(v, std::integral_constant<int, 0x128>{}, std::integral_constant<int, 0xf>{});  // row_ror:8
+  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});  // row_bcast:15 into rows 1, 3
+  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});  // row_bcast:31 into rows 2, 3
+  return v;
+}
+
+// The adjacent-pair tree over the 64 lanes of a wave, result in lane 63, on the vector ALU: the xor-butterfly's partners
+// at distance 1, 2, 4, 8 are reached by quad permutes and the two row mirrors (each lane of a finished group holds the
+// group's value, so any lane of the neighbouring group serves), the rows by the two row broadcasts.  op is commutative
+// (float add, nanmax), so the bits are those of the butterfly -- without its six trips through the LDS crossbar.
+template <class OP>
+__device__ __forceinline__ float wave_tree_dpp_lane63(float v, OP op) {
+  auto dpp = [](float x, auto ctrl, auto rowmask, float keep) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep), __builtin_bit_cast(int, x),
+                                                                 decltype(ctrl)::value, decltype(rowmask)::value, 0xf, false));
+  };
+  v = op(v, dpp(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{}, v));   // quad_perm [1, 0, 3, 2]
+  v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{}, v));   // quad_perm [2, 3, 0, 1]
+  v = op(v, dpp(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{}, v));  // row_half_mirror
+  v = op(v, dpp(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{}, v));  // row_mirror
+  // rows 1 and 3 take the total of rows 0 and 2; then row 3 takes that of row 1 (the other rows keep what they have)
+  const float r15 = dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{}, v);
+  v = ((threadIdx.x >> 4) & 1) ? op(v, r15) : v;
+  const float r31 = dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{}, v);
+  v = ((threadIdx.x & 63) >= 48) ? op(v, r31) : v;
+  return v;
+}
+
 // NaN-propagating maximum (jnp.max semantics)
 __device__ __forceinline__ float nanmax(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); }
 
@@ -163,14 +203,16 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
 
   // ---- workgroup reductions in the oracle's adjacent-pair tree order
   auto block_reduce = [&](float v, auto op) {  // v already reduced over the thread's own slots
-    BF_UNROLL for (int off = 1; off < 64; off <<= 1) v = op(v, __shfl_xor(v, off, 64));
+    v = wave_tree_dpp_lane63(v, op);
     if constexpr (NW > 1) {
       lds_barrier();
-      if (lane == 0) red[wave] = v;
+      if (lane == 63) red[wave] = v;
       lds_barrier();
       float r = (lane < NW) ? red[lane] : red[0];
       BF_UNROLL for (int off = 1; off < NW; off <<= 1) r = op(r, __shfl_xor(r, off, 64));
       v = __shfl(r, 0, 64);
+    } else {
+      v = __shfl(v, 63, 64);
     }
     return v;
   };
@@ -269,21 +311,49 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
       const U32x2 kc = threefry_split(nk.x, nk.y, 0u, 2u);
       const U32x2 kn = threefry_split(nk.x, nk.y, 1u, 2u);
       // gather through LDS, DCH dimensions per pass.  The first pass is staged BEFORE the ancestors are drawn: those
-      // DCH x PPT state registers are then dead while the CDF, the uniforms and the searches run (the 128-VGPR geometry
-      // spilled them to scratch and reloaded them here)
+      // DCH x PPT state registers are then dead while the CDF, the uniforms and the searches run.
+      // Tile layout: one record of DCH floats per particle, particle i = tid * PPT + p at record p * NT + tid -- the
+      // lanes of a wave write consecutive records (16-byte stores, every bank once per 8 lanes), and a drawn ancestor is
+      // fetched as DCH / 4 16-byte reads instead of DCH dword reads DCH banks apart.  (Dimensions that are not multiples
+      // of four keep the dimension-major dword layout.)
+      constexpr bool VEC = (DCH % 4 == 0) && (N % 4 == 0);
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      auto put = [&](int d0) __attribute__((always_inline)) {
+        if constexpr (VEC) {
+          f32x4* t4 = reinterpret_cast<f32x4*>(tile);
+          BF_UNROLL for (int p = 0; p < PPT; ++p) BF_UNROLL for (int v = 0; v < DCH / 4; ++v)
+              if (d0 + 4 * v < N)
+                t4[(p * NT + tid) * (DCH / 4) + v] = f32x4{x[p][d0 + 4 * v], x[p][d0 + 4 * v + 1], x[p][d0 + 4 * v + 2], x[p][d0 + 4 * v + 3]};
+        } else {
+          BF_UNROLL for (int p = 0; p < PPT; ++p) BF_UNROLL for (int d = 0; d < DCH; ++d)
+              if (d0 + d < N) tile[d * CAP + tid * PPT + p] = x[p][d0 + d];
+        }
+      };
+      auto get = [&](int d0) __attribute__((always_inline)) {
+        if constexpr (VEC) {
+          const f32x4* t4 = reinterpret_cast<const f32x4*>(tile);
+          BF_UNROLL for (int p = 0; p < PPT; ++p) {
+            const int rec = (anc[p] % PPT) * NT + anc[p] / PPT;
+            BF_UNROLL for (int v = 0; v < DCH / 4; ++v)
+                if (d0 + 4 * v < N) {
+                  const f32x4 t = t4[rec * (DCH / 4) + v];
+                  x[p][d0 + 4 * v] = t.x; x[p][d0 + 4 * v + 1] = t.y; x[p][d0 + 4 * v + 2] = t.z; x[p][d0 + 4 * v + 3] = t.w;
+                }
+          }
+        } else {
+          BF_UNROLL for (int p = 0; p < PPT; ++p) BF_UNROLL for (int d = 0; d < DCH; ++d)
+              if (d0 + d < N) x[p][d0 + d] = tile[d * CAP + anc[p]];
+        }
+      };
       lds_barrier();
-      BF_UNROLL for (int p = 0; p < PPT; ++p) BF_UNROLL for (int d = 0; d < DCH; ++d)
-          if (d < N) tile[d * CAP + tid * PPT + p] = x[p][d];
+      put(0);
       resample_indices<PPT, NW>(wn, valid, NP, kc, resampler, cdf, red, anc);  // (its barriers publish the tile)
-      BF_UNROLL for (int p = 0; p < PPT; ++p) BF_UNROLL for (int d = 0; d < DCH; ++d)
-          if (d < N) x[p][d] = tile[d * CAP + anc[p]];
+      get(0);
       BF_UNROLL for (int d0 = DCH; d0 < N; d0 += DCH) {
         lds_barrier();
-        BF_UNROLL for (int p = 0; p < PPT; ++p) BF_UNROLL for (int d = 0; d < DCH; ++d)
-            if (d0 + d < N) tile[d * CAP + tid * PPT + p] = x[p][d0 + d];
+        put(d0);
         lds_barrier();
-        BF_UNROLL for (int p = 0; p < PPT; ++p) BF_UNROLL for (int d = 0; d < DCH; ++d)
-            if (d0 + d < N) x[p][d0 + d] = tile[d * CAP + anc[p]];
+        get(d0);
       }
       BF_UNROLL for (int p = 0; p < PPT; ++p) w[p] = valid[p] ? 1.0f / (float)NP : 0.f;
       k0 = kn.x;
@@ -306,11 +376,10 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
       BF_UNROLL for (int d = 0; d < N; ++d) {
         float s = 0.f;
         BF_UNROLL for (int p = 0; p < PPT; ++p) s = fmaf(w[p], x[p][d], s);
-        BF_UNROLL for (int off = 1; off < 64; off <<= 1) s += __shfl_xor(s, off, 64);
-        part[d] = s;
+        part[d] = wave_sum_dpp_lane63(s);
       }
       lds_barrier();
-      if (lane == 0) BF_UNROLL for (int d = 0; d < N; ++d) tile[wave * N + d] = part[d];
+      if (lane == 63) BF_UNROLL for (int d = 0; d < N; ++d) tile[wave * N + d] = part[d];
       lds_barrier();
       if (tid < N) {
         float s = 0.f;
