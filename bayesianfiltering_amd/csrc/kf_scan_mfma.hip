@@ -481,6 +481,9 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
 //   * the serial phase's elimination steps are packed (v_pk_fma_f32 on (row entry, right-hand-side entry) pairs):
 //     2 295 -> 1 668 vector instructions in chol_w_rows, which is issue bound (4 cycles per wave64 instruction);
 //   * roles placed by the hardware's wave placement rather than by blockIdx (+1 %, see the kernel).
+// Tried and measured flat or worse: a half-step start offset for the second workgroup of a CU (0 %); s_setprio 3 around
+// the factorization (-2 %); dropping the log-likelihood factorization altogether as an upper bound for deriving it from
+// the jittered factor by the matrix determinant lemma (0 %: that wave is not on the critical path).
 // Phase timers (scripts/mfma_phase_probe.py, us per step): alone on its CU a workgroup takes 9.9 (A 1.3, S 1.1,
 // factorization + W 3.6, H 1.0, I 1.5, J 1.3); with a second workgroup on the CU 14.1 per workgroup, i.e. 7.0 per step and
 // CU: the factorization stretches to 6.3 beside the other workgroup's phases although neither the vector nor the matrix
