@@ -229,11 +229,16 @@ def make_kalman64(args, rank, world, device):
         c = st["carry"]
         return float((torch.isfinite(c.means.reshape(B, n)).all(dim=1) & torch.isfinite(c.covariances.reshape(B, n * n)).all(dim=1)).float().mean())
 
-    bps, fl = 4 * m + 4 * (1 + 2 * n + 2 * n * n), 512 * 4096   # 512 v_mfma_f32_32x32x2_f32 per step x 4096 flop
+    # algorithmic flop per step of the reference's formulation (2 n^3 x 2 predict, H P, S, the gain solve,
+    # K S K^T ~ 2.0e6); the kernel executes 452 v_mfma_f32_32x32x2_f32 (1.85e6) plus a ~2 900-instruction vector Cholesky
+    bps, fl = 4 * m + 4 * (1 + 2 * n + 2 * n * n), 2.0e6
     return dict(kernels=kernels, summary=summary, finite=finite, units=B * T, total_units=Bt * T, scaling="strong", gather_rows=Bt,
                 roofline=lambda ms: {"bound": "mfma", "achieved": fl * B * T / (ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFS, "unit": "TFLOP/s",
-                                     "kernel": "kf_scan_mfma_kernel<64,32>", "flop_per_step": fl, "bytes_per_step": bps,
-                                     "hbm_GBs": bps * B * T / (ms * 1e-3) / 1e9},
+                                     "kernel": "kf_scan_mfma2_kernel<64,32,2>", "flop_per_step": fl, "bytes_per_step": bps,
+                                     "hbm_GBs": bps * B * T / (ms * 1e-3) / 1e9,
+                                     "note": "fp32 MFMA and fp32 vector instructions share ONE datapath per SIMD on gfx950 "
+                                             "(profiles/r02_f32_pipe_probe.txt: two waves' MFMA and v_fma streams take the sum of their "
+                                             "times); per step the kernel needs ~13.3 us of MFMA + ~7 us of vector SIMD-time over 4 SIMDs"},
                 workload=f"Kalman filter state_dim=64 obs_dim=32 T={T} batch={Bt}, FULL5 in T-chunks of {Tc}, fp32 MFMA path, "
                          "observations drawn from the model",
                 extra={"batch_total": Bt, "batch_this_rank": B, "T": T})
