@@ -128,7 +128,7 @@ int bf_set_option(const char* name, int value) {
     return BF_OK;
   }
   if (name && std::strcmp(name, "kf_mfma_variant") == 0) {
-    if (value < 1 || value > 4) return bf::set_error(BF_EINVAL, "kf_mfma_variant must be 1, 2, 3 or 4");
+    if (value < 1 || value > 5) return bf::set_error(BF_EINVAL, "kf_mfma_variant must be 1 ... 5");
     bf::g_kf_mfma_variant = value;
     return BF_OK;
   }

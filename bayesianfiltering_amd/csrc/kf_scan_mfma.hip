@@ -28,6 +28,7 @@
 // conditioned S of a filter (the parity budget is 1e-5); the log-likelihood uses the Cholesky
 // factor of the un-jittered S exactly like the reference (inference.py:104, :24).
 #include <cstdlib>
+#include <cstring>
 #include "bf_common.hpp"
 #include "kf_math.hpp"
 #include "lane_group.hpp"
@@ -35,10 +36,10 @@
 
 namespace bf {
 
-static int mfma_variant_default() {  // BAYESFILT_MFMA_VARIANT=1..4 overrides the default for A/B runs of unmodified programs
+static int mfma_variant_default() {  // BAYESFILT_MFMA_VARIANT=1..5 overrides the default for A/B runs of unmodified programs
   const char* e = std::getenv("BAYESFILT_MFMA_VARIANT");
   const int v = e ? std::atoi(e) : 2;
-  return (v >= 1 && v <= 4) ? v : 2;
+  return (v >= 1 && v <= 5) ? v : 2;
 }
 std::atomic<int> g_kf_mfma_variant{mfma_variant_default()};  // bf_set_option "kf_mfma_variant": 2 = gain-free update, factorization in VALU registers (default); 3 = factorization by rank-2 MFMAs; 4 = variant 2 at three workgroups per CU (A in registers); 1 = round 1's kernel
 
@@ -51,6 +52,7 @@ using lds_f4 = const __attribute__((address_space(3))) v4f;
 template <int N, int M>
 struct MfmaConst {  // device-resident (too large for kernel arguments)
   float A[N * N], H[M * N], GQG[N * N], DRD[M * M], Gq0[N], Dr0[M];
+  unsigned short A3[3][N * N], H3[3][M * N];  // variant 5: A = A3[0] + A3[1] + A3[2] exactly, three bf16 terms (row-major)
 };
 
 __device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) {
@@ -518,14 +520,45 @@ __device__ __forceinline__ float rdlane_u(float v, int l) {  // v_readlane_b32: 
 // elimination step is one v_pk_fma_f32 on (a[k], w[k]) with the broadcast multiplier as its scalar operand -- the same
 // fmas in the same order as the unpacked form, half the instructions.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __attribute__((noinline)) void chol_w_rows(lds_f* sc, lds_f* sT, lds_f* sv, lds_f* mcur, lds_f* mnxt, lds_f* scv,
-                                                      int lane) {
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+using lds_u32x2 = __attribute__((address_space(3))) u32x2;
+using lds_u32x4 = __attribute__((address_space(3))) u32x4;
+using lds_c = __attribute__((address_space(3))) char;
+
+// x0, x1 -> three packed pairs of bf16 (round to nearest even, v_cvt_pk_bf16_f32) with x = hi + mid + lo EXACTLY: the
+// residual of a 24-bit significand after an 8-bit term has at most 16 bits, after two terms at most 8.
+struct Split3 {
+  unsigned hi, mid, lo;
+};
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ float bf_lo(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
+__device__ __forceinline__ float bf_hi(unsigned pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
+__device__ __forceinline__ Split3 split_pair(float x0, float x1) {
+  Split3 o;
+  o.hi = pk_bf16(x0, x1);
+  const float r0 = x0 - bf_lo(o.hi), r1 = x1 - bf_hi(o.hi);
+  o.mid = pk_bf16(r0, r1);
+  const float q0 = r0 - bf_lo(o.mid), q1 = r1 - bf_hi(o.mid);
+  o.lo = pk_bf16(q0, q1);
+  return o;
+}
+
+// BF = false: W (fp32) -> sT rows 32..63.  BF = true (variant 5): W^T as three bf16 terms, wt[p][lane][k], 80-byte rows.
+template <bool BF>
+__device__ __forceinline__ void chol_w_rows_impl(lds_f* sc, lds_f* sT, lds_f* sv, lds_f* mcur, lds_f* mnxt, lds_f* scv,
+                                                 lds_c* wt, int lane) {
   constexpr int PP = 65, PS = 33;
   const int r = lane & 31;
   f32x2 aw[32];  // .x: row r of S + 1e-6 (psd_solve's jitter on every entry, utils.py:258); .y: column `lane` of H P
   BF_UNROLL for (int k = 0; k < 32; ++k) aw[k] = f32x2{sc[r * PS + k] + 1e-6f, sT[k * PP + lane]};
   f32x2 rgz = f32x2{1.0f, sv[r]};  // residuals of g = L^-1 1, z = L^-1 v (row r)
   f32x2 acc_cm = f32x2{0.f, 0.f};  // (W^T g)[lane], (W^T z)[lane]
+  Split3 wsp[4];
   static_for<0, 32>([&](auto J) {
     constexpr int j = decltype(J)::value;
     const float rinv = rsqrt_newton(rdlane_u(aw[j].x, j));            // 1 / L[j][j], wave-uniform
@@ -550,15 +583,43 @@ __device__ __attribute__((noinline)) void chol_w_rows(lds_f* sc, lds_f* sT, lds_
       });
       __builtin_amdgcn_sched_barrier(0);
     });
+    // variant 5: rows j - 1, j of W are final; their bf16 terms are formed here, in the issue gaps of the dependent
+    // chain (the loop runs at ~55 % of the issue rate), and go out eight rows per 16-byte store
+    if constexpr (BF && (j & 1)) {
+      wsp[(j >> 1) & 3] = split_pair(aw[j - 1].y, aw[j].y);
+      if constexpr ((j & 7) == 7) {
+        constexpr int q = j >> 3;
+        *reinterpret_cast<lds_u32x4*>(wt + 0 * 5120 + lane * 80 + q * 16) = u32x4{wsp[0].hi, wsp[1].hi, wsp[2].hi, wsp[3].hi};
+        *reinterpret_cast<lds_u32x4*>(wt + 1 * 5120 + lane * 80 + q * 16) = u32x4{wsp[0].mid, wsp[1].mid, wsp[2].mid, wsp[3].mid};
+        *reinterpret_cast<lds_u32x4*>(wt + 2 * 5120 + lane * 80 + q * 16) = u32x4{wsp[0].lo, wsp[1].lo, wsp[2].lo, wsp[3].lo};
+      }
+    }
   });
-  BF_UNROLL for (int i = 0; i < 32; ++i) sT[(32 + i) * PP + lane] = aw[i].y;
+  if constexpr (!BF) {
+    BF_UNROLL for (int i = 0; i < 32; ++i) sT[(32 + i) * PP + lane] = aw[i].y;
+  }
   scv[lane] = acc_cm.x * 1e-3f;                            // sqrt(1e-6) (W^T g): enters P+ as + c c^T
   mnxt[lane] = mcur[lane] + acc_cm.y;                      // filtered mean
+}
+#ifndef BF_V5_INLINE
+#define BF_V5_INLINE 0
+#endif
+#ifndef BF_V5_HOP_RELOAD
+#define BF_V5_HOP_RELOAD 0
+#endif
+__device__ __attribute__((noinline)) void chol_w_rows_bf(lds_f* sc, lds_f* sT, lds_f* sv, lds_f* mcur, lds_f* mnxt, lds_f* scv, lds_c* wt,
+                                                         int lane) {
+  chol_w_rows_impl<true>(sc, sT, sv, mcur, mnxt, scv, wt, lane);
+}
+// out of line for variants 2 / 4 (a register allocation of its own); variant 5 inlines the body (it holds 112 operand
+// registers across the factorization, which a call would spill and reload)
+__device__ __attribute__((noinline)) void chol_w_rows(lds_f* sc, lds_f* sT, lds_f* sv, lds_f* mcur, lds_f* mnxt, lds_f* scv, int lane) {
+  chol_w_rows_impl<false>(sc, sT, sv, mcur, mnxt, scv, nullptr, lane);
 }
 
 // wave 2: chol(S) (no jitter), z = L^-1 v, log N(v; 0, S) -- inference.py:104, :24
 // Packed like chol_w_rows, here two neighbouring entries of the row per register pair and two broadcasts per scalar pair.
-__device__ __attribute__((noinline)) float chol_loglik_rows(lds_f* sc, lds_f* sv, int lane) {
+__device__ __forceinline__ float chol_loglik_rows_impl(lds_f* sc, lds_f* sv, int lane) {
   constexpr int PS = 33;
   const int r = lane & 31;
   f32x2 ap[16];  // (a[2 i], a[2 i + 1]) of row r
@@ -596,6 +657,8 @@ __device__ __attribute__((noinline)) float chol_loglik_rows(lds_f* sc, lds_f* sv
   // -sum log L_jj = log prod (1 / L_jj) (32 factors of O(1) stay in range)
   return -0.5f * quad - 0.5f * 32.0f * 1.8378770664093453f + fast_log(rprod);
 }
+
+__device__ __attribute__((noinline)) float chol_loglik_rows(lds_f* sc, lds_f* sv, int lane) { return chol_loglik_rows_impl(sc, sv, lane); }
 
 // ---- Variant 3: the factorization itself on the matrix cores.  In the accumulator layout of the 32x32 MFMA shapes a
 // lane holds 16 entries of ONE column of S; S is symmetric, so register r_j of the 32 lanes of half h_j (j = r & 3 +
@@ -998,6 +1061,283 @@ kf_scan_mfma2_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
 #endif
 }
 
+// =======================================================================================================================
+// Variant 5: the five matrix products off the fp32 datapath.  On gfx950 v_mfma_f32_32x32x2_f32 and the fp32 vector
+// instructions share ONE datapath per SIMD (profiles/r02_f32_pipe_probe.txt), so the fp32 products (13.3 us of the
+// 20.4 us of SIMD-time a step needs) cannot hide behind the factorization.  v_mfma_f32_32x32x16_bf16 runs at 16x the
+// rate; with every operand written as the EXACT sum of three bf16 terms (x = hi + mid + lo: 8 + 8 + 8 significand bits)
+// and the six cross terms of weight >= 2^-16 accumulated in fp32, a product costs 6/16 of the fp32 MFMA time at the same
+// rounding (scripts/probes/bf16x3_check.hip: 9.3e-8 of sum |terms| against 1.1e-7 for the fp32 MFMA).
+//
+// Layouts.  The bf16 MFMA wants 8 consecutive k per lane for both operands: A-operand X[m][k] row-major, B-operand as
+// Yt[n][k] = Y[k][n].  An accumulator tile holds, per lane, one column and four groups of four consecutive rows, so its
+// cheap store is the TRANSPOSED one, T[col][row] (8-byte stores of 4 terms): stored that way a result Z serves as the
+// A-operand of Z^T . and as the B-operand of . Z.  The products are arranged so that nothing else is ever needed:
+//   A   Z = (H P-)^T = P-^T H^T        A-op: P- as stored (J), B-op: H (registers)          -> Z stored; H P also fp32
+//   B   S^T = H Z                       A-op: H (registers),    B-op: Z as stored
+//   C   factorizations as in variant 2; W^T written as bf16 terms row-major (each lane owns a column of W)
+//   H   P+ = P- - W^T W + c c^T         A-op: -W^T, B-op: W^T (the same array); P- from the accumulators of J
+//   I   Y^T = (A P+)^T = P+^T A^T       A-op: P+ as stored (H), B-op: A rows (registers)    -> Y^T stored
+//   J   P- = Y A^T + G Q G^T            A-op: Y^T as stored (I) = Y row-major, B-op: A rows (registers)
+// A and H live in registers as bf16 terms (2 x 48 VGPRs per wave); the matrix-vector products rebuild their fp32
+// values from the terms (hi + mid + lo is exact).  LDS: 72.8 KB per workgroup, two workgroups per CU.
+__device__ __forceinline__ f32x16 mfma_bf6(const u32x4* a, const u32x4* b, f32x16 c) {  // smallest cross terms first
+  auto m = [](u32x4 x, u32x4 y, f32x16 acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), acc, 0, 0, 0);
+  };
+  c = m(a[1], b[1], c);
+  c = m(a[0], b[2], c);
+  c = m(a[2], b[0], c);
+  c = m(a[0], b[1], c);
+  c = m(a[1], b[0], c);
+  c = m(a[0], b[0], c);
+  return c;
+}
+// accumulator tile (row tile rt, column tile ct) -> dst[term][32 ct + col][32 rt + row] as bf16 terms, `pitch` bytes per column
+__device__ __forceinline__ void store_terms_transposed(lds_c* dst, int term_bytes, int pitch, int rt, int ct, int lane, const f32x16& acc) {
+  const int lr = lane & 31, lk = lane >> 5;
+  lds_c* base = dst + (32 * ct + lr) * pitch + (32 * rt + 4 * lk) * 2;
+  BF_UNROLL for (int g = 0; g < 4; ++g) {  // rows 8 g + 4 lk + 0..3 of the tile
+    const Split3 a = split_pair(acc[4 * g], acc[4 * g + 1]), b = split_pair(acc[4 * g + 2], acc[4 * g + 3]);
+    *reinterpret_cast<lds_u32x2*>(base + 16 * g) = u32x2{a.hi, b.hi};
+    *reinterpret_cast<lds_u32x2*>(base + term_bytes + 16 * g) = u32x2{a.mid, b.mid};
+    *reinterpret_cast<lds_u32x2*>(base + 2 * term_bytes + 16 * g) = u32x2{a.lo, b.lo};
+  }
+}
+__device__ __forceinline__ void load_terms(u32x4* dst, const lds_c* arr, int term_bytes, int pitch, int row, int chunk, int lk) {
+  const lds_c* p = arr + row * pitch + (16 * chunk + 8 * lk) * 2;
+  BF_UNROLL for (int t = 0; t < 3; ++t) dst[t] = *reinterpret_cast<const lds_u32x4*>(p + t * term_bytes);
+}
+// sum_k X[row][k] v[k] over the lane's 32 k (16 c + 8 lk + 0..7) from the register terms of X
+__device__ __forceinline__ float dot_terms(const u32x4 (*x)[4], const float* v, int lk) {
+  float s = 0.f;
+  BF_UNROLL for (int c = 0; c < 4; ++c) BF_UNROLL for (int d = 0; d < 4; ++d) {
+    const float x0 = (bf_lo(x[0][c][d]) + bf_lo(x[1][c][d])) + bf_lo(x[2][c][d]);
+    const float x1 = (bf_hi(x[0][c][d]) + bf_hi(x[1][c][d])) + bf_hi(x[2][c][d]);
+    s = fmaf(x0, v[16 * c + 8 * lk + 2 * d], s);
+    s = fmaf(x1, v[16 * c + 8 * lk + 2 * d + 1], s);
+  }
+  return s;
+}
+
+// the same over half of the k range (chunks 2 h, 2 h + 1)
+__device__ __forceinline__ float dot_terms_half(const u32x4 (*x)[4], const float* v, int lk, int h) {
+  float s = 0.f;
+  BF_UNROLL for (int cc = 0; cc < 2; ++cc) BF_UNROLL for (int d = 0; d < 4; ++d) {
+    const u32x4 x0v = h ? x[0][2 + cc] : x[0][cc], x1v = h ? x[1][2 + cc] : x[1][cc], x2v = h ? x[2][2 + cc] : x[2][cc];
+    const float x0 = (bf_lo(x0v[d]) + bf_lo(x1v[d])) + bf_lo(x2v[d]);
+    const float x1 = (bf_hi(x0v[d]) + bf_hi(x1v[d])) + bf_hi(x2v[d]);
+    const int k = 16 * (2 * h + cc) + 8 * lk + 2 * d;
+    s = fmaf(x0, v[k], s);
+    s = fmaf(x1, v[k + 1], s);
+  }
+  return s;
+}
+
+template <int N, int M>
+__global__ void __launch_bounds__(256, 2)
+kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView carry, OutViews out, long long B, long long T,
+                     int rot_mode) {
+  static_assert(N == 64 && M == 32, "tile assignment is written for n = 64, m = 32");
+  constexpr int PS = M + 1, HPP = N + 1;
+  constexpr int PITCH = 144, PN_TERM = 64 * PITCH, ZN_TERM = 32 * PITCH, WT_PITCH = 80, WT_TERM = 64 * WT_PITCH;
+  constexpr int OFF_ZN = 3 * PN_TERM, OFF_WT = OFF_ZN + 3 * ZN_TERM, OFF_YN = OFF_ZN, OFF_F32 = OFF_WT + 3 * WT_TERM;
+  static_assert(3 * PN_TERM <= 3 * ZN_TERM + 3 * WT_TERM, "Y^T aliases Z and W^T");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int lr = lane & 31, lk = lane >> 5;
+  __shared__ int s_rot;
+  if (tid == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    const unsigned k = (hw >> 4) & 3, pos = ((k & 1) << 1) | (k >> 1);
+    s_rot = rot_mode == 0 ? (int)blockIdx.x : (int)(pos + 2 * (hw & 15));
+  }
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(((tid >> 6) + s_rot) & 3);
+  const int ti = wave >> 1, tj = wave & 1;
+  const long long b = blockIdx.x;
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  lds_c* L = (lds_c*)reinterpret_cast<char*>(lds);
+  lds_c* Pn = L;             // [3][64][144 B]  P- (after J) / P+ (after H), transposed terms
+  lds_c* Zn = L + OFF_ZN;    // [3][32][144 B]  Z = (H P-)^T
+  lds_c* Wt = L + OFF_WT;    // [3][64][80 B]   W^T, row-major terms
+  lds_c* Yn = L + OFF_YN;    // [3][64][144 B]  Y^T (aliases Zn, Wt)
+  float* sHP = lds + OFF_F32 / 4;   // [32][65]  H P- in fp32 for the forward substitution
+  float* sc2 = sHP + M * HPP;       // [32][33]  S as wave 2 sees it
+  float* sc3 = sc2 + M * PS;        // [32][33]  S as wave 3 sees it
+  float* sm = sc3 + M * PS;         // [64] mean
+  float* sm2 = sm + N;              // [64] mean (ping-pong)
+  float* sv = sm2 + N;              // [32] innovation
+  float* scv = sv + M;              // [64] 1e-3 W^T g
+  float* part = scv + N;            // [2][64] halves (over k) of the two matrix-vector products
+  float* sv3 = part + 2 * N;        // [32] innovation, wave 3's copy
+
+  // A rows 32 tj + lr and H row lr as bf16 terms: the wave's B-operand in phases A, I, J and A-operand in phase B
+  u32x4 hop[3][4], aop[3][4];
+  BF_UNROLL for (int t = 0; t < 3; ++t) BF_UNROLL for (int c = 0; c < 4; ++c) {
+    hop[t][c] = *reinterpret_cast<const u32x4*>(&cst->H3[t][lr * N + 16 * c + 8 * lk]);
+    aop[t][c] = *reinterpret_cast<const u32x4*>(&cst->A3[t][(32 * tj + lr) * N + 16 * c + 8 * lk]);
+  }
+  f32x16 Pacc;  // the wave's tile of P-: carried in registers from phase J to phase H
+  BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] = carry.P_in[b * N * N + (32 * ti + c_row(r, lane)) * N + 32 * tj + lr];
+  store_terms_transposed(Pn, PN_TERM, PITCH, ti, tj, lane, Pacc);
+  if (tid < N) sm[tid] = carry.m_in[b * N + tid];
+  float w = carry.w_in ? carry.w_in[b] : 1.0f;
+  float ynext = (wave >= 2 && lane < M) ? y.p[b * y.sB + lane * y.sE] : 0.f;
+  const float dr0 = cst->Dr0[lr], gq0 = cst->Gq0[lane];
+  __syncthreads();
+
+#ifdef BF_MFMA_PHASE_TIMERS
+  long long tacc[12] = {0};
+  long long tprev = wall_clock64();
+#define BF_TICK5(i) { const long long tn_ = wall_clock64(); tacc[i] += tn_ - tprev; tprev = tn_; }
+#else
+#define BF_TICK5(i)
+#endif
+  float* mcur = sm;
+  float* mnxt = sm2;
+  for (long long t = 0; t < T; ++t) {
+    // ================= phase A: Z = P-^T H^T (waves 0, 1: row tile = wave); innovation (wave 2)
+    if (wave < 2) {
+      f32x16 z = {0};
+      BF_UNROLL for (int c = 0; c < 4; ++c) {
+        u32x4 a[3];
+        load_terms(a, Pn, PN_TERM, PITCH, 32 * wave + lr, c, lk);
+        const u32x4 bh[3] = {hop[0][c], hop[1][c], hop[2][c]};
+        z = mfma_bf6(a, bh, z);
+      }
+      BF_UNROLL for (int r = 0; r < 16; ++r) sHP[lr * HPP + 32 * wave + c_row(r, lane)] = z[r];   // (H P-)[lr][.]
+      store_terms_transposed(Zn, ZN_TERM, PITCH, wave, 0, lane, z);
+    } else {
+      // H m-: waves 2 and 3 (idle in this phase) take half of the k range each; the halves meet after the barrier
+      float s = dot_terms_half(hop, mcur, lk, wave - 2);
+      s += __shfl_xor(s, 32, 64);
+      if (lane < M) part[(wave - 2) * N + lane] = s;
+    }
+    BF_TICK5(0)
+    lds_barrier();
+    BF_TICK5(1)
+    // ================= phases B + C (waves 2 and 3): S^T = H Z + (D R D^T)^T, the factorizations, W^T, c, m+
+    float ll = 0.f;
+    if (wave >= 2) {
+      {  // innovation v = y - (H m- + D r0): both factorizing waves form it (same bits) for their own use
+        const float yv = ynext;
+        const long long tn = t + 1 < T ? t + 1 : t;
+        if (lane < M) ynext = y.p[b * y.sB + tn * y.sT + lane * y.sE];  // prefetch
+        if (lane < M) (wave == 2 ? sv : sv3)[lane] = yv - ((part[lane] + part[N + lane]) + dr0);
+      }
+      f32x16 acc;
+      gl_cf* drd = per_step(cst->DRD);
+      BF_UNROLL for (int r = 0; r < 16; ++r) acc[r] = drd[lr * M + c_row(r, lane)];
+      BF_UNROLL for (int c = 0; c < 4; ++c) {
+        u32x4 bz[3];
+        load_terms(bz, Zn, ZN_TERM, PITCH, lr, c, lk);
+        const u32x4 ah[3] = {hop[0][c], hop[1][c], hop[2][c]};
+        acc = mfma_bf6(ah, bz, acc);
+      }
+      float* sc = wave == 2 ? sc2 : sc3;
+      BF_UNROLL for (int r = 0; r < 16; ++r) sc[lr * PS + c_row(r, lane)] = acc[r];   // S[lr][.] = S^T[.][lr]
+      wave_lds_order();
+      BF_TICK5(10)
+#if BF_V5_INLINE
+      if (wave == 3) chol_w_rows_impl<true>((lds_f*)sc3, (lds_f*)sHP, (lds_f*)sv3, (lds_f*)mcur, (lds_f*)mnxt, (lds_f*)scv, Wt, lane);
+      else ll = chol_loglik_rows_impl((lds_f*)sc2, (lds_f*)sv, lane);
+#else
+      if (wave == 3) chol_w_rows_bf((lds_f*)sc3, (lds_f*)sHP, (lds_f*)sv3, (lds_f*)mcur, (lds_f*)mnxt, (lds_f*)scv, Wt, lane);
+      else ll = chol_loglik_rows((lds_f*)sc2, (lds_f*)sv, lane);
+#endif
+    }
+    BF_TICK5(2)
+    lds_barrier();
+    BF_TICK5(3)
+    // ================= phase H: P+ = P- - W^T W + c c^T (K = 32 + 2); emit filtered streams; P+ stored as terms
+    {
+      f32x16 acc = Pacc;
+      BF_UNROLL for (int c = 0; c < 2; ++c) {
+        u32x4 a[3], bw[3];
+        load_terms(a, Wt, WT_TERM, WT_PITCH, 32 * ti + lr, c, lk);
+        load_terms(bw, Wt, WT_TERM, WT_PITCH, 32 * tj + lr, c, lk);
+        BF_UNROLL for (int q = 0; q < 3; ++q) a[q] ^= 0x80008000u;   // -W^T
+        acc = mfma_bf6(a, bw, acc);
+      }
+      acc = mfma2(lk == 0 ? scv[32 * ti + lr] : 0.f, lk == 0 ? scv[32 * tj + lr] : 0.f, acc);
+      store_tile<N>(out.P, b, t, ti, tj, lane, acc);
+      store_terms_transposed(Pn, PN_TERM, PITCH, ti, tj, lane, acc);
+    }
+    if (wave == 1 && out.m.p) out.m.p[b * out.m.sB + t * out.m.sT + lane * out.m.sE] = mnxt[lane];
+    if (wave == 2 && lane == 0) {
+      w = reweight_single(ll, w);
+      if (out.w.p) out.w.p[b * out.w.sB + t * out.w.sT] = w;
+      if (out.ll.p) out.ll.p[b * out.ll.sB + t * out.ll.sT] = ll;
+    }
+    BF_TICK5(4)
+    lds_barrier();
+    BF_TICK5(5)
+    // ================= phase I: Y^T = P+^T A^T (K = 64); m- = A m+ + G q0 (waves 0, 1: rows 32 tj + lr)
+    // Fetched here, a phase ahead of their use: the tile of G Q G^T (added after phase J's products) and H's terms for the
+    // next step's phases A and B (12 KB shared by every wave of the CU) -- an L2 round trip under this load is ~1 us, and
+    // held through the factorization instead the 48 + 16 registers spill
+    float gq[16];
+    {
+#if BF_V5_HOP_RELOAD
+      const int oz = opaque_szero();
+      BF_UNROLL for (int q = 0; q < 3; ++q) BF_UNROLL for (int c = 0; c < 4; ++c)
+          hop[q][c] = *reinterpret_cast<const u32x4*>(&cst->H3[q][lr * N + 16 * c + 8 * lk + oz]);
+#endif
+      gl_cf* gqg = per_step(cst->GQG);
+      BF_UNROLL for (int r = 0; r < 16; ++r) gq[r] = gqg[(32 * ti + c_row(r, lane)) * N + 32 * tj + lr];
+    }
+    {
+      f32x16 acc = {0};
+      BF_UNROLL for (int c = 0; c < 4; ++c) {
+        u32x4 a[3];
+        load_terms(a, Pn, PN_TERM, PITCH, 32 * ti + lr, c, lk);
+        const u32x4 ba[3] = {aop[0][c], aop[1][c], aop[2][c]};
+        acc = mfma_bf6(a, ba, acc);
+      }
+      store_terms_transposed(Yn, PN_TERM, PITCH, ti, tj, lane, acc);
+    }
+    {  // A m+: the two waves holding rows 32 tj + lr take half of the k range each
+      float s = dot_terms_half(aop, mnxt, lk, ti);
+      s += __shfl_xor(s, 32, 64);
+      if (lane < 32) part[ti * N + 32 * tj + lane] = s;
+    }
+    BF_TICK5(6)
+    lds_barrier();
+    BF_TICK5(7)
+    // ================= phase J: P- = Y A^T + G Q G^T (K = 64); emit predicted streams; P- stored as terms
+    {
+      // H's terms for the next step's phases A and B are fetched here (12 KB shared by every wave of the CU: L1 hits) rather
+      // than held through the factorization, where 48 more live registers spill
+      if (wave == 2) mcur[lane] = (part[lane] + part[N + lane]) + gq0;   // predicted mean m- = A m+ + G q0
+      BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] = 0.f;
+      BF_UNROLL for (int c = 0; c < 4; ++c) {
+        u32x4 a[3];
+        load_terms(a, Yn, PN_TERM, PITCH, 32 * ti + lr, c, lk);
+        const u32x4 ba[3] = {aop[0][c], aop[1][c], aop[2][c]};
+        Pacc = mfma_bf6(a, ba, Pacc);
+      }
+      BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] += gq[r];
+      store_tile<N>(out.pP, b, t, ti, tj, lane, Pacc);
+      store_terms_transposed(Pn, PN_TERM, PITCH, ti, tj, lane, Pacc);
+    }
+    if (wave == 2 && out.pm.p) out.pm.p[b * out.pm.sB + t * out.pm.sT + lane * out.pm.sE] = (part[lane] + part[N + lane]) + gq0;
+    BF_TICK5(8)
+    lds_barrier();
+    BF_TICK5(9)
+  }
+
+  if (carry.P_out) BF_UNROLL for (int r = 0; r < 16; ++r)
+      carry.P_out[b * N * N + (32 * ti + c_row(r, lane)) * N + 32 * tj + lr] = Pacc[r];
+  if (carry.m_out && tid < N) carry.m_out[b * N + tid] = mcur[tid];
+  if (carry.w_out && wave == 2 && lane == 0) carry.w_out[b] = w;
+#ifdef BF_MFMA_PHASE_TIMERS
+  __syncthreads();
+  if (b == 0 && lane == 0 && carry.P_out) for (int i = 0; i < 12; ++i) carry.P_out[wave * 16 + i] = (float)tacc[i];
+#endif
+}
+
 // ---------------------------------------------------------------------------------------
 int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
                    const bf_out_desc* out, hipStream_t stream) {
@@ -1011,6 +1351,32 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
   auto Dat = [&](int i, int k) { return p->D ? p->D[i * dr + k] : (i == k ? 1.f : 0.f); };
   for (int i = 0; i < N * N; ++i) h->A[i] = p->A[i];
   for (int i = 0; i < M * N; ++i) h->H[i] = p->H[i];
+  {  // x = hi + mid + lo, three bf16 terms (round to nearest even), exact for finite x
+    auto bf = [](float x) {
+      uint32_t u;
+      std::memcpy(&u, &x, 4);
+      u += 0x7FFFu + ((u >> 16) & 1u);
+      return (unsigned short)(u >> 16);
+    };
+    auto fl = [](unsigned short hbits) {
+      const uint32_t u = (uint32_t)hbits << 16;
+      float f;
+      std::memcpy(&f, &u, 4);
+      return f;
+    };
+    auto split3 = [&](const float* src, int cnt, unsigned short (*dst)[N * N], unsigned short (*dstH)[M * N]) {
+      for (int i = 0; i < cnt; ++i) {
+        float x = src[i];
+        for (int t = 0; t < 3; ++t) {
+          const unsigned short hb = bf(x);
+          if (dst) dst[t][i] = hb; else dstH[t][i] = hb;
+          x -= fl(hb);
+        }
+      }
+    };
+    split3(p->A, N * N, h->A3, nullptr);
+    split3(p->H, M * N, nullptr, h->H3);
+  }
   {  // (G Q) G^T and (D R) D^T, association of inference.py:69,:100
     float* GQ = new float[(size_t)N * dq];
     for (int i = 0; i < N; ++i)
@@ -1069,12 +1435,20 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
     hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(256), lds_bytes, stream, d, yv, cv, ov, B, T);
   } else {
     const int var = g_kf_mfma_variant.load();
+    static const int rot_mode = [] { const char* e = std::getenv("BAYESFILT_MFMA_ROT"); return e ? std::atoi(e) : 1; }();
+    if (var == 5) {
+      const size_t lds5 = 3 * 64 * 144 + 3 * 32 * 144 + 3 * 64 * 80 + sizeof(float) * (size_t)(M * (N + 1) + 2 * M * (M + 1) + 5 * N + 2 * M);
+      auto kern5 = kf_scan_mfma5_kernel<N, M>;
+      BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern5), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5));
+      hipLaunchKernelGGL(kern5, dim3((unsigned)B), dim3(256), lds5, stream, d, yv, cv, ov, B, T, rot_mode);
+      BF_HIP_CHECK(hipGetLastError());
+      return BF_OK;
+    }
     const size_t lds_bytes = var == 4 ? sizeof(float) * (size_t)(2 * N * (N + 1) + M * (N + 1) + 2 * M * (M + 1) + 3 * N + M)
                                       : sizeof(float) * (size_t)(3 * N * (N + 1) + M * (N + 1) + 3 * M * (M + 1) + 3 * N + M);
     auto kern = var == 2 ? kf_scan_mfma2_kernel<N, M, 2> : var == 3 ? kf_scan_mfma2_kernel<N, M, 3> : kf_scan_mfma2_kernel<N, M, 4>;
     if (lds_bytes > 64 * 1024)
       BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    static const int rot_mode = [] { const char* e = std::getenv("BAYESFILT_MFMA_ROT"); return e ? std::atoi(e) : 1; }();
     hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(256), lds_bytes, stream, d, yv, cv, ov, B, T, rot_mode);
   }
   BF_HIP_CHECK(hipGetLastError());
