@@ -38,10 +38,10 @@ namespace bf {
 
 static int mfma_variant_default() {  // BAYESFILT_MFMA_VARIANT=1..5 overrides the default for A/B runs of unmodified programs
   const char* e = std::getenv("BAYESFILT_MFMA_VARIANT");
-  const int v = e ? std::atoi(e) : 2;
-  return (v >= 1 && v <= 5) ? v : 2;
+  const int v = e ? std::atoi(e) : 5;
+  return (v >= 1 && v <= 5) ? v : 5;
 }
-std::atomic<int> g_kf_mfma_variant{mfma_variant_default()};  // bf_set_option "kf_mfma_variant": 2 = gain-free update, factorization in VALU registers (default); 3 = factorization by rank-2 MFMAs; 4 = variant 2 at three workgroups per CU (A in registers); 1 = round 1's kernel
+std::atomic<int> g_kf_mfma_variant{mfma_variant_default()};  // bf_set_option "kf_mfma_variant": 5 = products as three-term bf16 splits on the bf16 matrix pipe (default); 2 = fp32 MFMAs, gain-free update, factorization in VALU registers; 3 = factorization by rank-2 MFMAs; 4 = variant 2 at three workgroups per CU; 1 = round 1's kernel
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using lds_f = __attribute__((address_space(3))) float;
@@ -475,13 +475,19 @@ kf_scan_mfma_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView 
 
 // =======================================================================================================================
 // Measured on one MI355X, BASELINE configs[4] (B = 32 768, T = 2 000, all five streams in T-chunks of 100; bench.py
-// --config kalman64), same box, steps/s:   variant 1 (round 1) 3.28e7 | variant 2 3.73e7 | variant 3 3.69e7 | variant 4 3.1e7.
+// --config kalman64), same box, steps/s:   variant 1 (round 1) 3.28e7 | 2 3.73e7 | 3 3.69e7 | 4 3.1e7 | 5 (default) 4.90e7.
+// Variants 1-4 run the five products on v_mfma_f32_32x32x2_f32, which shares the SIMD's fp32 datapath with the vector
+// instructions of the factorization (see variant 5's header and profiles/r02_f32_pipe_probe.txt); variant 5 moves them to
+// the bf16 matrix pipe as three-term splits at fp32-level rounding.  Errors against the oracle over the 2 000 steps
+// (scripts/mfma_parity_probe.py): variant 2 means 3.0e-6, covariances 1.2e-6, log-likelihood 3.8e-6; variant 5 3.6e-6,
+// 1.5e-6, 4.6e-6 (budget 1e-5).
 // What moved variants 2 and 3 from 3.54e7 / 3.07e7 (first cut of this round) to these numbers:
 //   * no loop-invariant operand lives in registers across steps (per_step() below): the compiler had hoisted the sixteen
 //     64-bit store addresses of each output stream and the loads of G Q G^T out of the time loop and spilled them
 //     (62 / 87 VGPRs spilled -> 0 / 0);
 //   * the serial phase's elimination steps are packed (v_pk_fma_f32 on (row entry, right-hand-side entry) pairs):
-//     2 295 -> 1 668 vector instructions in chol_w_rows, which is issue bound (4 cycles per wave64 instruction);
+//     2 295 -> 1 668 vector instructions in chol_w_rows (a v_pk_fma_f32 costs 1.75 v_fma_f32, so the gain is in the
+//     instruction count around them, not in the multiply-adds);
 //   * roles placed by the hardware's wave placement rather than by blockIdx (+1 %, see the kernel).
 // Tried and measured flat or worse: a half-step start offset for the second workgroup of a CU (0 %); s_setprio 3 around
 // the factorization (-2 %); dropping the log-likelihood factorization altogether as an upper bound for deriving it from

@@ -230,16 +230,19 @@ def make_kalman64(args, rank, world, device):
         return float((torch.isfinite(c.means.reshape(B, n)).all(dim=1) & torch.isfinite(c.covariances.reshape(B, n * n)).all(dim=1)).float().mean())
 
     # algorithmic flop per step of the reference's formulation (2 n^3 x 2 predict, H P, S, the gain solve,
-    # K S K^T ~ 2.0e6); the kernel executes 452 v_mfma_f32_32x32x2_f32 (1.85e6) plus a ~2 900-instruction vector Cholesky
+    # K S K^T ~ 2.0e6).  The kernel runs the five products as three-term bf16 splits (6 x v_mfma_f32_32x32x16_bf16 per
+    # K = 16 chunk, fp32 accumulation, fp32-level rounding) plus a ~2 900-instruction fp32 vector Cholesky; "peak" stays the
+    # fp32 matrix / vector peak the same algebra would be priced against in fp32
     bps, fl = 4 * m + 4 * (1 + 2 * n + 2 * n * n), 2.0e6
     return dict(kernels=kernels, summary=summary, finite=finite, units=B * T, total_units=Bt * T, scaling="strong", gather_rows=Bt,
                 roofline=lambda ms: {"bound": "mfma", "achieved": fl * B * T / (ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFS, "unit": "TFLOP/s",
-                                     "kernel": "kf_scan_mfma2_kernel<64,32,2>", "flop_per_step": fl, "bytes_per_step": bps,
+                                     "kernel": "kf_scan_mfma5_kernel<64,32>", "flop_per_step": fl, "bytes_per_step": bps,
                                      "hbm_GBs": bps * B * T / (ms * 1e-3) / 1e9,
                                      "note": "fp32 MFMA and fp32 vector instructions share ONE datapath per SIMD on gfx950 "
-                                             "(profiles/r02_f32_pipe_probe.txt: two waves' MFMA and v_fma streams take the sum of their "
-                                             "times); per step the kernel needs ~13.3 us of MFMA + ~7 us of vector SIMD-time over 4 SIMDs"},
-                workload=f"Kalman filter state_dim=64 obs_dim=32 T={T} batch={Bt}, FULL5 in T-chunks of {Tc}, fp32 MFMA path, "
+                                             "(profiles/r02_f32_pipe_probe.txt), so the products run on the bf16 matrix pipe as exact "
+                                             "three-term splits of the fp32 operands: 336 bf16 MFMAs (5.5 us of SIMD-time) + ~8 us of fp32 "
+                                             "vector work per step over 4 SIMDs; parity with the fp32 oracle 4e-6 over 2 000 steps"},
+                workload=f"Kalman filter state_dim=64 obs_dim=32 T={T} batch={Bt}, FULL5 in T-chunks of {Tc}, MFMA path (bf16 three-term splits, fp32 rounding), "
                          "observations drawn from the model",
                 extra={"batch_total": Bt, "batch_this_rank": B, "T": T})
 

@@ -123,10 +123,13 @@ int bf_device_count(void);
  *                   stores, 2 = LDS time-transpose (contiguous reference layout only).
  *   "kf_lanes":     lanes that cooperate on one trajectory (0 = default for the dimensions;
  *                   otherwise one of the compiled powers of two, e.g. 1, 2 or 4 at n = 4).
- *   "kf_mfma_variant": the n = 64, m = 32 Kalman kernel: 2 (default) = gain-free update (P+ = P - W^T W + c c^T with
- *                   W = L^-1 H P), Cholesky and forward substitution fused in one wave's registers; 3 = the same update
- *                   with the factorization itself on the matrix cores (rank-2 MFMA eliminations); 1 = round 1's kernel
- *                   (explicit inverse through LDS).  Same results to rounding; env BAYESFILT_MFMA_VARIANT sets the default.
+ *   "kf_mfma_variant": the n = 64, m = 32 Kalman kernel: 5 (default) = gain-free update (P+ = P - W^T W + c c^T with
+ *                   W = L^-1 H P) with the five matrix products as three-term bf16 splits of the fp32 operands on the
+ *                   bf16 matrix pipe (fp32-level rounding); 2 = the same update on fp32 MFMAs, Cholesky and forward
+ *                   substitution fused in one wave's registers; 3 = 2 with the factorization itself as rank-2 MFMA
+ *                   eliminations; 4 = 2 at three workgroups per CU; 1 = round 1's kernel (explicit inverse through LDS).
+ *                   Same results to rounding (< 5e-6 against the test oracle over 2 000 steps); env BAYESFILT_MFMA_VARIANT
+ *                   sets the default.
  *   "force_generic": 1 = bf_kalman_filter_f32 / bf_gsf_ekf_f32 run the run-time-dimension kernel (any n, m, K; state in
  *                   LDS) even where a compile-time-dimension instance exists (test hook; default 0).
  *   "gsf_structured": 1 (default) lets bf_gsf_ekf_f32 use the structure-aware kernel instances
