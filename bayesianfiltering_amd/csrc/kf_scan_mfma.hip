@@ -1068,6 +1068,22 @@ kf_scan_mfma2_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
 }
 
 // =======================================================================================================================
+// store_tile for a model of nr <= N states riding zero-padded in the N x N tiles: entries (row, col) with both < nr, at the
+// model's own row length
+template <int N>
+__device__ __forceinline__ void store_tile_n(const SView& sv, long long b, long long t, int pi, int pj, int lane, const f32x16& acc, int nr) {
+  if (nr == N) return store_tile<N>(sv, b, t, pi, pj, lane, acc);
+  if (!sv.p) return;
+  const int lr = lane & 31, lk = lane >> 5;
+  gl_f* base = per_step(sv.p + b * sv.sB + t * sv.sT);
+  const int col = 32 * pj + lr;
+  const long long sE = sv.sE + (long long)opaque_szero();
+  BF_UNROLL for (int r = 0; r < 16; ++r) {
+    const int row = 32 * pi + (r & 3) + 8 * (r >> 2) + 4 * lk;
+    if (col < nr && row < nr) __builtin_nontemporal_store(acc[r], base + (long long)(row * nr + col) * sE);
+  }
+}
+
 // Variant 5: the five matrix products off the fp32 datapath.  On gfx950 v_mfma_f32_32x32x2_f32 and the fp32 vector
 // instructions share ONE datapath per SIMD (profiles/r02_f32_pipe_probe.txt), so the fp32 products (13.3 us of the
 // 20.4 us of SIMD-time a step needs) cannot hide behind the factorization.  v_mfma_f32_32x32x16_bf16 runs at 16x the
@@ -1143,7 +1159,8 @@ __device__ __forceinline__ float dot_terms_half(const u32x4 (*x)[4], const float
 template <int N, int M>
 __global__ void __launch_bounds__(256, 2)
 kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView carry, OutViews out, long long B, long long T,
-                     int rot_mode) {
+                     int rot_mode, int nr, int mr) {
+  // nr <= 64, mr <= 32: the model's own dimensions (streams and carry are laid out for them); inside, everything is (64, 32)
   static_assert(N == 64 && M == 32, "tile assignment is written for n = 64, m = 32");
   constexpr int PS = M + 1, HPP = N + 1;
   constexpr int PITCH = 144, PN_TERM = 64 * PITCH, ZN_TERM = 32 * PITCH, WT_PITCH = 80, WT_TERM = 64 * WT_PITCH;
@@ -1186,11 +1203,16 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
     aop[t][c] = *reinterpret_cast<const u32x4*>(&cst->A3[t][(32 * tj + lr) * N + 16 * c + 8 * lk]);
   }
   f32x16 Pacc;  // the wave's tile of P-: carried in registers from phase J to phase H
-  BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] = carry.P_in[b * N * N + (32 * ti + c_row(r, lane)) * N + 32 * tj + lr];
+  const bool col_ok = 32 * tj + lr < nr;
+  BF_UNROLL for (int r = 0; r < 16; ++r) {
+    const int row = 32 * ti + c_row(r, lane);
+    Pacc[r] = (col_ok && row < nr) ? carry.P_in[b * nr * nr + row * nr + 32 * tj + lr] : 0.f;
+  }
   store_terms_transposed(Pn, PN_TERM, PITCH, ti, tj, lane, Pacc);
-  if (tid < N) sm[tid] = carry.m_in[b * N + tid];
+  if (tid < N) sm[tid] = tid < nr ? carry.m_in[b * nr + tid] : 0.f;
   float w = carry.w_in ? carry.w_in[b] : 1.0f;
-  float ynext = (wave >= 2 && lane < M) ? y.p[b * y.sB + lane * y.sE] : 0.f;
+  float ynext = (wave >= 2 && lane < mr) ? y.p[b * y.sB + lane * y.sE] : 0.f;
+  const float ll_pad = 0.5f * 1.8378770664093453f * (float)(M - mr);   // the padded observations' log N(0; 0, 1), taken off
   const float dr0 = cst->Dr0[lr], gq0 = cst->Gq0[lane];
   __syncthreads();
 
@@ -1230,7 +1252,7 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
       {  // innovation v = y - (H m- + D r0): both factorizing waves form it (same bits) for their own use
         const float yv = ynext;
         const long long tn = t + 1 < T ? t + 1 : t;
-        if (lane < M) ynext = y.p[b * y.sB + tn * y.sT + lane * y.sE];  // prefetch
+        if (lane < mr) ynext = y.p[b * y.sB + tn * y.sT + lane * y.sE];  // prefetch
         if (lane < M) (wave == 2 ? sv : sv3)[lane] = yv - ((part[lane] + part[N + lane]) + dr0);
       }
       f32x16 acc;
@@ -1248,10 +1270,10 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
       BF_TICK5(10)
 #if BF_V5_INLINE
       if (wave == 3) chol_w_rows_impl<true>((lds_f*)sc3, (lds_f*)sHP, (lds_f*)sv3, (lds_f*)mcur, (lds_f*)mnxt, (lds_f*)scv, Wt, lane);
-      else ll = chol_loglik_rows_impl((lds_f*)sc2, (lds_f*)sv, lane);
+      else ll = chol_loglik_rows_impl((lds_f*)sc2, (lds_f*)sv, lane) + ll_pad;
 #else
       if (wave == 3) chol_w_rows_bf((lds_f*)sc3, (lds_f*)sHP, (lds_f*)sv3, (lds_f*)mcur, (lds_f*)mnxt, (lds_f*)scv, Wt, lane);
-      else ll = chol_loglik_rows((lds_f*)sc2, (lds_f*)sv, lane);
+      else ll = chol_loglik_rows((lds_f*)sc2, (lds_f*)sv, lane) + ll_pad;
 #endif
     }
     BF_TICK5(2)
@@ -1268,10 +1290,10 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
         acc = mfma_bf6(a, bw, acc);
       }
       acc = mfma2(lk == 0 ? scv[32 * ti + lr] : 0.f, lk == 0 ? scv[32 * tj + lr] : 0.f, acc);
-      store_tile<N>(out.P, b, t, ti, tj, lane, acc);
+      store_tile_n<N>(out.P, b, t, ti, tj, lane, acc, nr);
       store_terms_transposed(Pn, PN_TERM, PITCH, ti, tj, lane, acc);
     }
-    if (wave == 1 && out.m.p) out.m.p[b * out.m.sB + t * out.m.sT + lane * out.m.sE] = mnxt[lane];
+    if (wave == 1 && out.m.p && lane < nr) out.m.p[b * out.m.sB + t * out.m.sT + lane * out.m.sE] = mnxt[lane];
     if (wave == 2 && lane == 0) {
       w = reweight_single(ll, w);
       if (out.w.p) out.w.p[b * out.w.sB + t * out.w.sT] = w;
@@ -1325,18 +1347,20 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
         Pacc = mfma_bf6(a, ba, Pacc);
       }
       BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] += gq[r];
-      store_tile<N>(out.pP, b, t, ti, tj, lane, Pacc);
+      store_tile_n<N>(out.pP, b, t, ti, tj, lane, Pacc, nr);
       store_terms_transposed(Pn, PN_TERM, PITCH, ti, tj, lane, Pacc);
     }
-    if (wave == 2 && out.pm.p) out.pm.p[b * out.pm.sB + t * out.pm.sT + lane * out.pm.sE] = (part[lane] + part[N + lane]) + gq0;
+    if (wave == 2 && out.pm.p && lane < nr) out.pm.p[b * out.pm.sB + t * out.pm.sT + lane * out.pm.sE] = (part[lane] + part[N + lane]) + gq0;
     BF_TICK5(8)
     lds_barrier();
     BF_TICK5(9)
   }
 
-  if (carry.P_out) BF_UNROLL for (int r = 0; r < 16; ++r)
-      carry.P_out[b * N * N + (32 * ti + c_row(r, lane)) * N + 32 * tj + lr] = Pacc[r];
-  if (carry.m_out && tid < N) carry.m_out[b * N + tid] = mcur[tid];
+  if (carry.P_out && col_ok) BF_UNROLL for (int r = 0; r < 16; ++r) {
+      const int row = 32 * ti + c_row(r, lane);
+      if (row < nr) carry.P_out[b * nr * nr + row * nr + 32 * tj + lr] = Pacc[r];
+    }
+  if (carry.m_out && tid < nr) carry.m_out[b * nr + tid] = mcur[tid];
   if (carry.w_out && wave == 2 && lane == 0) carry.w_out[b] = w;
 #ifdef BF_MFMA_PHASE_TIMERS
   __syncthreads();
@@ -1348,15 +1372,22 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
 int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
                    const bf_out_desc* out, hipStream_t stream) {
   constexpr int N = 64, M = 32;
-  if (p->n != N || p->m != M) return set_error(BF_EUNSUPPORTED, "MFMA Kalman kernel is compiled for n = 64, m = 32");
+  // Smaller models ride in the (64, 32) tiles zero-padded (variant 5): A, H, G Q G^T padded with zeros keep the padded
+  // block of P at exactly zero; the padded observations are y = 0 with unit noise and H rows of zero, independent of the
+  // real ones up to the 1e-6 jitter's O(1e-12) coupling; each contributes log N(0; 0, 1) to the log-likelihood, taken
+  // off again in the kernel.
+  const int nr = p->n, mr = p->m;
+  const bool padded = nr != N || mr != M;
+  if (nr > N || mr > M || (padded && g_kf_mfma_variant.load() != 5))
+    return set_error(BF_EUNSUPPORTED, "MFMA Kalman kernel: n <= 64 and m <= 32 (smaller than (64, 32) on variant 5 only)");
   if (p->Q_steps > 1 || p->R_steps > 1)
     return set_error(BF_EUNSUPPORTED, "time-varying Q/R are not supported on the MFMA Kalman kernel");
   const int dq = p->dq, dr = p->dr;
   MfmaConst<N, M>* h = new MfmaConst<N, M>();  // zero-filled: the constant cache compares contents
   auto Gat = [&](int i, int k) { return p->G ? p->G[i * dq + k] : (i == k ? 1.f : 0.f); };
   auto Dat = [&](int i, int k) { return p->D ? p->D[i * dr + k] : (i == k ? 1.f : 0.f); };
-  for (int i = 0; i < N * N; ++i) h->A[i] = p->A[i];
-  for (int i = 0; i < M * N; ++i) h->H[i] = p->H[i];
+  for (int i = 0; i < nr; ++i) for (int j = 0; j < nr; ++j) h->A[i * N + j] = p->A[i * nr + j];
+  for (int i = 0; i < mr; ++i) for (int j = 0; j < nr; ++j) h->H[i * N + j] = p->H[i * nr + j];
   {  // x = hi + mid + lo, three bf16 terms (round to nearest even), exact for finite x
     auto bf = [](float x) {
       uint32_t u;
@@ -1380,45 +1411,46 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
         }
       }
     };
-    split3(p->A, N * N, h->A3, nullptr);
-    split3(p->H, M * N, nullptr, h->H3);
+    split3(h->A, N * N, h->A3, nullptr);
+    split3(h->H, M * N, nullptr, h->H3);
   }
   {  // (G Q) G^T and (D R) D^T, association of inference.py:69,:100
     float* GQ = new float[(size_t)N * dq];
-    for (int i = 0; i < N; ++i)
+    for (int i = 0; i < nr; ++i)
       for (int l = 0; l < dq; ++l) {
         float s = 0.f;
         for (int k = 0; k < dq; ++k) s = fmaf(Gat(i, k), p->Q[k * dq + l], s);
         GQ[i * dq + l] = s;
       }
-    for (int i = 0; i < N; ++i)
-      for (int j = 0; j < N; ++j) {
+    for (int i = 0; i < nr; ++i)
+      for (int j = 0; j < nr; ++j) {
         float s = 0.f;
         for (int l = 0; l < dq; ++l) s = fmaf(GQ[i * dq + l], Gat(j, l), s);
         h->GQG[i * N + j] = s;
       }
     delete[] GQ;
     float* DRm = new float[(size_t)M * dr];
-    for (int i = 0; i < M; ++i)
+    for (int i = 0; i < mr; ++i)
       for (int l = 0; l < dr; ++l) {
         float s = 0.f;
         for (int k = 0; k < dr; ++k) s = fmaf(Dat(i, k), p->R[k * dr + l], s);
         DRm[i * dr + l] = s;
       }
-    for (int i = 0; i < M; ++i)
-      for (int j = 0; j < M; ++j) {
+    for (int i = 0; i < mr; ++i)
+      for (int j = 0; j < mr; ++j) {
         float s = 0.f;
         for (int l = 0; l < dr; ++l) s = fmaf(DRm[i * dr + l], Dat(j, l), s);
         h->DRD[i * M + j] = s;
       }
+    for (int i = mr; i < M; ++i) h->DRD[i * M + i] = 1.0f;   // padded observations: unit noise
     delete[] DRm;
   }
-  for (int i = 0; i < N; ++i) {
+  for (int i = 0; i < nr; ++i) {
     float s = 0.f;
     for (int k = 0; k < dq; ++k) s = fmaf(Gat(i, k), p->q0 ? p->q0[k] : 0.f, s);
     h->Gq0[i] = s;
   }
-  for (int i = 0; i < M; ++i) {
+  for (int i = 0; i < mr; ++i) {
     float s = 0.f;
     for (int k = 0; k < dr; ++k) s = fmaf(Dat(i, k), p->r0 ? p->r0[k] : 0.f, s);
     h->Dr0[i] = s;
@@ -1446,7 +1478,7 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
       const size_t lds5 = 3 * 64 * 144 + 3 * 32 * 144 + 3 * 64 * 80 + sizeof(float) * (size_t)(M * (N + 1) + 2 * M * (M + 1) + 5 * N + 2 * M);
       auto kern5 = kf_scan_mfma5_kernel<N, M>;
       BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern5), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5));
-      hipLaunchKernelGGL(kern5, dim3((unsigned)B), dim3(256), lds5, stream, d, yv, cv, ov, B, T, rot_mode);
+      hipLaunchKernelGGL(kern5, dim3((unsigned)B), dim3(256), lds5, stream, d, yv, cv, ov, B, T, rot_mode, nr, mr);
       BF_HIP_CHECK(hipGetLastError());
       return BF_OK;
     }

@@ -163,3 +163,33 @@ def test_data_generator_lorenz96_n40():
     xs, ys = bfa.NonlinearSSM(n, n, m, m).sample(pp, otf.PRNGKey(3), T)
     rx, ry = go.sample_ssm(po, otf.PRNGKey(3), T)
     assert cm.rel_err(xs.cpu().numpy(), rx) < 2e-6 and cm.rel_err(ys.cpu().numpy(), ry) < 2e-6
+
+
+@pytest.mark.parametrize("n,m", [(24, 5), (32, 16), (33, 32), (40, 24), (48, 20), (64, 16), (64, 1), (64, 32)])
+def test_models_padded_into_the_matrix_core_kernel(n, m):
+    """From n = 24 up (m <= 32) the Kalman scan runs on the (64, 32) matrix-core kernel with the model zero-padded into
+    its tiles (unit-noise dummy observations, their log N(0; 0, 1) taken off the log-likelihood): against the oracle at
+    1e-5, against the run-time-dimension kernel, and chunked through the carry == one shot bit for bit."""
+    import bayesianfiltering_amd as bfa
+    dq, dr = max(1, n - 3), max(1, m - (n % 2))
+    a = cm.random_stable_lgssm(n, m, seed=11 * n + m, dq=dq, dr=dr, bias=True)
+    B, T = 6, 40
+    ys = cm.simulate_batch(a, B, T, seed=n - m)
+    init = np.tile(a["m0"], (B, 1)) + 0.05 * np.arange(B, dtype=F32)[:, None]
+    ref = c_oracle.kalman_filter(a, ys, init)
+    p = cm.product_params(a)
+    fast, llf, carry = bfa.kalman_filter(p, ys, initial_means=init, return_loglik=True, return_carry=True)
+    with _forced():
+        slow, lls = bfa.kalman_filter(p, ys, initial_means=init, return_loglik=True)
+    for k in FIELDS:
+        assert cm.rel_err(getattr(fast, k).cpu().numpy(), ref[k]) < 1e-5, (k, cm.rel_err(getattr(fast, k).cpu().numpy(), ref[k]))
+        assert cm.rel_err(getattr(fast, k).cpu().numpy(), getattr(slow, k).cpu().numpy()) < 1e-5, k
+    assert cm.rel_err(llf.cpu().numpy(), ref["loglik"]) < 5e-5
+    assert cm.rel_err(llf.cpu().numpy(), lls.cpu().numpy()) < 5e-5
+    # two chunks through the carry
+    h1, l1, c1 = bfa.kalman_filter(p, ys[:, :17], initial_means=init, return_loglik=True, return_carry=True)
+    h2, l2, c2 = bfa.kalman_filter(p, ys[:, 17:], carry=c1, return_loglik=True, return_carry=True)
+    for k in FIELDS:
+        whole = getattr(fast, k).cpu().numpy()
+        assert np.array_equal(np.concatenate([getattr(h1, k).cpu().numpy(), getattr(h2, k).cpu().numpy()], axis=2), whole), k
+    assert np.array_equal(c2.covariances.cpu().numpy(), carry.covariances.cpu().numpy())
