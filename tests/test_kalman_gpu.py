@@ -207,3 +207,27 @@ def test_staged_stores_for_non_power_of_two_state_dims(n, m, T):
     ref = cm.oracle_kalman_batch(a, ys, init)
     for k in FIELDS:
         assert cm.rel_err(getattr(staged, k).cpu().numpy(), ref[k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+def test_every_variant_of_the_matrix_core_kernel(variant):
+    """bf_set_option("kf_mfma_variant"): the (64, 32) kernel's selectable forms -- round 1's explicit inverse (1), the
+    gain-free update on fp32 MFMAs with the factorization in registers (2), as rank-2 MFMAs (3), at three workgroups per
+    CU (4), and the default with the products as three-term bf16 splits (5) -- all against the oracle at 1e-5."""
+    import bayesianfiltering_amd as bfa
+    from bayesianfiltering_amd import _lib
+    from oracle import c_oracle
+    a = cm.random_stable_lgssm(64, 32, seed=640 + variant, bias=True)
+    B, T = 3, 30
+    ys = cm.simulate_batch(a, B, T, seed=variant)
+    init = np.tile(a["m0"], (B, 1))
+    ref = c_oracle.kalman_filter(a, ys, init)
+    lib = _lib.require_gpu()
+    _lib.check(lib.bf_set_option(b"kf_mfma_variant", variant))
+    try:
+        post, ll = bfa.kalman_filter(cm.product_params(a), ys, initial_means=init, return_loglik=True)
+    finally:
+        _lib.check(lib.bf_set_option(b"kf_mfma_variant", 5))
+    for k in ("means", "covariances", "predicted_means", "predicted_covariances"):
+        assert cm.rel_err(getattr(post, k).cpu().numpy(), ref[k]) < 1e-5, (variant, k, cm.rel_err(getattr(post, k).cpu().numpy(), ref[k]))
+    assert cm.rel_err(ll.cpu().numpy(), ref["loglik"]) < 5e-5
