@@ -58,11 +58,23 @@ extern std::atomic<int> g_gsf_structured;
 extern std::atomic<int> g_kf_mfma_variant;
 static std::atomic<int> g_kf_emit_mode{-1};  // -1 = choose from the layout
 static std::atomic<int> g_kf_lanes{0};       // 0 = default lanes per trajectory for the (n, m) pair
+// op 0 log, 1 exp, 2 bits -> normal, 3 sin, 4 cos, 5 atan2(in[i], in[n + i])
+__host__ __device__ inline float canon_eval_one(int op, const float* in, long long n, long long i) {
+  const float x = in[i];
+  float s, c;
+  switch (op) {
+    case 0: return canon_log(x);
+    case 1: return canon_exp(x);
+    case 2: return bits_to_normal(canon_f_bits(x));
+    case 3: canon_sincos(x, &s, &c); return s;
+    case 4: canon_sincos(x, &s, &c); return c;
+    default: return canon_atan2(x, in[n + i]);
+  }
+}
 __global__ void canon_eval_kernel(int op, const float* __restrict__ in, long long n, float* __restrict__ out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float x = in[i];
-  out[i] = op == 0 ? canon_log(x) : op == 1 ? canon_exp(x) : bits_to_normal(canon_f_bits(x));
+  out[i] = canon_eval_one(op, in, n, i);
 }
 
 static std::atomic<int> g_force_generic{0};  // 1 = run the run-time-dimension kernel even where a compiled instance exists
@@ -308,11 +320,10 @@ int bf_resample_f32(const float* d_w, const uint32_t* d_keys, int64_t B, int32_t
 }
 
 int bf_canon_eval_f32(int32_t op, const float* in, int64_t n, float* out, int32_t on_device, void* stream) {
-  if (op < 0 || op > 2 || !in || !out || n < 0) return bf::set_error(BF_EINVAL, "bad argument");
+  if (op < 0 || op > 5 || !in || !out || n < 0) return bf::set_error(BF_EINVAL, "bad argument");
   if (n == 0) return BF_OK;
   if (!on_device) {
-    for (int64_t i = 0; i < n; ++i)
-      out[i] = op == 0 ? bf::canon_log(in[i]) : op == 1 ? bf::canon_exp(in[i]) : bf::bits_to_normal(bf::canon_f_bits(in[i]));
+    for (int64_t i = 0; i < n; ++i) out[i] = bf::canon_eval_one(op, in, n, i);
     return BF_OK;
   }
   hipLaunchKernelGGL(bf::canon_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), op, in, n, out);

@@ -87,4 +87,69 @@ __host__ __device__ inline float canon_exp(float x) {
   return (y * s1) * s2;
 }
 
+// sin and cos of one argument: Cephes sinf / cosf (S. Moshier) -- octant j = trunc(|x| 4 / pi) made even, three-part
+// Cody-Waite reduction |x| - j pi/4, the degree-7 / degree-8 minimax polynomials on [-pi/4, pi/4] -- with every product and
+// sum rounded on its own, in the order written (no fused multiply-adds: the test oracle restates it with NumPy float32
+// expressions).  < 2 ulp for |x| <= 64, 3e-7 absolute up to |x| = 8192, the range the reduction constants cover; beyond it
+// (and for NaN / inf) libm.
+__host__ __device__ inline void canon_sincos(float x, float* sn, float* cs) {
+#pragma clang fp contract(off)
+  const float ax = __builtin_fabsf(x);
+  if (!(ax <= 8192.0f)) {
+    *sn = __builtin_sinf(x);
+    *cs = __builtin_cosf(x);
+    return;
+  }
+  int j = (int)(ax * 1.27323954473516f);
+  j += j & 1;
+  const float y = (float)j;
+  float r = ax - y * 0.78515625f;
+  r = r - y * 2.4187564849853515625e-4f;
+  r = r - y * 3.77489497744594108e-8f;
+  const float z = r * r;
+  const float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+  const float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+  const int q = (j >> 1) & 3;
+  const float s_abs = q == 0 ? ps : q == 1 ? pc : q == 2 ? -ps : -pc;
+  *cs = q == 0 ? pc : q == 1 ? -ps : q == 2 ? -pc : ps;
+  *sn = x < 0.0f ? -s_abs : s_abs;
+}
+__host__ __device__ inline float canon_sin(float x) {
+  float s, c;
+  canon_sincos(x, &s, &c);
+  return s;
+}
+
+// atan2(y, x): Cephes atanf (two range reductions at tan(pi/8), tan(3 pi/8), degree-4 polynomial in t^2) of the IEEE
+// quotient y / x, plus the quadrant's multiple of pi; products and sums rounded one by one.  Zeros: atan2(0, x) = 0 or pi
+// by the sign of x, atan2(y, 0) = +- pi/2 (the sign of a zero argument is not looked at).
+__host__ __device__ inline float canon_atan(float x) {
+#pragma clang fp contract(off)
+  const float ax = __builtin_fabsf(x);
+  float y0, t;
+  if (ax > 2.414213562373095f) {
+    y0 = 1.5707963267948966f;
+    t = -(1.0f / ax);
+  } else if (ax > 0.4142135623730950f) {
+    y0 = 0.7853981633974483f;
+    t = (ax - 1.0f) / (ax + 1.0f);
+  } else {
+    y0 = 0.0f;
+    t = ax;
+  }
+  const float z = t * t;
+  const float p = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * t + t;
+  const float r = y0 + p;
+  return x < 0.0f ? -r : r;
+}
+__host__ __device__ inline float canon_atan2(float y, float x) {
+#pragma clang fp contract(off)
+  if (x != x || y != y) return x + y;
+  if (x == 0.0f) return y > 0.0f ? 1.5707963267948966f : y < 0.0f ? -1.5707963267948966f : 0.0f;
+  if (y == 0.0f) return x < 0.0f ? 3.14159265358979323846f : 0.0f;
+  const float z = canon_atan(y / x);
+  if (x < 0.0f) return y < 0.0f ? z - 3.14159265358979323846f : z + 3.14159265358979323846f;
+  return z;
+}
+
 }  // namespace bf

@@ -63,7 +63,7 @@ __device__ __forceinline__ void dyn_value_t(const MDL& p, const float* x, const 
         const float nrm = sqrtf(x[1] * x[1] + x[3] * x[3]);
         // the two turn matrices differ in the sign of the angle only: one sincos serves both (sin is odd, cos even)
         float sn0, cs0;
-        sincosf(dt * (0.1f * acc / nrm), &sn0, &cs0);
+        canon_sincos(dt * (0.1f * acc / nrm), &sn0, &cs0);
         BF_UNROLL for (int sgn = 0; sgn < 2; ++sgn) {
           const float cc = sgn == 0 ? c1 : c2;
           const float om = 0.1f * (sgn == 0 ? acc : -acc) / nrm;
@@ -75,7 +75,7 @@ __device__ __forceinline__ void dyn_value_t(const MDL& p, const float* x, const 
         mv<4, 4>(Mx, x, out);
       }
       break;
-    case DYN_SINE: BF_UNROLL for (int i = 0; i < N; ++i) out[i] = sinf(p.dth[0] * x[i]); break;
+    case DYN_SINE: BF_UNROLL for (int i = 0; i < N; ++i) out[i] = canon_sin(p.dth[0] * x[i]); break;
     case DYN_GROWTH:
       if constexpr (N == 1) out[0] = x[0] / 2.0f + 25.0f * x[0] / (1.f + x[0] * x[0]) + u0;
       break;
@@ -106,12 +106,12 @@ __device__ __forceinline__ void emi_mean_t(const MDL& p, const float* x, float u
     case EMI_LINEAR: mv<M, N>(p.Hm, x, hx); break;
     case EMI_BEARING_RANGE:
       if constexpr (N == 4 && M == 2) {
-        hx[0] = atan2f(x[2], x[0]);
+        hx[0] = canon_atan2(x[2], x[0]);
         hx[1] = sqrtf(x[0] * x[0] + x[2] * x[2]);
       }
       break;
     case EMI_BEARING:
-      if constexpr (N == 4 && M == 1) hx[0] = atan2f(x[2], x[0]);
+      if constexpr (N == 4 && M == 1) hx[0] = canon_atan2(x[2], x[0]);
       break;
     case EMI_QUADRATIC:
       if constexpr (M == 1) {

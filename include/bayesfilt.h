@@ -321,7 +321,8 @@ int bf_resample_f32(const float* d_w, const uint32_t* d_keys, int64_t B, int32_t
 /* The canonical fp32 arithmetic of the particle filter's weight path (csrc/bf_canon_math.hpp: IEEE add / mul / div /
  * sqrt / fma and integer operations in a fixed order, identical on host and device, restated by the oracle so that
  * in-filter resampling indices are bit-exact), evaluated elementwise: op 0 = log, 1 = exp, 2 = jax.random.normal's
- * bits -> N(0,1) map (the input words are the raw uint32 bits).  on_device = 0: HOST buffers, evaluated by the host
+ * bits -> N(0,1) map (the input words are the raw uint32 bits), 3 = sin, 4 = cos, 5 = atan2(in[i], in[n + i]) (the input
+ * holds 2 n values).  on_device = 0: HOST buffers, evaluated by the host
  * build of the same functions; 1: DEVICE buffers, one lane per element.  A test / audit hook. */
 int bf_canon_eval_f32(int32_t op, const float* in, int64_t n, float* out, int32_t on_device, void* stream);
 

@@ -202,3 +202,61 @@ def cholesky_lower(A):
                 s = F32(s - F32(L[i, k] * L[j, k]))
             L[i, j] = F32(s / d)
     return L
+
+
+def sincos(x):
+    """bf_canon_math.hpp: canon_sincos -- Cephes sinf / cosf with every product and sum rounded on its own (NumPy float32
+    expressions do exactly that).  Returns (sin, cos); |x| > 8192, NaN, inf: NumPy's functions (outside the canonical range)."""
+    x = np.atleast_1d(np.asarray(x, dtype=F32))
+    ax = np.abs(x)
+    ok = ax <= F32(8192.0)
+    axs = np.where(ok, ax, F32(0.0)).astype(F32)
+    j = (axs * F32(1.27323954473516)).astype(F32).astype(np.int32)      # truncation
+    j = j + (j & 1)
+    y = j.astype(F32)
+    r = (axs - y * F32(0.78515625)).astype(F32)
+    r = (r - y * F32(2.4187564849853515625e-4)).astype(F32)
+    r = (r - y * F32(3.77489497744594108e-8)).astype(F32)
+    z = (r * r).astype(F32)
+    ps = (((F32(-1.9515295891e-4) * z + F32(8.3321608736e-3)) * z - F32(1.6666654611e-1)) * z * r + r).astype(F32)
+    pc = (((F32(2.443315711809948e-5) * z - F32(1.388731625493765e-3)) * z + F32(4.166664568298827e-2)) * z * z
+          - F32(0.5) * z + F32(1.0)).astype(F32)
+    q = (j >> 1) & 3
+    s_abs = np.select([q == 0, q == 1, q == 2], [ps, pc, -ps], -pc).astype(F32)
+    cs = np.select([q == 0, q == 1, q == 2], [pc, -ps, -pc], ps).astype(F32)
+    sn = np.where(x < 0, -s_abs, s_abs).astype(F32)
+    with np.errstate(invalid="ignore"):
+        sn = np.where(ok, sn, np.sin(x)).astype(F32)
+        cs = np.where(ok, cs, np.cos(x)).astype(F32)
+    return sn, cs
+
+
+def atan(x):
+    """bf_canon_math.hpp: canon_atan (Cephes atanf), operations rounded one by one."""
+    x = np.atleast_1d(np.asarray(x, dtype=F32))
+    ax = np.abs(x)
+    big, mid = ax > F32(2.414213562373095), ax > F32(0.4142135623730950)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t_big = (-(F32(1.0) / ax)).astype(F32)
+        t_mid = ((ax - F32(1.0)) / (ax + F32(1.0))).astype(F32)
+    t = np.where(big, t_big, np.where(mid, t_mid, ax)).astype(F32)
+    y0 = np.where(big, F32(1.5707963267948966), np.where(mid, F32(0.7853981633974483), F32(0.0))).astype(F32)
+    z = (t * t).astype(F32)
+    p = ((((F32(8.05374449538e-2) * z - F32(1.38776856032e-1)) * z + F32(1.99777106478e-1)) * z - F32(3.33329491539e-1)) * z * t
+         + t).astype(F32)
+    r = (y0 + p).astype(F32)
+    return np.where(x < 0, -r, r).astype(F32)
+
+
+def atan2(y, x):
+    """bf_canon_math.hpp: canon_atan2."""
+    y, x = np.broadcast_arrays(np.atleast_1d(np.asarray(y, dtype=F32)), np.atleast_1d(np.asarray(x, dtype=F32)))
+    pi, half = F32(3.14159265358979323846), F32(1.5707963267948966)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        z = atan((y / x).astype(F32))
+    out = np.where(x < 0, np.where(y < 0, (z - pi).astype(F32), (z + pi).astype(F32)), z).astype(F32)
+    out = np.where(y == 0, np.where(x < 0, pi, F32(0.0)), out)
+    out = np.where(x == 0, np.where(y > 0, half, np.where(y < 0, -half, F32(0.0))), out)
+    with np.errstate(invalid="ignore"):
+        out = np.where(np.isnan(x) | np.isnan(y), (x + y).astype(F32), out)
+    return out.astype(F32)

@@ -187,6 +187,47 @@ class ManeuverBOT(Fn):
         dt = dtype(self.dt)
         return np.array([[1, dt, 0, 0], [0, 1, 0, 0], [0, 0, 1, dt], [0, 0, 0, 1]], dtype=dtype)
 
+    def value_c(self, X, W, u):
+        """Canonical fp32 arithmetic, batched (N, 4), (N, 2): the operation sequence of csrc/ssm_device.hpp (dyn_value_t,
+        DYN_MANEUVER_BOT): the mixing matrix entry by entry (products and sums rounded one by one, sin / cos by
+        fp32.sincos), M x as a product followed by an fma chain (kf_math.hpp: mv), G q as an fma chain from 0."""
+        from . import fp32
+        X, W = np.asarray(X, dtype=F32), np.asarray(W, dtype=F32)
+        u0 = F32(np.asarray(u).reshape(-1)[0])
+        dt, acc = self.dt, self.acc
+        c0 = F32(F32(F32(0.5) * F32(u0 - F32(1))) * F32(u0 - F32(2)))
+        c1 = F32(F32(-u0) * F32(u0 - F32(2)))
+        c2 = F32(F32(F32(0.5) * u0) * F32(u0 - F32(1)))
+        x1, x3 = X[:, 1], X[:, 3]
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            nrm = np.sqrt((x1 * x1 + x3 * x3).astype(F32)).astype(F32)
+            sn0, cs0 = fp32.sincos((dt * (F32(F32(0.1) * acc) / nrm).astype(F32)).astype(F32))
+            N = X.shape[0]
+            Mx = np.zeros((N, 16), dtype=F32)
+            for i, v in ((0, c0), (1, F32(c0 * dt)), (5, c0), (10, c0), (11, F32(c0 * dt)), (15, c0)):
+                Mx[:, i] = v
+            for sgn, cc in ((0, c1), (1, c2)):
+                a = acc if sgn == 0 else F32(-acc)
+                om = (F32(F32(0.1) * a) / nrm).astype(F32)
+                sn = sn0 if sgn == 0 else (-sn0).astype(F32)
+                cs = cs0
+                so = (sn / om).astype(F32)
+                co = ((F32(1.0) - cs).astype(F32) / om).astype(F32)
+                one, zero = np.ones(N, F32), np.zeros(N, F32)
+                Fm = [one, so, zero, -co, zero, cs, zero, -sn, zero, co, one, so, zero, sn, zero, cs]
+                for i in range(16):
+                    Mx[:, i] = (Mx[:, i] + (cc * Fm[i]).astype(F32)).astype(F32)
+            out = np.empty((N, 4), dtype=F32)
+            for i in range(4):
+                s = (Mx[:, 4 * i] * X[:, 0]).astype(F32)
+                for k in range(1, 4):
+                    s = fp32.fma(Mx[:, 4 * i + k], X[:, k], s)
+                g = np.zeros(N, dtype=F32)
+                for k in range(2):
+                    g = fp32.fma(np.full(N, self.G[i, k], F32), W[:, k], g)
+                out[:, i] = (s + g).astype(F32)
+        return out
+
     def value(self, x, w, u):
         c0, c1, c2 = self._coef(u)
         Fp, _, _ = self._mats(x, self.acc)
@@ -215,6 +256,16 @@ class BearingRange(Fn):
     def value(self, x, w, u):
         return (np.array([np.arctan2(x[2], x[0]), np.sqrt(x[0] * x[0] + x[2] * x[2])], dtype=F32) + w).astype(F32)
 
+    def value_c(self, X, W, u):
+        """Canonical fp32 arithmetic, batched: fp32.atan2, an IEEE square root of the sum of two rounded squares, then + r."""
+        from . import fp32
+        X, W = np.asarray(X, dtype=F32), np.asarray(W, dtype=F32)
+        x0, x2 = X[:, 0], X[:, 2]
+        with np.errstate(invalid="ignore", over="ignore"):
+            b = fp32.atan2(x2, x0)
+            r = np.sqrt(((x0 * x0).astype(F32) + (x2 * x2).astype(F32)).astype(F32)).astype(F32)
+        return (np.stack([b, r], axis=1).astype(F32) + W).astype(F32)
+
     def jac_x(self, x, w, u):
         d2 = x[0] * x[0] + x[2] * x[2]
         d = np.sqrt(d2)
@@ -232,6 +283,12 @@ class Bearing(Fn):
 
     def value(self, x, w, u):
         return (np.array([np.arctan2(x[2], x[0])], dtype=F32) + w).astype(F32)
+
+    def value_c(self, X, W, u):
+        """Canonical fp32 arithmetic, batched: fp32.atan2 + r."""
+        from . import fp32
+        X, W = np.asarray(X, dtype=F32), np.asarray(W, dtype=F32)
+        return (fp32.atan2(X[:, 2], X[:, 0]).reshape(-1, 1) + W).astype(F32)
 
     def jac_x(self, x, w, u):
         d2 = x[0] * x[0] + x[2] * x[2]

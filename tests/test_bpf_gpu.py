@@ -173,16 +173,75 @@ def test_bot_model_with_inputs_and_carry_chunks():
     pp = bfa.ParamsBPF(mu0, S0, nl.maneuver_bot(), np.zeros(2, F32), Q, g, np.zeros(2, F32), R, nl.gaussian_log_prob(g, R))
     xs, ys = go.sample_ssm(go.ParamsNLSSM(*po[:8]), otf.PRNGKey(3), T, inputs.reshape(T, 1))
     key = np.array([0, 5], np.uint32)
-    ref, dbg = go.bootstrap_particle_filter(po, ys, N, key=key, inputs=inputs.reshape(T, 1), debug=True)
+    ref, dbg = go.bootstrap_particle_filter(po, ys, N, key=key, inputs=inputs.reshape(T, 1), debug=True, arith="canonical")
     out = bfa.bootstrap_particle_filter(pp, ys, N, key, inputs, return_ancestors=True)
     assert np.array_equal(out["ancestors"].cpu().numpy().T, dbg["ancestors"])
-    assert cm.rel_err(out["particles"].cpu().numpy(), ref["particles"]) < 2e-5
+    assert _bits_equal(out["particles"].cpu().numpy(), ref["particles"])
     # chunked run through the carry == one shot, bit for bit
     o1, c1 = bfa.bootstrap_particle_filter(pp, ys[:5], N, key, inputs[:5], return_carry=True)
     o2 = bfa.bootstrap_particle_filter(pp, ys[5:], N, key, inputs[5:], carry=c1)
     whole = out["particles"].cpu().numpy()
     parts = np.concatenate([o1["particles"].cpu().numpy(), o2["particles"].cpu().numpy()], axis=1)
     assert np.array_equal(whole, parts)
+
+
+@pytest.mark.parametrize("op", [3, 4, 5])
+def test_device_canonical_trig_equals_oracle_bit_for_bit(op):
+    """canon_sincos / canon_atan2 evaluated ON THE DEVICE against oracle/fp32.py (sin, cos: |x| up to 8192; atan2: every
+    quadrant, zeros, huge and tiny ratios)."""
+    import ctypes as C
+    import torch
+    from oracle import fp32
+    from bayesianfiltering_amd import _lib
+    lib = _lib.require_gpu()
+    rng = np.random.default_rng(op)
+    if op in (3, 4):
+        x = np.concatenate([np.array([0.0, -0.0, 1e-30, 0.78539816, 0.7853982, 1.5707964, 3.1415927, -3.1415927, 8192.0], F32),
+                            (rng.normal(size=1 << 20) * 20).astype(F32), (rng.normal(size=1 << 18) * 1e-3).astype(F32),
+                            rng.uniform(-8192, 8192, 1 << 18).astype(F32)])
+        ref = fp32.sincos(x)[op - 3]
+        xin, n = x, x.size
+    else:
+        y = np.concatenate([np.array([0.0, 0.0, 1.0, -1.0, 0.0, 1e-30, 1e30], F32), rng.normal(size=1 << 20).astype(F32),
+                            (rng.normal(size=1 << 18) * 1e3).astype(F32)])
+        xx = np.concatenate([np.array([1.0, -1.0, 0.0, 0.0, 0.0, 1e30, 1e-30], F32), rng.normal(size=1 << 20).astype(F32),
+                             rng.normal(size=1 << 18).astype(F32)])
+        ref = fp32.atan2(y, xx)
+        xin, n = np.concatenate([y, xx]), y.size
+    din = torch.as_tensor(xin, device="cuda")
+    out = torch.empty(n, dtype=torch.float32, device="cuda")
+    _lib.check(lib.bf_canon_eval_f32(op, C.c_void_p(din.data_ptr()), n, C.c_void_p(out.data_ptr()), 1, None))
+    assert _bits_equal(out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("N,resampler", [(64, "multinomial"), (1000, "multinomial"), (4096, "systematic")])
+def test_bot_model_ancestry_bit_exact(N, resampler):
+    """The manoeuvring-target model of docs/experiments/BOT_Experiment_script.py:31-44 (sin / cos in the turn matrices,
+    atan2 and a square root in the bearing-range emission) with inputs: on the canonical sin / cos / atan2 of
+    csrc/bf_canon_math.hpp the whole ancestry, every weight and every particle equal the oracle's bits."""
+    bfa, nl = _bfa()
+    T = 24
+    mu0 = np.array([2.0, 0.3, 3.0, -0.2], F32)
+    S0 = np.diag([0.1, 0.005, 0.1, 0.01]).astype(F32)
+    Q, R = 1e-3 * np.eye(2, dtype=F32), np.diag([1e-3, 1e-2]).astype(F32)
+    inputs = np.array([1] * 8 + [0] * 8 + [2] * 8, F32)
+    po = go.ParamsBPF(mu0, S0, om.ManeuverBOT(), np.zeros(2, F32), Q, om.BearingRange(), np.zeros(2, F32), R,
+                      go.GaussianEmissionLogProb(om.BearingRange(), R))
+    g = nl.bearing_range()
+    pp = bfa.ParamsBPF(mu0, S0, nl.maneuver_bot(), np.zeros(2, F32), Q, g, np.zeros(2, F32), R, nl.gaussian_log_prob(g, R))
+    xs, ys = go.sample_ssm(go.ParamsNLSSM(*po[:8]), otf.PRNGKey(3), T, inputs.reshape(T, 1))
+    key = np.array([0, 5], np.uint32)
+    ref, dbg = go.bootstrap_particle_filter(po, ys, N, key=key, inputs=inputs.reshape(T, 1), resampler=resampler, debug=True,
+                                            arith="canonical")
+    out = bfa.bootstrap_particle_filter(pp, ys, N, key, inputs, resampler=resampler, return_ancestors=True, output="both")
+    assert dbg["resampled"].any()
+    assert np.array_equal(out["resampled"].cpu().numpy() > 0.5, dbg["resampled"])
+    assert np.array_equal(out["ancestors"].cpu().numpy().T, dbg["ancestors"])
+    assert _bits_equal(out["weights"].cpu().numpy(), ref["weights"])
+    assert _bits_equal(out["particles"].cpu().numpy(), ref["particles"])
+    # the libm-arithmetic oracle agrees to rounding
+    ref0 = go.bootstrap_particle_filter(po, ys, N, key=key, inputs=inputs.reshape(T, 1), resampler=resampler)
+    assert np.max(np.abs(out["weights"].cpu().numpy()[:, 0] - ref0["weights"][:, 0])) < 1e-6
 
 
 def test_bpf_errors():
@@ -237,6 +296,10 @@ def test_sixteen_thousand_particles_for_small_states():
     if t_ok >= 1:
         assert cm.rel_err(out["particles"].cpu().numpy()[:, :t_ok], ref["particles"][:, :t_ok]) < 2e-5
         assert np.max(np.abs(out["weights"].cpu().numpy()[:, :t_ok] - ref["weights"][:, :t_ok])) < 1e-6
+    # against the oracle on the engine's own (canonical) arithmetic: every ancestor, weight and particle of all steps
+    refc, dbgc = go.bootstrap_particle_filter(po, ys, N, key=key, inputs=inputs.reshape(T, 1), debug=True, arith="canonical")
+    assert np.array_equal(anc, np.asarray(dbgc["ancestors"]).T)
+    assert _bits_equal(out["weights"].cpu().numpy(), refc["weights"]) and _bits_equal(out["particles"].cpu().numpy(), refc["particles"])
 
 
 @pytest.mark.parametrize("N,resampler", [(20000, "multinomial"), (17000, "systematic"), (70000, "multinomial")])

@@ -133,3 +133,30 @@ def test_canonical_particle_filter_agrees_with_the_libm_oracle():
         a = lp.logprob_c(X, y, u)
         b = np.array([lp(X[i], y, u) for i in range(64)], F32)
         assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1)) < 5e-6
+
+
+def test_engine_host_trig_equals_oracle_bit_for_bit():
+    """canon_sincos / canon_atan2 (csrc/bf_canon_math.hpp, host build) against oracle/fp32.py, and their accuracy against
+    float64: Cephes single-precision algorithms, < 2 ulp for |x| <= 64 and 3e-7 absolute up to 8192 (sin, cos), <= 3 ulp (atan2)."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([np.array([0.0, -0.0, 1e-30, 0.78539816, 0.7853982, 1.5707964, 3.1415927, -3.1415927, 6.2831855, 100.0,
+                                  8191.9, 8192.0], F32),
+                        (rng.normal(size=300000) * 20).astype(F32), (rng.normal(size=100000) * 1e-3).astype(F32),
+                        rng.uniform(-8192, 8192, 100000).astype(F32)])
+    sn, cs = fp32.sincos(x)
+    assert _same_bits(_host_eval(3, x), sn) and _same_bits(_host_eval(4, x), cs)
+    xd = x.astype(np.float64)
+    near = np.abs(x) <= 64          # relative accuracy where the three-part reduction is exact enough; absolute beyond
+    assert _ulps(sn[near], np.sin(xd[near])).max() < 2.0 and _ulps(cs[near], np.cos(xd[near])).max() < 2.0
+    assert np.abs(sn - np.sin(xd)).max() < 3e-7 and np.abs(cs - np.cos(xd)).max() < 3e-7
+    y = np.concatenate([np.array([0.0, 0.0, 1.0, -1.0, 0.0, 1.0, -1.0, 1.0, -1.0, 1e-30, 1e30], F32), rng.normal(size=300000).astype(F32),
+                        (rng.normal(size=100000) * 1e3).astype(F32)])
+    xx = np.concatenate([np.array([1.0, -1.0, 0.0, 0.0, 0.0, 1.0, 1.0, -1.0, -1.0, 1e30, 1e-30], F32), rng.normal(size=300000).astype(F32),
+                         rng.normal(size=100000).astype(F32)])
+    a = fp32.atan2(y, xx)
+    from bayesianfiltering_amd import _lib
+    yx, got = np.ascontiguousarray(np.concatenate([y, xx])), np.empty(y.size, F32)
+    _lib.check(_lib.load().bf_canon_eval_f32(5, yx.ctypes.data_as(C.c_void_p), y.size, got.ctypes.data_as(C.c_void_p), 0, None))
+    assert _same_bits(got, a)
+    nz = (y != 0) & (xx != 0)
+    assert _ulps(a[nz], np.arctan2(y[nz].astype(np.float64), xx[nz].astype(np.float64))).max() < 3.5
