@@ -24,6 +24,8 @@ int launch_kf_group(const bf_lgssm* p, const bf_cstream* y, long long B, long lo
 
 int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
                    const bf_out_desc* out, hipStream_t stream);
+int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry, const bf_out_desc* out,
+                   hipStream_t stream);
 int launch_kf_generic(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
                       const bf_out_desc* out, hipStream_t stream);
 int launch_gsf_generic(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int K,
@@ -77,6 +79,7 @@ __global__ void canon_eval_kernel(int op, const float* __restrict__ in, long lon
   out[i] = canon_eval_one(op, in, n, i);
 }
 
+static std::atomic<int> g_kf_small_mode{1};   // bf_set_option "kf_small_mode": 1 = one-wave matrix-core kernel for 9 <= n <= 32 (default), 0 = off
 static std::atomic<int> g_force_generic{0};  // 1 = run the run-time-dimension kernel even where a compiled instance exists
 
 // A shape / option the compiled instances do not cover falls through to the run-time-dimension kernel
@@ -144,6 +147,11 @@ int bf_set_option(const char* name, int value) {
     bf::g_kf_mfma_variant = value;
     return BF_OK;
   }
+  if (name && std::strcmp(name, "kf_small_mode") == 0) {
+    if (value < 0 || value > 1) return bf::set_error(BF_EINVAL, "kf_small_mode must be 0 or 1");
+    bf::g_kf_small_mode = value;
+    return BF_OK;
+  }
   if (name && std::strcmp(name, "force_generic") == 0) {
     if (value < 0 || value > 1) return bf::set_error(BF_EINVAL, "force_generic must be 0 or 1");
     bf::g_force_generic = value;
@@ -204,6 +212,10 @@ int bf_kalman_filter_f32(const bf_lgssm* model, const bf_cstream* y, int64_t B, 
   if (bf::g_force_generic.load()) return generic();
   // dense products large enough for the matrix cores: (64, 32) itself and, zero-padded into its tiles, every model from
   // n = 24 up (4.9e7 steps/s whatever the size; the run-time-dimension kernel does 3.8e7 at n = 24, 1.6e7 at 32, 1.2e6 at 64)
+  // 9 <= n <= 32: one wave per trajectory on single 32 x 32 tiles, 1.15e8 steps/s whatever the size; the run-time-dimension
+  // kernel is faster only for the smallest of them (n = 12, m = 4: 1.7e8; n = 16, m = 8: 1.0e8; (32, 32): 3.5e6)
+  if (model->n >= 9 && model->n <= 32 && model->m <= 32 && (model->n >= 16 || model->m > 8) && bf::g_kf_small_mode.load() != 0)
+    return bf::with_generic_fallback(bf::launch_kf_bf32(model, y, B, T, carry, out, hs), generic);
   if (model->n >= 24 && model->n <= 64 && model->m <= 32)
     return bf::with_generic_fallback(bf::launch_kf_mfma(model, y, B, T, carry, out, hs), generic);
   return bf::with_generic_fallback(

@@ -29,6 +29,7 @@
 // factor of the un-jittered S exactly like the reference (inference.py:104, :24).
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 #include "bf_common.hpp"
 #include "kf_math.hpp"
 #include "lane_group.hpp"
@@ -555,11 +556,14 @@ __device__ __forceinline__ Split3 split_pair(float x0, float x1) {
 }
 
 // BF = false: W (fp32) -> sT rows 32..63.  BF = true (variant 5): W^T as three bf16 terms, wt[p][lane][k], 80-byte rows.
-template <bool BF>
+// NCOL = 64: every lane carries its own column of H P (pitch 65); NCOL = 32 (the one-wave kernel for n <= 32): the upper
+// half-wave repeats the lower one's columns (pitch 33), its stores land on the same addresses with the same values.
+template <bool BF, int NCOL = 64>
 __device__ __forceinline__ void chol_w_rows_impl(lds_f* sc, lds_f* sT, lds_f* sv, lds_f* mcur, lds_f* mnxt, lds_f* scv,
-                                                 lds_c* wt, int lane) {
-  constexpr int PP = 65, PS = 33;
-  const int r = lane & 31;
+                                                 lds_c* wt, int lane_in) {
+  constexpr int PP = NCOL + 1, PS = 33, WT_TERM_B = NCOL * 80;
+  const int r = lane_in & 31;
+  const int lane = NCOL == 64 ? lane_in : r;
   f32x2 aw[32];  // .x: row r of S + 1e-6 (psd_solve's jitter on every entry, utils.py:258); .y: column `lane` of H P
   BF_UNROLL for (int k = 0; k < 32; ++k) aw[k] = f32x2{sc[r * PS + k] + 1e-6f, sT[k * PP + lane]};
   f32x2 rgz = f32x2{1.0f, sv[r]};  // residuals of g = L^-1 1, z = L^-1 v (row r)
@@ -595,9 +599,9 @@ __device__ __forceinline__ void chol_w_rows_impl(lds_f* sc, lds_f* sT, lds_f* sv
       wsp[(j >> 1) & 3] = split_pair(aw[j - 1].y, aw[j].y);
       if constexpr ((j & 7) == 7) {
         constexpr int q = j >> 3;
-        *reinterpret_cast<lds_u32x4*>(wt + 0 * 5120 + lane * 80 + q * 16) = u32x4{wsp[0].hi, wsp[1].hi, wsp[2].hi, wsp[3].hi};
-        *reinterpret_cast<lds_u32x4*>(wt + 1 * 5120 + lane * 80 + q * 16) = u32x4{wsp[0].mid, wsp[1].mid, wsp[2].mid, wsp[3].mid};
-        *reinterpret_cast<lds_u32x4*>(wt + 2 * 5120 + lane * 80 + q * 16) = u32x4{wsp[0].lo, wsp[1].lo, wsp[2].lo, wsp[3].lo};
+        *reinterpret_cast<lds_u32x4*>(wt + 0 * WT_TERM_B + lane * 80 + q * 16) = u32x4{wsp[0].hi, wsp[1].hi, wsp[2].hi, wsp[3].hi};
+        *reinterpret_cast<lds_u32x4*>(wt + 1 * WT_TERM_B + lane * 80 + q * 16) = u32x4{wsp[0].mid, wsp[1].mid, wsp[2].mid, wsp[3].mid};
+        *reinterpret_cast<lds_u32x4*>(wt + 2 * WT_TERM_B + lane * 80 + q * 16) = u32x4{wsp[0].lo, wsp[1].lo, wsp[2].lo, wsp[3].lo};
       }
     }
   });
@@ -616,6 +620,10 @@ __device__ __forceinline__ void chol_w_rows_impl(lds_f* sc, lds_f* sT, lds_f* sv
 __device__ __attribute__((noinline)) void chol_w_rows_bf(lds_f* sc, lds_f* sT, lds_f* sv, lds_f* mcur, lds_f* mnxt, lds_f* scv, lds_c* wt,
                                                          int lane) {
   chol_w_rows_impl<true>(sc, sT, sv, mcur, mnxt, scv, wt, lane);
+}
+__device__ __attribute__((noinline)) void chol_w_rows_bf32(lds_f* sc, lds_f* sT, lds_f* sv, lds_f* mcur, lds_f* mnxt, lds_f* scv, lds_c* wt,
+                                                           int lane) {
+  chol_w_rows_impl<true, 32>(sc, sT, sv, mcur, mnxt, scv, wt, lane);
 }
 // out of line for variants 2 / 4 (a register allocation of its own); variant 5 inlines the body (it holds 112 operand
 // registers across the factorization, which a call would spill and reload)
@@ -1366,6 +1374,270 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
   __syncthreads();
   if (b == 0 && lane == 0 && carry.P_out) for (int i = 0; i < 12; ++i) carry.P_out[wave * 16 + i] = (float)tacc[i];
 #endif
+}
+
+// =======================================================================================================================
+// n <= 32, m <= 32: ONE WAVE per trajectory.  Every matrix is a single 32 x 32 tile, so the whole step of variant 5 --
+// Z = P-^T H^T, S^T = H Z, the two factorizations, P+ = P- - W^T W + c c^T, Y^T = P+^T A^T, P- = Y A^T + G Q G^T, all as
+// three-term bf16 products -- runs inside one wave without a single barrier (a wave's LDS traffic executes in issue
+// order), no wave ever waits for another's factorization, and the CU holds six independent trajectories (24.3 KB of LDS
+// each, two per workgroup) instead of two workgroups with three of four waves idle through the serial phase.
+// Smaller models ride zero-padded in the tile exactly as in launch_kf_mfma.
+struct Bf32Const {
+  unsigned short A3[3][32 * 32], H3[3][32 * 32];
+  float GQG[32 * 32], DRD[32 * 32], Gq0[32], Dr0[32];
+};
+__device__ __forceinline__ float dot_terms32(const u32x4 (*x)[2], const float* v, int lk) {  // sum over the lane's 16 k
+  float s = 0.f;
+  BF_UNROLL for (int c = 0; c < 2; ++c) BF_UNROLL for (int d = 0; d < 4; ++d) {
+    const float x0 = (bf_lo(x[0][c][d]) + bf_lo(x[1][c][d])) + bf_lo(x[2][c][d]);
+    const float x1 = (bf_hi(x[0][c][d]) + bf_hi(x[1][c][d])) + bf_hi(x[2][c][d]);
+    s = fmaf(x0, v[16 * c + 8 * lk + 2 * d], s);
+    s = fmaf(x1, v[16 * c + 8 * lk + 2 * d + 1], s);
+  }
+  return s;
+}
+// one 32 x 32 accumulator tile of a [nr][nr] stream entry at (b, t)
+__device__ __forceinline__ void store_tile32(const SView& sv, long long b, long long t, int lane, const f32x16& acc, int nr) {
+  if (!sv.p) return;
+  const int lr = lane & 31, lk = lane >> 5;
+  gl_f* base = per_step(sv.p + b * sv.sB + t * sv.sT);
+  const long long sE = sv.sE + (long long)opaque_szero();
+  BF_UNROLL for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+    if (lr < nr && row < nr) __builtin_nontemporal_store(acc[r], base + (long long)(row * nr + lr) * sE);
+  }
+}
+
+constexpr int BF32_WAVE_LDS = 3 * 32 * 80 + (3 * 32 * 80 + 2 * 32 * 33 * 4) + 4 * 32 * 4;   // bytes per trajectory
+
+__global__ void __launch_bounds__(128, 2)
+kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry, OutViews out, long long B, long long T, int nr, int mr) {
+  constexpr int PITCH = 80, TERM = 32 * PITCH, PS = 33;
+  const int lane = threadIdx.x & 63;
+  const int lr = lane & 31, lk = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long b_raw = (long long)blockIdx.x * 2 + wv;
+  if (b_raw >= B) return;   // (no workgroup barrier anywhere below)
+  const long long b = b_raw;
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  lds_c* L = (lds_c*)reinterpret_cast<char*>(lds) + wv * BF32_WAVE_LDS;
+  lds_c* Pn = L;                       // [3][32][80 B]  P- / P+, transposed terms
+  lds_c* Zn = L + 3 * TERM;            // [3][32][80 B]  Z = (H P-)^T; later W^T, then Y^T
+  lds_c* Wt = Zn;
+  lds_c* Yn = Zn;
+  float* sHP = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + wv * BF32_WAVE_LDS + 6 * TERM);   // [32][33] H P- (fp32)
+  float* sc = sHP + 32 * PS;           // [32][33]  S
+  float* sm = sc + 32 * PS;            // [32] predicted mean
+  float* sm2 = sm + 32;                // [32] filtered mean
+  float* sv = sm2 + 32;                // [32] innovation
+  float* scv = sv + 32;                // [32] 1e-3 W^T g
+
+  u32x4 hop[3][2], aop[3][2];          // row lr of H and of A as bf16 terms
+  BF_UNROLL for (int q = 0; q < 3; ++q) BF_UNROLL for (int c = 0; c < 2; ++c) {
+    hop[q][c] = *reinterpret_cast<const u32x4*>(&cst->H3[q][lr * 32 + 16 * c + 8 * lk]);
+    aop[q][c] = *reinterpret_cast<const u32x4*>(&cst->A3[q][lr * 32 + 16 * c + 8 * lk]);
+  }
+  const float dr0 = cst->Dr0[lr], gq0 = cst->Gq0[lr];
+  f32x16 Pacc;
+  BF_UNROLL for (int r = 0; r < 16; ++r) {
+    const int row = c_row(r, lane);
+    Pacc[r] = (lr < nr && row < nr) ? carry.P_in[b * nr * nr + row * nr + lr] : 0.f;
+  }
+  store_terms_transposed(Pn, TERM, PITCH, 0, 0, lane, Pacc);
+  sm[lr] = lr < nr ? carry.m_in[b * nr + lr] : 0.f;
+  float w = carry.w_in ? carry.w_in[b] : 1.0f;
+  float ynext = lr < mr ? y.p[b * y.sB + lr * y.sE] : 0.f;
+  const float ll_pad = 0.5f * 1.8378770664093453f * (float)(32 - mr);
+  wave_lds_order();
+
+  for (long long t = 0; t < T; ++t) {
+    // ---- Z = P-^T H^T; H P- in fp32 for the forward substitution; innovation
+    {
+      f32x16 z = {0};
+      BF_UNROLL for (int c = 0; c < 2; ++c) {
+        u32x4 a[3];
+        load_terms(a, Pn, TERM, PITCH, lr, c, lk);
+        const u32x4 bh[3] = {hop[0][c], hop[1][c], hop[2][c]};
+        z = mfma_bf6(a, bh, z);
+      }
+      BF_UNROLL for (int r = 0; r < 16; ++r) sHP[lr * PS + c_row(r, lane)] = z[r];
+      store_terms_transposed(Zn, TERM, PITCH, 0, 0, lane, z);
+      const float yv = ynext;
+      const long long tn = t + 1 < T ? t + 1 : t;
+      if (lr < mr) ynext = y.p[b * y.sB + tn * y.sT + lr * y.sE];
+      float s = dot_terms32(hop, sm, lk);
+      s += __shfl_xor(s, 32, 64);
+      sv[lr] = yv - (s + dr0);
+    }
+    wave_lds_order();
+    // ---- S^T = H Z + (D R D^T)^T
+    {
+      f32x16 acc;
+      gl_cf* drd = per_step(cst->DRD);
+      BF_UNROLL for (int r = 0; r < 16; ++r) acc[r] = drd[lr * 32 + c_row(r, lane)];
+      BF_UNROLL for (int c = 0; c < 2; ++c) {
+        u32x4 bz[3];
+        load_terms(bz, Zn, TERM, PITCH, lr, c, lk);
+        const u32x4 ah[3] = {hop[0][c], hop[1][c], hop[2][c]};
+        acc = mfma_bf6(ah, bz, acc);
+      }
+      BF_UNROLL for (int r = 0; r < 16; ++r) sc[lr * PS + c_row(r, lane)] = acc[r];
+    }
+    wave_lds_order();
+    // ---- the two factorizations: log-likelihood from chol(S), then W^T (over Z's terms), c, m+ from chol(S + 1e-6)
+    const float ll = chol_loglik_rows((lds_f*)sc, (lds_f*)sv, lane) + ll_pad;
+    chol_w_rows_bf32((lds_f*)sc, (lds_f*)sHP, (lds_f*)sv, (lds_f*)sm, (lds_f*)sm2, (lds_f*)scv, Wt, lane);
+    wave_lds_order();
+    // ---- P+ = P- - W^T W + c c^T; filtered streams
+    {
+      f32x16 acc = Pacc;
+      BF_UNROLL for (int c = 0; c < 2; ++c) {
+        u32x4 a[3], bw[3];
+        load_terms(bw, Wt, TERM, PITCH, lr, c, lk);
+        BF_UNROLL for (int q = 0; q < 3; ++q) a[q] = bw[q] ^ 0x80008000u;
+        acc = mfma_bf6(a, bw, acc);
+      }
+      const float cv = lk == 0 ? scv[lr] : 0.f;
+      acc = mfma2(cv, cv, acc);
+      store_tile32(out.P, b, t, lane, acc, nr);
+      wave_lds_order();   // (W^T's terms are read before Y^T overwrites them below; P-'s before P+'s here)
+      store_terms_transposed(Pn, TERM, PITCH, 0, 0, lane, acc);
+      if (out.m.p && lane < nr) out.m.p[b * out.m.sB + t * out.m.sT + lane * out.m.sE] = sm2[lane];
+      if (lane == 0) {
+        w = reweight_single(ll, w);
+        if (out.w.p) out.w.p[b * out.w.sB + t * out.w.sT] = w;
+        if (out.ll.p) out.ll.p[b * out.ll.sB + t * out.ll.sT] = ll;
+      }
+    }
+    wave_lds_order();
+    // ---- Y^T = P+^T A^T; m- = A m+ + G q0
+    {
+      f32x16 acc = {0};
+      BF_UNROLL for (int c = 0; c < 2; ++c) {
+        u32x4 a[3];
+        load_terms(a, Pn, TERM, PITCH, lr, c, lk);
+        const u32x4 ba[3] = {aop[0][c], aop[1][c], aop[2][c]};
+        acc = mfma_bf6(a, ba, acc);
+      }
+      store_terms_transposed(Yn, TERM, PITCH, 0, 0, lane, acc);
+      float s = dot_terms32(aop, sm2, lk);
+      s += __shfl_xor(s, 32, 64);
+      sm[lr] = s + gq0;
+    }
+    wave_lds_order();
+    // ---- P- = Y A^T + G Q G^T; predicted streams
+    {
+      gl_cf* gqg = per_step(cst->GQG);
+      float gq[16];
+      BF_UNROLL for (int r = 0; r < 16; ++r) gq[r] = gqg[c_row(r, lane) * 32 + lr];
+      BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] = 0.f;
+      BF_UNROLL for (int c = 0; c < 2; ++c) {
+        u32x4 a[3];
+        load_terms(a, Yn, TERM, PITCH, lr, c, lk);
+        const u32x4 ba[3] = {aop[0][c], aop[1][c], aop[2][c]};
+        Pacc = mfma_bf6(a, ba, Pacc);
+      }
+      BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] += gq[r];
+      store_tile32(out.pP, b, t, lane, Pacc, nr);
+      store_terms_transposed(Pn, TERM, PITCH, 0, 0, lane, Pacc);
+      if (out.pm.p && lane < nr) out.pm.p[b * out.pm.sB + t * out.pm.sT + lane * out.pm.sE] = sm[lane];
+    }
+    wave_lds_order();
+  }
+
+  if (carry.P_out && lr < nr) BF_UNROLL for (int r = 0; r < 16; ++r) {
+      const int row = c_row(r, lane);
+      if (row < nr) carry.P_out[b * nr * nr + row * nr + lr] = Pacc[r];
+    }
+  if (carry.m_out && lane < nr) carry.m_out[b * nr + lane] = sm[lane];
+  if (carry.w_out && lane == 0) carry.w_out[b] = w;
+}
+
+int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry, const bf_out_desc* out,
+                   hipStream_t stream) {
+  constexpr int N = 32;
+  const int nr = p->n, mr = p->m, dq = p->dq, dr = p->dr;
+  if (nr > N || mr > N) return set_error(BF_EUNSUPPORTED, "one-wave matrix-core Kalman kernel: n <= 32 and m <= 32");
+  if (p->Q_steps > 1 || p->R_steps > 1)
+    return set_error(BF_EUNSUPPORTED, "time-varying Q/R are not supported on the matrix-core Kalman kernels");
+  Bf32Const* h = new Bf32Const();
+  std::memset(h, 0, sizeof(*h));
+  auto Gat = [&](int i, int k) { return p->G ? p->G[i * dq + k] : (i == k ? 1.f : 0.f); };
+  auto Dat = [&](int i, int k) { return p->D ? p->D[i * dr + k] : (i == k ? 1.f : 0.f); };
+  auto bf = [](float x) {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+  };
+  auto fl = [](unsigned short hbits) {
+    const uint32_t u = (uint32_t)hbits << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+  };
+  for (int i = 0; i < nr; ++i)
+    for (int j = 0; j < nr; ++j) {
+      float x = p->A[i * nr + j];
+      for (int t3 = 0; t3 < 3; ++t3) { const unsigned short hb = bf(x); h->A3[t3][i * N + j] = hb; x -= fl(hb); }
+    }
+  for (int i = 0; i < mr; ++i)
+    for (int j = 0; j < nr; ++j) {
+      float x = p->H[i * nr + j];
+      for (int t3 = 0; t3 < 3; ++t3) { const unsigned short hb = bf(x); h->H3[t3][i * N + j] = hb; x -= fl(hb); }
+    }
+  {  // (G Q) G^T and (D R) D^T, association of inference.py:69,:100
+    std::vector<float> GQ((size_t)nr * dq), DRm((size_t)mr * dr);
+    for (int i = 0; i < nr; ++i)
+      for (int l = 0; l < dq; ++l) {
+        float s = 0.f;
+        for (int k = 0; k < dq; ++k) s = fmaf(Gat(i, k), p->Q[k * dq + l], s);
+        GQ[i * dq + l] = s;
+      }
+    for (int i = 0; i < nr; ++i)
+      for (int j = 0; j < nr; ++j) {
+        float s = 0.f;
+        for (int l = 0; l < dq; ++l) s = fmaf(GQ[i * dq + l], Gat(j, l), s);
+        h->GQG[i * N + j] = s;
+      }
+    for (int i = 0; i < mr; ++i)
+      for (int l = 0; l < dr; ++l) {
+        float s = 0.f;
+        for (int k = 0; k < dr; ++k) s = fmaf(Dat(i, k), p->R[k * dr + l], s);
+        DRm[i * dr + l] = s;
+      }
+    for (int i = 0; i < mr; ++i)
+      for (int j = 0; j < mr; ++j) {
+        float s = 0.f;
+        for (int l = 0; l < dr; ++l) s = fmaf(DRm[i * dr + l], Dat(j, l), s);
+        h->DRD[i * N + j] = s;
+      }
+    for (int i = mr; i < N; ++i) h->DRD[i * N + i] = 1.0f;   // padded observations: unit noise
+  }
+  for (int i = 0; i < nr; ++i) {
+    float s = 0.f;
+    for (int k = 0; k < dq; ++k) s = fmaf(Gat(i, k), p->q0 ? p->q0[k] : 0.f, s);
+    h->Gq0[i] = s;
+  }
+  for (int i = 0; i < mr; ++i) {
+    float s = 0.f;
+    for (int k = 0; k < dr; ++k) s = fmaf(Dat(i, k), p->r0 ? p->r0[k] : 0.f, s);
+    h->Dr0[i] = s;
+  }
+  const void* dv = nullptr;
+  const int crc = device_constants(h, sizeof(*h), stream, &dv);
+  delete h;
+  if (crc != BF_OK) return crc;
+  CView yv{y->ptr, y->sB, y->sT, y->sE};
+  CarryView cv{carry->w_in, carry->m_in, carry->P_in, carry->w_out, carry->m_out, carry->P_out};
+  OutViews ov{make_sview(out->weights), make_sview(out->means), make_sview(out->covs),
+              make_sview(out->pred_means), make_sview(out->pred_covs), make_sview(out->loglik)};
+  hipLaunchKernelGGL(kf_scan_bf32_kernel, dim3((unsigned)((B + 1) / 2)), dim3(128), 2 * BF32_WAVE_LDS, stream,
+                     static_cast<const Bf32Const*>(dv), yv, cv, ov, B, T, nr, mr);
+  BF_HIP_CHECK(hipGetLastError());
+  return BF_OK;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -130,6 +130,9 @@ int bf_device_count(void);
  *                   eliminations; 4 = 2 at three workgroups per CU; 1 = round 1's kernel (explicit inverse through LDS).
  *                   Same results to rounding (< 5e-6 against the test oracle over 2 000 steps); env BAYESFILT_MFMA_VARIANT
  *                   sets the default.
+ *   "kf_small_mode": 1 (default) = Kalman models with 9 <= n <= 32, m <= 32 run on the one-wave-per-trajectory matrix-core
+ *                   kernel (single 32 x 32 tiles, bf16 three-term products); 0 = off (n >= 24 then rides padded in the
+ *                   (64, 32) kernel, smaller n on the run-time-dimension kernel).
  *   "force_generic": 1 = bf_kalman_filter_f32 / bf_gsf_ekf_f32 run the run-time-dimension kernel (any n, m, K; state in
  *                   LDS) even where a compile-time-dimension instance exists (test hook; default 0).
  *   "gsf_structured": 1 (default) lets bf_gsf_ekf_f32 use the structure-aware kernel instances

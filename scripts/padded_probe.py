@@ -7,7 +7,7 @@ import bayesianfiltering_amd as bfa
 from bayesianfiltering_amd import _lib
 from tests import common as cm
 lib = _lib.require_gpu()
-for n, m, B, T in ((20, 8, 8192, 100), (24, 12, 8192, 100), (32, 16, 8192, 100), (48, 24, 8192, 50), (64, 16, 8192, 50), (64, 32, 8192, 50)):
+for n, m, B, T in ((12, 4, 16384, 100), (16, 8, 16384, 100), (20, 8, 16384, 100), (24, 12, 16384, 100), (32, 16, 16384, 100), (32, 32, 16384, 100), (48, 24, 8192, 50), (64, 16, 8192, 50), (64, 32, 8192, 50)):
     a = cm.random_stable_lgssm(n, m, seed=n)
     p = cm.product_params(a)
     y = torch.randn((B, T, m), device="cuda")

@@ -165,16 +165,18 @@ def test_data_generator_lorenz96_n40():
     assert cm.rel_err(xs.cpu().numpy(), rx) < 2e-6 and cm.rel_err(ys.cpu().numpy(), ry) < 2e-6
 
 
-@pytest.mark.parametrize("n,m", [(24, 5), (32, 16), (33, 32), (40, 24), (48, 20), (64, 16), (64, 1), (64, 32)])
+@pytest.mark.parametrize("n,m", [(9, 9), (12, 30), (16, 8), (17, 3), (24, 5), (32, 16), (32, 32), (33, 32), (40, 24), (48, 20),
+                                 (64, 16), (64, 1), (64, 32)])
 def test_models_padded_into_the_matrix_core_kernel(n, m):
-    """From n = 24 up (m <= 32) the Kalman scan runs on the (64, 32) matrix-core kernel with the model zero-padded into
-    its tiles (unit-noise dummy observations, their log N(0; 0, 1) taken off the log-likelihood): against the oracle at
-    1e-5, against the run-time-dimension kernel, and chunked through the carry == one shot bit for bit."""
+    """Kalman models ride zero-padded in matrix-core tiles (unit-noise dummy observations, their log N(0; 0, 1) taken off
+    the log-likelihood): up to n = 32 on the one-wave-per-trajectory kernel (single 32 x 32 tiles), from there to n = 64 in
+    the (64, 32) kernel -- against the oracle at 1e-5, against the run-time-dimension kernel, and chunked through the carry
+    == one shot bit for bit."""
     import bayesianfiltering_amd as bfa
     dq, dr = max(1, n - 3), max(1, m - (n % 2))
     a = cm.random_stable_lgssm(n, m, seed=11 * n + m, dq=dq, dr=dr, bias=True)
     B, T = 6, 40
-    ys = cm.simulate_batch(a, B, T, seed=n - m)
+    ys = cm.simulate_batch(a, B, T, seed=abs(n - m) + 1)
     init = np.tile(a["m0"], (B, 1)) + 0.05 * np.arange(B, dtype=F32)[:, None]
     ref = c_oracle.kalman_filter(a, ys, init)
     p = cm.product_params(a)
@@ -193,3 +195,24 @@ def test_models_padded_into_the_matrix_core_kernel(n, m):
         whole = getattr(fast, k).cpu().numpy()
         assert np.array_equal(np.concatenate([getattr(h1, k).cpu().numpy(), getattr(h2, k).cpu().numpy()], axis=2), whole), k
     assert np.array_equal(c2.covariances.cpu().numpy(), carry.covariances.cpu().numpy())
+
+
+@pytest.mark.parametrize("n,m", [(16, 8), (24, 12), (32, 16)])
+def test_small_mode_off_routes_to_the_other_kernels(n, m):
+    """bf_set_option("kf_small_mode", 0): the same models on the (64, 32) kernel (n >= 24) or the run-time-dimension kernel."""
+    import bayesianfiltering_amd as bfa
+    from bayesianfiltering_amd import _lib
+    a = cm.random_stable_lgssm(n, m, seed=n + m, bias=True)
+    B, T = 4, 25
+    ys = cm.simulate_batch(a, B, T, seed=1)
+    init = np.tile(a["m0"], (B, 1))
+    ref = c_oracle.kalman_filter(a, ys, init)
+    lib = _lib.require_gpu()
+    _lib.check(lib.bf_set_option(b"kf_small_mode", 0))
+    try:
+        post, ll = bfa.kalman_filter(cm.product_params(a), ys, initial_means=init, return_loglik=True)
+    finally:
+        _lib.check(lib.bf_set_option(b"kf_small_mode", 1))
+    for k in FIELDS:
+        assert cm.rel_err(getattr(post, k).cpu().numpy(), ref[k]) < 1e-5, k
+    assert cm.rel_err(ll.cpu().numpy(), ref["loglik"]) < 5e-5
