@@ -558,9 +558,14 @@ __device__ __forceinline__ Split3 split_pair(float x0, float x1) {
 // BF = false: W (fp32) -> sT rows 32..63.  BF = true (variant 5): W^T as three bf16 terms, wt[p][lane][k], 80-byte rows.
 // NCOL = 64: every lane carries its own column of H P (pitch 65); NCOL = 32 (the one-wave kernel for n <= 32): the upper
 // half-wave repeats the lower one's columns (pitch 33), its stores land on the same addresses with the same values.
-template <bool BF, int NCOL = 64>
-__device__ __forceinline__ void chol_w_rows_impl(lds_f* sc, lds_f* sT, lds_f* sv, lds_f* mcur, lds_f* mnxt, lds_f* scv,
-                                                 lds_c* wt, int lane_in) {
+// LL: also returns log N(v; 0, S) for the UN-jittered S, from this factorization of S_j = S + eps 1 1^T (eps = 1e-6) by
+// the matrix determinant lemma and Sherman-Morrison: with g = L^-1 1, z = L^-1 v (both carried through the loop anyway)
+//   det S = det S_j (1 - eps g^T g),   v^T S^-1 v = z^T z + eps (g^T z)^2 / (1 - eps g^T g)
+// -- exact identities, evaluated in fp32 (eps g^T g is O(1e-4) for a conditioned S): the separate factorization of S that
+// inference.py:104 implies (a second 1 200-instruction serial chain) is not needed.
+template <bool BF, int NCOL = 64, bool LL = false>
+__device__ __forceinline__ float chol_w_rows_impl(lds_f* sc, lds_f* sT, lds_f* sv, lds_f* mcur, lds_f* mnxt, lds_f* scv,
+                                                  lds_c* wt, int lane_in) {
   constexpr int PP = NCOL + 1, PS = 33, WT_TERM_B = NCOL * 80;
   const int r = lane_in & 31;
   const int lane = NCOL == 64 ? lane_in : r;
@@ -568,6 +573,7 @@ __device__ __forceinline__ void chol_w_rows_impl(lds_f* sc, lds_f* sT, lds_f* sv
   BF_UNROLL for (int k = 0; k < 32; ++k) aw[k] = f32x2{sc[r * PS + k] + 1e-6f, sT[k * PP + lane]};
   f32x2 rgz = f32x2{1.0f, sv[r]};  // residuals of g = L^-1 1, z = L^-1 v (row r)
   f32x2 acc_cm = f32x2{0.f, 0.f};  // (W^T g)[lane], (W^T z)[lane]
+  float s_gg = 0.f, s_gz = 0.f, s_zz = 0.f, rprod = 1.f;   // LL: g^T g, g^T z, z^T z, prod 1 / L_jj (wave-uniform)
   Split3 wsp[4];
   static_for<0, 32>([&](auto J) {
     constexpr int j = decltype(J)::value;
@@ -577,6 +583,12 @@ __device__ __forceinline__ void chol_w_rows_impl(lds_f* sc, lds_f* sT, lds_f* sv
     aw[j] = lw;
     rgz = __builtin_elementwise_fma(f32x2{-lw.x, -lw.x}, gz, rgz);
     acc_cm = __builtin_elementwise_fma(f32x2{lw.y, lw.y}, gz, acc_cm);
+    if constexpr (LL) {
+      s_gg = fmaf(gz.x, gz.x, s_gg);
+      s_gz = fmaf(gz.x, gz.y, s_gz);
+      s_zz = fmaf(gz.y, gz.y, s_zz);
+      rprod *= rinv;
+    }
     const f32x2 ntq = -(lw * rinv);                                    // -a[r][j] / d_j, -w[j] / d_j
     // L[k][j] sqrt(d_j) = a[k][j] = a[j][k] by symmetry: lane j's own entries, read BEFORE this step updates them.
     // The broadcasts go out in batches of BF_MFMA_RDB ahead of the multiply-adds that consume them: a v_readlane's
@@ -610,9 +622,21 @@ __device__ __forceinline__ void chol_w_rows_impl(lds_f* sc, lds_f* sT, lds_f* sv
   }
   scv[lane] = acc_cm.x * 1e-3f;                            // sqrt(1e-6) (W^T g): enters P+ as + c c^T
   mnxt[lane] = mcur[lane] + acc_cm.y;                      // filtered mean
+  if constexpr (LL) {
+    const float one_m = fmaf(-1e-6f, s_gg, 1.0f);                                   // 1 - eps g^T g
+    const float quad = s_zz + (1e-6f * s_gz) * s_gz / one_m;
+    return -0.5f * quad - 0.5f * 32.0f * 1.8378770664093453f + fast_log(rprod) - 0.5f * fast_log(one_m);
+  } else {
+    return 0.f;
+  }
 }
 #ifndef BF_V5_INLINE
 #define BF_V5_INLINE 0
+#endif
+#ifndef BF_V5_LL_LEMMA
+#define BF_V5_LL_LEMMA 0   // 1: log-likelihood from the jittered factorization (chol_w_rows_impl<.., LL = true>), wave 2 idle in phases B + C.
+                           // Measured -7 % (4.23e7 against 4.56e7 on one box): the extra sums lengthen the critical wave's chain, the
+                           // factorization they replace ran beside it.  (The one-wave kernel, where both chains are serial, gains 33 %.)
 #endif
 #ifndef BF_V5_HOP_RELOAD
 #define BF_V5_HOP_RELOAD 0
@@ -621,9 +645,13 @@ __device__ __attribute__((noinline)) void chol_w_rows_bf(lds_f* sc, lds_f* sT, l
                                                          int lane) {
   chol_w_rows_impl<true>(sc, sT, sv, mcur, mnxt, scv, wt, lane);
 }
-__device__ __attribute__((noinline)) void chol_w_rows_bf32(lds_f* sc, lds_f* sT, lds_f* sv, lds_f* mcur, lds_f* mnxt, lds_f* scv, lds_c* wt,
-                                                           int lane) {
-  chol_w_rows_impl<true, 32>(sc, sT, sv, mcur, mnxt, scv, wt, lane);
+__device__ __attribute__((noinline)) float chol_w_rows_bf_ll(lds_f* sc, lds_f* sT, lds_f* sv, lds_f* mcur, lds_f* mnxt, lds_f* scv, lds_c* wt,
+                                                             int lane) {
+  return chol_w_rows_impl<true, 64, true>(sc, sT, sv, mcur, mnxt, scv, wt, lane);
+}
+__device__ __attribute__((noinline)) float chol_w_rows_bf32(lds_f* sc, lds_f* sT, lds_f* sv, lds_f* mcur, lds_f* mnxt, lds_f* scv, lds_c* wt,
+                                                            int lane) {
+  return chol_w_rows_impl<true, 32, true>(sc, sT, sv, mcur, mnxt, scv, wt, lane);
 }
 // out of line for variants 2 / 4 (a register allocation of its own); variant 5 inlines the body (it holds 112 operand
 // registers across the factorization, which a call would spill and reload)
@@ -1256,7 +1284,7 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
     BF_TICK5(1)
     // ================= phases B + C (waves 2 and 3): S^T = H Z + (D R D^T)^T, the factorizations, W^T, c, m+
     float ll = 0.f;
-    if (wave >= 2) {
+    if (wave >= 2 + BF_V5_LL_LEMMA) {
       {  // innovation v = y - (H m- + D r0): both factorizing waves form it (same bits) for their own use
         const float yv = ynext;
         const long long tn = t + 1 < T ? t + 1 : t;
@@ -1279,6 +1307,8 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
 #if BF_V5_INLINE
       if (wave == 3) chol_w_rows_impl<true>((lds_f*)sc3, (lds_f*)sHP, (lds_f*)sv3, (lds_f*)mcur, (lds_f*)mnxt, (lds_f*)scv, Wt, lane);
       else ll = chol_loglik_rows_impl((lds_f*)sc2, (lds_f*)sv, lane) + ll_pad;
+#elif BF_V5_LL_LEMMA
+      ll = chol_w_rows_bf_ll((lds_f*)sc3, (lds_f*)sHP, (lds_f*)sv3, (lds_f*)mcur, (lds_f*)mnxt, (lds_f*)scv, Wt, lane) + ll_pad;
 #else
       if (wave == 3) chol_w_rows_bf((lds_f*)sc3, (lds_f*)sHP, (lds_f*)sv3, (lds_f*)mcur, (lds_f*)mnxt, (lds_f*)scv, Wt, lane);
       else ll = chol_loglik_rows((lds_f*)sc2, (lds_f*)sv, lane) + ll_pad;
@@ -1302,7 +1332,7 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
       store_terms_transposed(Pn, PN_TERM, PITCH, ti, tj, lane, acc);
     }
     if (wave == 1 && out.m.p && lane < nr) out.m.p[b * out.m.sB + t * out.m.sT + lane * out.m.sE] = mnxt[lane];
-    if (wave == 2 && lane == 0) {
+    if (wave == 2 + BF_V5_LL_LEMMA && lane == 0) {
       w = reweight_single(ll, w);
       if (out.w.p) out.w.p[b * out.w.sB + t * out.w.sT] = w;
       if (out.ll.p) out.ll.p[b * out.ll.sB + t * out.ll.sT] = ll;
@@ -1369,7 +1399,7 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
       if (row < nr) carry.P_out[b * nr * nr + row * nr + 32 * tj + lr] = Pacc[r];
     }
   if (carry.m_out && tid < nr) carry.m_out[b * nr + tid] = mcur[tid];
-  if (carry.w_out && wave == 2 && lane == 0) carry.w_out[b] = w;
+  if (carry.w_out && wave == 2 + BF_V5_LL_LEMMA && lane == 0) carry.w_out[b] = w;
 #ifdef BF_MFMA_PHASE_TIMERS
   __syncthreads();
   if (b == 0 && lane == 0 && carry.P_out) for (int i = 0; i < 12; ++i) carry.P_out[wave * 16 + i] = (float)tacc[i];
@@ -1486,9 +1516,8 @@ kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry,
       BF_UNROLL for (int r = 0; r < 16; ++r) sc[lr * PS + c_row(r, lane)] = acc[r];
     }
     wave_lds_order();
-    // ---- the two factorizations: log-likelihood from chol(S), then W^T (over Z's terms), c, m+ from chol(S + 1e-6)
-    const float ll = chol_loglik_rows((lds_f*)sc, (lds_f*)sv, lane) + ll_pad;
-    chol_w_rows_bf32((lds_f*)sc, (lds_f*)sHP, (lds_f*)sv, (lds_f*)sm, (lds_f*)sm2, (lds_f*)scv, Wt, lane);
+    // ---- ONE factorization, chol(S + 1e-6): W^T (over Z's terms), c, m+, and the log-likelihood of the un-jittered S
+    const float ll = chol_w_rows_bf32((lds_f*)sc, (lds_f*)sHP, (lds_f*)sv, (lds_f*)sm, (lds_f*)sm2, (lds_f*)scv, Wt, lane) + ll_pad;
     wave_lds_order();
     // ---- P+ = P- - W^T W + c c^T; filtered streams
     {
