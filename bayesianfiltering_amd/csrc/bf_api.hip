@@ -212,7 +212,7 @@ int bf_kalman_filter_f32(const bf_lgssm* model, const bf_cstream* y, int64_t B, 
   if (bf::g_force_generic.load()) return generic();
   // dense products large enough for the matrix cores: (64, 32) itself and, zero-padded into its tiles, every model from
   // n = 24 up (4.9e7 steps/s whatever the size; the run-time-dimension kernel does 3.8e7 at n = 24, 1.6e7 at 32, 1.2e6 at 64)
-  // 9 <= n <= 32: one wave per trajectory on single 32 x 32 tiles, 1.5e8 steps/s whatever the size; the run-time-dimension
+  // 9 <= n <= 32: one wave per trajectory on single 32 x 32 tiles, 1.8e8 steps/s whatever the size; the run-time-dimension
   // kernel is faster only for the smallest of them (n = 12, m = 4: 1.7e8; n = 16, m = 8: 1.0e8; (32, 32): 3.5e6)
   if (model->n >= 9 && model->n <= 32 && model->m <= 32 && (model->n >= 16 || model->m > 8) && bf::g_kf_small_mode.load() != 0)
     return bf::with_generic_fallback(bf::launch_kf_bf32(model, y, B, T, carry, out, hs), generic);

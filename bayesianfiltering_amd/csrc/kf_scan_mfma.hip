@@ -1410,7 +1410,7 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
 // n <= 32, m <= 32: ONE WAVE per trajectory.  Every matrix is a single 32 x 32 tile, so the whole step of variant 5 --
 // Z = P-^T H^T, S^T = H Z, the two factorizations, P+ = P- - W^T W + c c^T, Y^T = P+^T A^T, P- = Y A^T + G Q G^T, all as
 // three-term bf16 products -- runs inside one wave without a single barrier (a wave's LDS traffic executes in issue
-// order), no wave ever waits for another's factorization, and the CU holds six independent trajectories (24.3 KB of LDS
+// order), no wave ever waits for another's factorization, and the CU holds eight independent trajectories (16.6 KB of LDS
 // each, two per workgroup) instead of two workgroups with three of four waves idle through the serial phase.
 // Smaller models ride zero-padded in the tile exactly as in launch_kf_mfma.
 struct Bf32Const {
@@ -1439,7 +1439,10 @@ __device__ __forceinline__ void store_tile32(const SView& sv, long long b, long 
   }
 }
 
-constexpr int BF32_WAVE_LDS = 3 * 32 * 80 + (3 * 32 * 80 + 2 * 32 * 33 * 4) + 4 * 32 * 4;   // bytes per trajectory
+// bytes per trajectory: [P-/P+ terms | fp32 H P and S, which live only between the last read of P-'s terms (phase A) and the
+// factorization's first instructions, while that buffer is idle] + [Z / W^T / Y^T terms] + four 32-vectors
+constexpr int BF32_PN_BYTES = 2 * 32 * 33 * 4;   // 8 448 >= 3 * 32 * 80
+constexpr int BF32_WAVE_LDS = BF32_PN_BYTES + 3 * 32 * 80 + 4 * 32 * 4;
 
 __global__ void __launch_bounds__(128, 2)
 kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry, OutViews out, long long B, long long T, int nr, int mr) {
@@ -1454,12 +1457,12 @@ kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry,
   extern __shared__ __attribute__((aligned(16))) float lds[];
   lds_c* L = (lds_c*)reinterpret_cast<char*>(lds) + wv * BF32_WAVE_LDS;
   lds_c* Pn = L;                       // [3][32][80 B]  P- / P+, transposed terms
-  lds_c* Zn = L + 3 * TERM;            // [3][32][80 B]  Z = (H P-)^T; later W^T, then Y^T
+  lds_c* Zn = L + BF32_PN_BYTES;       // [3][32][80 B]  Z = (H P-)^T; later W^T, then Y^T
   lds_c* Wt = Zn;
   lds_c* Yn = Zn;
-  float* sHP = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + wv * BF32_WAVE_LDS + 6 * TERM);   // [32][33] H P- (fp32)
-  float* sc = sHP + 32 * PS;           // [32][33]  S
-  float* sm = sc + 32 * PS;            // [32] predicted mean
+  float* sHP = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + wv * BF32_WAVE_LDS);   // [32][33] H P- (fp32), over Pn
+  float* sc = sHP + 32 * PS;           // [32][33]  S, over Pn
+  float* sm = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + wv * BF32_WAVE_LDS + BF32_PN_BYTES + 3 * TERM);   // [32] predicted mean
   float* sm2 = sm + 32;                // [32] filtered mean
   float* sv = sm2 + 32;                // [32] innovation
   float* scv = sv + 32;                // [32] 1e-3 W^T g
@@ -1492,6 +1495,7 @@ kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry,
         const u32x4 bh[3] = {hop[0][c], hop[1][c], hop[2][c]};
         z = mfma_bf6(a, bh, z);
       }
+      wave_lds_order();   // P-'s terms have been read: their buffer now takes H P (fp32) and, below, S
       BF_UNROLL for (int r = 0; r < 16; ++r) sHP[lr * PS + c_row(r, lane)] = z[r];
       store_terms_transposed(Zn, TERM, PITCH, 0, 0, lane, z);
       const float yv = ynext;
