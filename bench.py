@@ -200,7 +200,7 @@ def make_gsf32(args, rank, world, device):
 
 
 def make_kalman64(args, rank, world, device):
-    """BASELINE configs[4]: n = 64, m = 32, T = 2 000, B = 32 768 split over the ranks (fp32 MFMA path)."""
+    """BASELINE configs[4]: n = 64, m = 32, T = 2 000, B = 32 768 split over the ranks (matrix-core path, bf16 three-term products)."""
     import torch
     import bayesianfiltering_amd as bfa
     from bayesianfiltering_amd import distributed as bdist
