@@ -94,3 +94,29 @@ def test_capacity_limits():
     assert bool(np.isfinite(out["mean"].cpu().numpy()).all())
     with pytest.raises(bfa.BayesFiltError):
         bfa.bootstrap_particle_filter(bp, y4, (1 << 20) + 1, bfa.PRNGKey(0))
+
+
+@pytest.mark.parametrize("n,m", [(4, 2), (12, 4), (20, 8), (32, 16), (48, 20), (64, 32)])
+def test_nan_observation_poisons_the_trajectory_and_only_it(n, m):
+    """A NaN observation at step t makes the innovation, the log-likelihood, the weight and the mean NaN from t on
+    (inference.py:102-104, :347-350: nothing in the reference guards it) -- in every Kalman kernel family (register,
+    run-time-dimension, one-wave matrix-core, padded and native (64, 32)): the launch terminates, the steps before t and the
+    other trajectories are untouched."""
+    import bayesianfiltering_amd as bfa
+    a = cm.random_stable_lgssm(n, m, seed=n * 7 + m, bias=True)
+    B, T, tb, bb = 3, 14, 5, 1
+    ys = cm.simulate_batch(a, B, T, seed=2)
+    init = np.tile(a["m0"], (B, 1))
+    p = cm.product_params(a)
+    clean, ll_clean = bfa.kalman_filter(p, ys, initial_means=init, return_loglik=True)
+    bad = ys.copy()
+    bad[bb, tb, 0] = np.nan
+    post, ll = bfa.kalman_filter(p, bad, initial_means=init, return_loglik=True)
+    mm, mc = post.means.cpu().numpy(), clean.means.cpu().numpy()
+    assert np.isnan(mm[bb, 0, tb:]).all() and np.isnan(ll.cpu().numpy()[bb, 0, tb:]).all()
+    assert np.isnan(post.weights.cpu().numpy()[bb, 0, tb:]).all()
+    assert np.array_equal(mm[bb, 0, :tb], mc[bb, 0, :tb])
+    for b in (0, 2):
+        assert np.array_equal(mm[b], mc[b]) and np.array_equal(ll.cpu().numpy()[b], ll_clean.cpu().numpy()[b])
+    # the covariance recursion does not depend on the data: it stays finite
+    assert np.isfinite(post.covariances.cpu().numpy()).all()
