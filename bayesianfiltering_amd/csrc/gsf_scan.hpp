@@ -48,12 +48,16 @@ struct GsfCfg {
   static constexpr int EP = NS * NS;
   static constexpr int WMIN = 4 * NL;
   static constexpr int WP = (EP >= 32 ? EP : 32) > WMIN ? (EP >= 32 ? EP : 32) : WMIN;
-  // 128-byte rows for the mean / weight streams as well (8 waves per CU leave the LDS for it): a 64-byte run is
-  // half a cache line and writes ~15 % slower (scripts/store_pattern_bench.hip)
-#ifndef BF_GSF_WSM
-#define BF_GSF_WSM 32
-#endif
+  // 128-byte rows for the mean / weight streams as well where the LDS allows: a 64-byte run is half a cache line and
+  // writes ~15 % slower (scripts/store_pattern_bench.hip).  At n = 8 it does not: with 256-byte covariance rows the
+  // five-stream tiles of a wave come to 26.1 KB, ONE 256-thread workgroup per CU (a wave per SIMD), and the stores of a
+  // step no longer overlap anybody's algebra -- cfg3 ran compute (6.1 ms per 200 steps) plus stores (6 ms) back to back.
+  // 64-byte rows there: 17.9 KB per wave, two workgroups per CU, 12.06 -> 10.4 ms (5.0 -> 5.85 TB/s).
+#ifdef BF_GSF_WSM
   static constexpr int WSM = BF_GSF_WSM;
+#else
+  static constexpr int WSM = NS * NS >= 64 ? 16 : 32;
+#endif
   static constexpr int WM = (NS >= WSM ? NS : WSM) > WMIN ? (NS >= WSM ? NS : WSM) : WMIN;
   static constexpr int WW = WSM > WMIN ? WSM : WMIN;
   using TP = Tile<EP, WP, CPW, 4>;
