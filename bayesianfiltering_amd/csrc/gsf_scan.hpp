@@ -48,15 +48,17 @@ struct GsfCfg {
   static constexpr int EP = NS * NS;
   static constexpr int WMIN = 4 * NL;
   static constexpr int WP = (EP >= 32 ? EP : 32) > WMIN ? (EP >= 32 ? EP : 32) : WMIN;
-  // 128-byte rows for the mean / weight streams as well where the LDS allows: a 64-byte run is half a cache line and
-  // writes ~15 % slower (scripts/store_pattern_bench.hip).  At n = 8 it does not: with 256-byte covariance rows the
-  // five-stream tiles of a wave come to 26.1 KB, ONE 256-thread workgroup per CU (a wave per SIMD), and the stores of a
-  // step no longer overlap anybody's algebra -- cfg3 ran compute (6.1 ms per 200 steps) plus stores (6 ms) back to back.
-  // 64-byte rows there: 17.9 KB per wave, two workgroups per CU, 12.06 -> 10.4 ms (5.0 -> 5.85 TB/s).
+  // 64-byte rows for the mean / weight streams.  128-byte rows write ~15 % faster per byte (scripts/store_pattern_bench.hip)
+  // but the five-stream tiles of a wave then come to 26 KB, ONE 256-thread workgroup per CU (a wave per SIMD), and the stores
+  // of a step overlap nobody's algebra: cfg3 (n = 8, K = 32) ran compute (6.1 ms per 200 steps) plus stores (6 ms) back to
+  // back.  With 64-byte rows (17.9 KB per wave, two workgroups per CU): cfg3 12.06 -> 10.4 ms (5.0 -> 5.85 TB/s); the
+  // manoeuvring-target model (n = 4, K = 128 / 32 / 4 / 1, scripts/gsf_k_probe.py) 4.99 / 4.46 / 3.90 / 3.66 ->
+  // 3.41 / 2.87 / 2.70 / 2.84 ms.  (The K = 1 linear Kalman kernel of the headline, whose algebra is light, keeps 128-byte
+  // rows: 18.8 against 19.7 ms, kf_scan_group.hpp.)
 #ifdef BF_GSF_WSM
   static constexpr int WSM = BF_GSF_WSM;
 #else
-  static constexpr int WSM = NS * NS >= 64 ? 16 : 32;
+  static constexpr int WSM = 16;
 #endif
   static constexpr int WM = (NS >= WSM ? NS : WSM) > WMIN ? (NS >= WSM ? NS : WSM) : WMIN;
   static constexpr int WW = WSM > WMIN ? WSM : WMIN;
