@@ -182,7 +182,7 @@ __device__ __forceinline__ float wave_tree_dpp_lane63(float v, OP op) {
 // NaN-propagating maximum (jnp.max semantics)
 __device__ __forceinline__ float nanmax(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); }
 
-template <int N, int DQ, int M, int PPT, int NW>
+template <int N, int DQ, int M, int PPT, int NW, class SP = SpecRuntime>
 __global__ void __launch_bounds__(64 * NW)
 bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const float* __restrict__ uptr, long long u_sB,
                 long long u_sT, BpfCarry carry, BpfOut out, long long B, long long T, int NP, float ess_threshold,
@@ -278,13 +278,14 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
       // the model is re-read (scalar loads through the constant cache) for every particle instead of being held: hoisted
       // out of the time loop its matrices occupy several hundred scalar registers, which spill through vector lanes and
       // from there to scratch (1024 x 4 geometry: 492 -> 82 spilled VGPRs, 52 -> 42 ms at cfg4's shape, B = 1024, T = 100)
+      // (a SpecFixed instance reads a few dozen fields only: they stay in scalar registers across particles and steps)
       int zoff = 0;
-      asm volatile("" : "+s"(zoff));
+      if constexpr (!SP::fixed) asm volatile("" : "+s"(zoff));
       const BpfModel<N, DQ, M>& mdl = mdlp[zoff];
-      draw_dynamics_noise<N, DQ, M>(mdl, ki, q);
-      dyn_value<N, DQ, M>(mdl, x[p], q, u0, xn);
+      draw_dynamics_noise<N, DQ, M, SP>(mdl, ki, q);
+      dyn_value<N, DQ, M, SP>(mdl, x[p], q, u0, xn);
       BF_UNROLL for (int d = 0; d < N; ++d) x[p][d] = xn[d];
-      const float llp = emission_loglik<N, DQ, M>(mdl, xn, u0, yv);
+      const float llp = emission_loglik<N, DQ, M, SP>(mdl, xn, u0, yv);
       ll[p] = valid[p] ? llp : -__builtin_inff();
       // one particle at a time: interleaving the PPT independent Threefry / erfinv chains overruns the
       // 128-VGPR budget of the 1024-thread geometry and spills

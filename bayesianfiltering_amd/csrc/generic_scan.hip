@@ -196,6 +196,7 @@ static int gen_nt64_max() {
 }
 
 int launch_user_kernel(const bf_user_model* um, int nt, unsigned grid, size_t lds_bytes, hipStream_t stream, void** args);
+int check_user_model(const bf_user_model* um, const bf_model* p);
 
 int launch_gsf_generic(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int K,
                        const bf_carry* carry, const bf_out_desc* out, hipStream_t stream) {
@@ -204,7 +205,9 @@ int launch_gsf_generic(const bf_model* p, const bf_cstream* y, const bf_cstream*
                                       "use bf_collapse_f32 on the emitted streams");
   GenModel g;
   std::vector<float> blk;
-  int rc = gen_fill(p, T, g, blk);
+  int rc = p->user ? check_user_model(p->user, p) : BF_OK;
+  if (rc != BF_OK) return rc;
+  rc = gen_fill(p, T, g, blk);
   if (rc != BF_OK) return rc;
   int KP = 1;
   while (KP < K) KP <<= 1;

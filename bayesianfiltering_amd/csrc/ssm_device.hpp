@@ -29,14 +29,41 @@ struct BpfModel {
   float L0[N * N];    // chol(P0), lower
 };
 
+// What the sampling code reads from a model's STRUCTURE fields (function ids, "this factor is diagonal" flags): at run time
+// from the struct (SpecRuntime: one binary serves every registry model), or as compile-time constants (SpecFixed: the
+// instance a launch selects when the host-side model matches -- same arithmetic, operation for operation, but no per-particle
+// switch, none of the other models' code or registers, and only the fields that model reads).
+struct SpecRuntime {
+  static constexpr bool fixed = false;
+};
+template <int DYN, int EMI, bool G_ID, bool LQ_DIAG, bool LR_DIAG, bool H_PICK>
+struct SpecFixed {
+  static constexpr bool fixed = true;
+  static constexpr int dyn_id = DYN, emi_id = EMI;
+  static constexpr bool g_identity = G_ID, lq_diag = LQ_DIAG, lr_diag = LR_DIAG, h_pick = H_PICK;
+};
+#define BF_SPEC_GET(NAME_, TYPE_)                                              \
+  template <class SP, class MDL>                                               \
+  __host__ __device__ __forceinline__ TYPE_ spec_##NAME_(const MDL& p) {       \
+    if constexpr (SP::fixed) return SP::NAME_;                                 \
+    else return p.NAME_;                                                       \
+  }
+BF_SPEC_GET(dyn_id, int)
+BF_SPEC_GET(emi_id, int)
+BF_SPEC_GET(g_identity, bool)
+BF_SPEC_GET(lq_diag, bool)
+BF_SPEC_GET(lr_diag, bool)
+BF_SPEC_GET(h_pick, bool)
+#undef BF_SPEC_GET
+
 // value of f(x, q, u) for the registry dynamics (additive noise through F_q); MDL is any model struct
 // with the fields dyn_id, dth, A, Gm, g_identity
-template <int N, int DQ, class MDL>
+template <int N, int DQ, class MDL, class SP = SpecRuntime>
 __device__ __forceinline__ void dyn_value_t(const MDL& p, const float* x, const float* q, float u0, float* out) {
   // canonical arithmetic (bf_canon_math.hpp): every operation rounded on its own, in the order written -- the order
   // of the test oracle's NumPy expressions -- and fused multiply-adds only where spelled out (mv)
 #pragma clang fp contract(off)
-  switch (p.dyn_id) {
+  switch (spec_dyn_id<SP>(p)) {
     case DYN_LINEAR: mv<N, N>(p.A, x, out); break;
     case DYN_LORENZ96: {
       const float alpha = p.dth[0], beta = p.dth[1], gamma = p.dth[2], dt = p.dth[3];
@@ -81,7 +108,7 @@ __device__ __forceinline__ void dyn_value_t(const MDL& p, const float* x, const 
       break;
     default: BF_UNROLL for (int i = 0; i < N; ++i) out[i] = x[i]; break;
   }
-  if (p.g_identity) {
+  if (spec_g_identity<SP>(p)) {
     if constexpr (DQ == N) BF_UNROLL for (int i = 0; i < N; ++i) out[i] += q[i];
   } else {
     BF_UNROLL for (int i = 0; i < N; ++i) {
@@ -92,17 +119,17 @@ __device__ __forceinline__ void dyn_value_t(const MDL& p, const float* x, const 
   }
 }
 
-template <int N, int DQ, int M>
+template <int N, int DQ, int M, class SP = SpecRuntime>
 __device__ __forceinline__ void dyn_value(const BpfModel<N, DQ, M>& p, const float* x, const float* q, float u0, float* out) {
-  dyn_value_t<N, DQ>(p, x, q, u0, out);
+  dyn_value_t<N, DQ, BpfModel<N, DQ, M>, SP>(p, x, q, u0, out);
 }
 
 // noise-free part g(x, u) of the registry emissions h(x, r, u) = g(x, u) + H_r r (constant H_r); MDL is any
 // model struct with the fields emi_id, eth, Hm
-template <int N, int M, class MDL>
+template <int N, int M, class MDL, class SP = SpecRuntime>
 __device__ __forceinline__ void emi_mean_t(const MDL& p, const float* x, float u0, float* hx) {
 #pragma clang fp contract(off)
-  switch (p.emi_id) {
+  switch (spec_emi_id<SP>(p)) {
     case EMI_LINEAR: mv<M, N>(p.Hm, x, hx); break;
     case EMI_BEARING_RANGE:
       if constexpr (N == 4 && M == 2) {
@@ -137,37 +164,38 @@ __device__ __forceinline__ float sv_scale(const MDL& p, float xa, float u0) {
 
 // mean of the emission density: h(x, r_eval, u) for the registry emissions with constant H_r (hb = H_r r_eval), and
 // for the stochastic-volatility emission (hb = r_eval)
-template <int N, int DQ, int M>
+template <int N, int DQ, int M, class SP = SpecRuntime>
 __device__ __forceinline__ void emi_value(const BpfModel<N, DQ, M>& p, const float* x, float u0, float* hx) {
 #pragma clang fp contract(off)
   if constexpr (N == M) {
-    if (p.emi_id == EMI_STOCH_VOL) {
+    if (spec_emi_id<SP>(p) == EMI_STOCH_VOL) {
       BF_UNROLL for (int a = 0; a < M; ++a)
         hx[a] = u0 * p.eth[1] * canon_exp(x[a] / p.eth[0]) * p.hb[a] + (1.f - u0) * (p.eth[2] * x[a] + p.hb[a]);
       return;
     }
   }
-  emi_mean_t<N, M>(p, x, u0, hx);
+  emi_mean_t<N, M, BpfModel<N, DQ, M>, SP>(p, x, u0, hx);
   BF_UNROLL for (int a = 0; a < M; ++a) hx[a] += p.hb[a];
 }
 
 // q = q0 + chol(Q) normal(key_i, (dq,)) (gaussfiltax/models.py:82-83): accumulated column by column as the normals
 // arrive (per entry the same fma chain as the row-wise product, c ascending from 0), so no z vector stays live.
 // normal(key, (dq,)): Threefry block j yields entries j and h + j.
-template <int N, int DQ, int M>
+template <int N, int DQ, int M, class SP = SpecRuntime>
 __device__ __forceinline__ void draw_dynamics_noise(const BpfModel<N, DQ, M>& mdl, U32x2 ki, float* q) {
   constexpr int h = (DQ + 1) / 2;
+  const bool lq_diag = spec_lq_diag<SP>(mdl);
   float zhi[h];
   BF_UNROLL for (int d = 0; d < DQ; ++d) q[d] = 0.f;
   BF_UNROLL for (int j = 0; j < h; ++j) {
     const U32x2 o = threefry2x32(ki.x, ki.y, (uint32_t)j, (h + j < DQ) ? (uint32_t)(h + j) : 0u);
     const float zj = bits_to_normal(o.x);
     zhi[j] = (h + j < DQ) ? bits_to_normal(o.y) : 0.f;
-    if (mdl.lq_diag) q[j] = mdl.LQ[j * DQ + j] * zj;
+    if (lq_diag) q[j] = mdl.LQ[j * DQ + j] * zj;
     else BF_UNROLL for (int d = j; d < DQ; ++d) q[d] = __builtin_fmaf(mdl.LQ[d * DQ + j], zj, q[d]);
   }
   BF_UNROLL for (int j = 0; h + j < DQ; ++j) {
-    if (mdl.lq_diag) q[h + j] = mdl.LQ[(h + j) * DQ + h + j] * zhi[j];
+    if (lq_diag) q[h + j] = mdl.LQ[(h + j) * DQ + h + j] * zhi[j];
     else BF_UNROLL for (int d = h + j; d < DQ; ++d) q[d] = __builtin_fmaf(mdl.LQ[d * DQ + h + j], zhi[j], q[d]);
   }
   BF_UNROLL for (int d = 0; d < DQ; ++d) q[d] = mdl.q0[d] + q[d];
@@ -177,26 +205,26 @@ __device__ __forceinline__ void draw_dynamics_noise(const BpfModel<N, DQ, M>& md
 // through the Cholesky factor: forward substitution by fma, multiplication by the reciprocal diagonal, the quadratic
 // form by fma, -0.5 quad + const as ONE fma.  The oracle restates exactly this sequence (gaussfilt_oracle.py,
 // arith = "canonical").
-template <int N, int DQ, int M>
+template <int N, int DQ, int M, class SP = SpecRuntime>
 __device__ __forceinline__ float emission_loglik(const BpfModel<N, DQ, M>& mdl, const float* xn, float u0, const float* yv) {
 #pragma clang fp contract(off)
   float hx[M], zz[M];
-  if (mdl.h_pick) {  // selection emission (e.g. the even states of Lorenz-96): the exact-zero terms of H x are skipped
+  if (spec_h_pick<SP>(mdl)) {  // selection emission (e.g. the even states of Lorenz-96): the exact-zero terms of H x are skipped
     BF_UNROLL for (int a = 0; a < M; ++a) hx[a] = xn[(2 * a) % N] + mdl.hb[a];
   } else {
-    emi_value<N, DQ, M>(mdl, xn, u0, hx);
+    emi_value<N, DQ, M, SP>(mdl, xn, u0, hx);
   }
   float quad = 0.f, lsc = 0.f;
   BF_UNROLL for (int a = 0; a < M; ++a) {
     float s = yv[a] - hx[a];
     if constexpr (N == M) {
-      if (mdl.emi_id == EMI_STOCH_VOL) {  // state-dependent covariance M R M^T: chol(M R M^T) = M chol(R)
+      if (spec_emi_id<SP>(mdl) == EMI_STOCH_VOL) {  // state-dependent covariance M R M^T: chol(M R M^T) = M chol(R)
         const float d = sv_scale(mdl, xn[a], u0);
         s = s / d;
         lsc = lsc + canon_log(d);
       }
     }
-    if (!mdl.lr_diag) BF_UNROLL for (int c = 0; c < a; ++c) s = __builtin_fmaf(-mdl.LR[a * M + c], zz[c], s);
+    if (!spec_lr_diag<SP>(mdl)) BF_UNROLL for (int c = 0; c < a; ++c) s = __builtin_fmaf(-mdl.LR[a * M + c], zz[c], s);
     zz[a] = s * mdl.rdLR[a];
     quad = __builtin_fmaf(zz[a], zz[a], quad);
   }

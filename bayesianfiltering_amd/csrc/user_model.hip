@@ -11,6 +11,9 @@
 // next to the HIP runtime the process already uses, so the library itself carries no link-time dependency on it.
 #include <dlfcn.h>
 #include <sys/stat.h>
+#include <unistd.h>
+#include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -19,10 +22,15 @@
 #include <vector>
 #include "bf_common.hpp"
 
+#ifndef BF_ARCH_NAME
+#define BF_ARCH_NAME "gfx950"
+#endif
+
 struct bf_user_model {
   hipModule_t mod = nullptr;
   hipFunction_t k64 = nullptr, k256 = nullptr;
   int n = 0, dq = 0, m = 0, dr = 0;
+  int device = -1;
   bool has_dyn = false, has_emi = false;
 };
 
@@ -44,6 +52,7 @@ struct Rtc {
   int (*GetCode)(hiprtcProgram, char*) = nullptr;
   int (*DestroyProgram)(hiprtcProgram*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*Version)(int*, int*) = nullptr;
 };
 Rtc g_rtc;
 std::mutex g_mu;
@@ -52,24 +61,30 @@ std::map<std::string, bf_user_model*> g_models;  // by source hash: a model comp
 bool load_rtc(std::string& why) {
   if (g_rtc.h) return true;
   std::vector<std::string> cand;
-  Dl_info info;
-  if (dladdr(reinterpret_cast<void*>(&hipModuleLoadData), &info) && info.dli_fname) {  // next to the runtime in use
-    std::string p(info.dli_fname);
-    const size_t slash = p.rfind('/');
-    if (slash != std::string::npos) cand.push_back(p.substr(0, slash + 1) + "libhiprtc.so");
+  const char* forced = std::getenv("BAYESFILT_HIPRTC_LIB");   // when set: this library and no other
+  if (forced && *forced) {
+    cand.push_back(forced);
+  } else {
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(&hipModuleLoadData), &info) && info.dli_fname) {  // next to the runtime in use
+      std::string p(info.dli_fname);
+      const size_t slash = p.rfind('/');
+      if (slash != std::string::npos) cand.push_back(p.substr(0, slash + 1) + "libhiprtc.so");
+    }
+    cand.push_back("libhiprtc.so");
+    cand.push_back("libhiprtc.so.7");
+    cand.push_back("/opt/rocm/lib/libhiprtc.so");
   }
-  cand.push_back("libhiprtc.so");
-  cand.push_back("libhiprtc.so.7");
-  cand.push_back("/opt/rocm/lib/libhiprtc.so");
   for (const std::string& c : cand) {
     void* h = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!h) {
-      why += c + ": " + (dlerror() ? dlerror() : "?") + "; ";
+      const char* de = dlerror();  // ONE call: dlerror() clears the message it returns
+      why += c + ": " + (de ? de : "?") + "; ";
       continue;
     }
 #define BF_RTC_SYM(F_) *reinterpret_cast<void**>(&g_rtc.F_) = dlsym(h, "hiprtc" #F_)
     BF_RTC_SYM(CreateProgram); BF_RTC_SYM(CompileProgram); BF_RTC_SYM(GetProgramLogSize); BF_RTC_SYM(GetProgramLog);
-    BF_RTC_SYM(GetCodeSize); BF_RTC_SYM(GetCode); BF_RTC_SYM(DestroyProgram); BF_RTC_SYM(GetErrorString);
+    BF_RTC_SYM(GetCodeSize); BF_RTC_SYM(GetCode); BF_RTC_SYM(DestroyProgram); BF_RTC_SYM(GetErrorString); BF_RTC_SYM(Version);
 #undef BF_RTC_SYM
     if (g_rtc.CreateProgram && g_rtc.CompileProgram && g_rtc.GetCodeSize && g_rtc.GetCode && g_rtc.DestroyProgram) {
       g_rtc.h = h;
@@ -191,15 +206,107 @@ std::string cache_dir() {  // $BAYESFILT_CACHE_DIR, else .jit_cache next to this
 
 }  // namespace
 
+int check_user_model(const bf_user_model* um, const bf_model* p) {
+  // the JIT kernel indexes LDS and registers with the COMPILE-TIME dimensions of bf_user_model_create while the launch
+  // carves LDS from the run-time bf_model: they must be the same model
+  if (um->n != p->n || um->dq != p->dq || um->m != p->m || um->dr != p->dr)
+    return set_error(BF_EINVAL, "bf_model.user was compiled for (n, dq, m, dr) = (%d, %d, %d, %d) but the model says (%d, %d, %d, %d)",
+                     um->n, um->dq, um->m, um->dr, p->n, p->dq, p->m, p->dr);
+  if (p->dyn_id == BF_FN_USER && !um->has_dyn)
+    return set_error(BF_EINVAL, "dyn_id = BF_FN_USER but bf_model.user was created without dynamics source");
+  if (p->emi_id == BF_FN_USER && !um->has_emi)
+    return set_error(BF_EINVAL, "emi_id = BF_FN_USER but bf_model.user was created without emission source");
+  if (p->dyn_id != BF_FN_USER && um->has_dyn)
+    return set_error(BF_EINVAL, "bf_model.user holds dynamics source: dyn_id must be BF_FN_USER");
+  if (p->emi_id != BF_FN_USER && um->has_emi)
+    return set_error(BF_EINVAL, "bf_model.user holds emission source: emi_id must be BF_FN_USER");
+  return BF_OK;
+}
+
 int launch_user_kernel(const bf_user_model* um, int nt, unsigned grid, size_t lds_bytes, hipStream_t stream, void** args) {
+  int dev = -1;
+  (void)hipGetDevice(&dev);
+  if (dev != um->device)
+    return set_error(BF_EINVAL, "bf_model.user was loaded on device %d, the current device is %d (create one handle per device)", um->device, dev);
   hipFunction_t f = nt == 64 ? um->k64 : um->k256;
-  if (lds_bytes > 64 * 1024) {
-    // module functions take the same attribute as host-side kernels; a runtime that refuses it reports the launch error below
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  }
+  // (a module function needs no opt-in for more than 64 KiB of dynamic LDS on gfx950: the launch itself checks the 160 KiB limit)
   BF_HIP_CHECK(hipModuleLaunchKernel(f, grid, 1, 1, (unsigned)nt, 1, 1, (unsigned)lds_bytes, stream, args, nullptr));
   return BF_OK;
 }
+
+namespace {
+
+bool read_file(const std::string& path, std::vector<char>& code) {
+  code.clear();
+  if (FILE* f = std::fopen(path.c_str(), "rb")) {
+    std::fseek(f, 0, SEEK_END);
+    const long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    if (sz > 0) {
+      code.resize((size_t)sz);
+      if (std::fread(code.data(), 1, (size_t)sz, f) != (size_t)sz) code.clear();
+    }
+    std::fclose(f);
+  }
+  return !code.empty();
+}
+
+// every rank of a torchrun job misses at the same moment: each writes its OWN temporary (pid + counter) and renames it over
+// the final name -- rename is atomic, a reader sees either nothing or a whole file
+void write_file_atomically(const std::string& path, const std::vector<char>& code) {
+  static std::atomic<unsigned> counter{0};
+  const std::string tmp = path + "." + std::to_string((long long)getpid()) + "." + std::to_string(counter.fetch_add(1)) + ".tmp";
+  if (FILE* f = std::fopen(tmp.c_str(), "wb")) {  // best effort
+    const bool ok = std::fwrite(code.data(), 1, code.size(), f) == code.size();
+    const bool closed = std::fclose(f) == 0;
+    if (ok && closed && std::rename(tmp.c_str(), path.c_str()) == 0) return;
+    std::remove(tmp.c_str());
+  }
+}
+
+int compile_with_hiprtc(const std::string& src, std::vector<char>& code) {
+  std::string why;
+  if (!load_rtc(why)) return set_error(BF_EUNSUPPORTED, "hiprtc is not available: %.400s", why.c_str());
+  hiprtcProgram prog = nullptr;
+  int rc = g_rtc.CreateProgram(&prog, src.c_str(), "bf_user_model.hip", 0, nullptr, nullptr);
+  if (rc != 0) return set_error(BF_EHIP, "hiprtcCreateProgram failed (%d)", rc);
+  const char* opts[] = {"--offload-arch=" BF_ARCH_NAME, "-O3", "-std=c++17", "-ffp-contract=off"};
+  rc = g_rtc.CompileProgram(prog, 4, opts);
+  if (rc != 0) {
+    size_t ls = 0;
+    std::string log;
+    if (g_rtc.GetProgramLogSize && g_rtc.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
+      log.resize(ls);
+      g_rtc.GetProgramLog(prog, &log[0]);
+    }
+    g_rtc.DestroyProgram(&prog);
+    // the first error lines are what the author of the source needs
+    const size_t pos = log.find("error");
+    return set_error(BF_EINVAL, "the model source does not compile: %.440s", (pos == std::string::npos ? log : log.substr(pos)).c_str());
+  }
+  size_t cs = 0;
+  rc = g_rtc.GetCodeSize(prog, &cs);
+  if (rc == 0 && cs > 0) {
+    code.resize(cs);
+    rc = g_rtc.GetCode(prog, code.data());
+  }
+  g_rtc.DestroyProgram(&prog);
+  if (rc != 0 || code.empty()) return set_error(BF_EHIP, "hiprtc returned no code object (%d)", rc);
+  return BF_OK;
+}
+
+hipError_t load_module(bf_user_model* um, const std::vector<char>& code) {
+  hipError_t e = hipModuleLoadData(&um->mod, code.data());
+  if (e == hipSuccess) e = hipModuleGetFunction(&um->k64, um->mod, "bf_user_scan_64");
+  if (e == hipSuccess) e = hipModuleGetFunction(&um->k256, um->mod, "bf_user_scan_256");
+  if (e != hipSuccess && um->mod) {
+    (void)hipModuleUnload(um->mod);
+    um->mod = nullptr;
+  }
+  return e;
+}
+
+}  // namespace
 
 }  // namespace bf
 
@@ -212,74 +319,59 @@ int bf_user_model_create(const char* dynamics_src, const char* emission_src, int
   if (n <= 0 || dq <= 0 || m <= 0 || dr <= 0 || n > 64 || dq > 64 || m > 64 || dr > 64)
     return set_error(BF_EINVAL, "bf_user_model_create: dimensions must be in 1..64");
   const std::string src = build_source(dynamics_src, emission_src, n, dq, m, dr);
+  // the code object depends on the source, the target and the compiler: all three are in the key (the HIP runtime's version
+  // stands for hiprtc's, which ships with it -- known without loading hiprtc on a cache hit)
+  int rtver = 0;
+  (void)hipRuntimeGetVersion(&rtver);
   char key[32];
-  std::snprintf(key, sizeof(key), "%016llx", (unsigned long long)fnv1a(src));
+  std::snprintf(key, sizeof(key), "%016llx", (unsigned long long)fnv1a(src + "|" BF_ARCH_NAME "|" + std::to_string(rtver)));
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    dev = -1;
+    (void)hipGetLastError();
+  }
+  const std::string mem_key = std::string(key) + "@" + std::to_string(dev);   // a module is loaded on ONE device
   std::lock_guard<std::mutex> lock(g_mu);
-  auto it = g_models.find(key);
+  auto it = g_models.find(mem_key);
   if (it != g_models.end()) {
     *model = it->second;
     return BF_OK;
   }
-  // ---- code object: disk cache, else hiprtc
-  std::vector<char> code;
-  const std::string path = cache_dir() + "/user_" + key + "_gfx950.co";
-  if (FILE* f = std::fopen(path.c_str(), "rb")) {
-    std::fseek(f, 0, SEEK_END);
-    const long sz = std::ftell(f);
-    std::fseek(f, 0, SEEK_SET);
-    if (sz > 0) {
-      code.resize((size_t)sz);
-      if (std::fread(code.data(), 1, (size_t)sz, f) != (size_t)sz) code.clear();
-    }
-    std::fclose(f);
-  }
-  if (code.empty()) {
-    std::string why;
-    if (!load_rtc(why)) return set_error(BF_EUNSUPPORTED, "hiprtc is not available: %.400s", why.c_str());
-    hiprtcProgram prog = nullptr;
-    int rc = g_rtc.CreateProgram(&prog, src.c_str(), "bf_user_model.hip", 0, nullptr, nullptr);
-    if (rc != 0) return set_error(BF_EHIP, "hiprtcCreateProgram failed (%d)", rc);
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
-    rc = g_rtc.CompileProgram(prog, 4, opts);
-    if (rc != 0) {
-      size_t ls = 0;
-      std::string log;
-      if (g_rtc.GetProgramLogSize && g_rtc.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
-        log.resize(ls);
-        g_rtc.GetProgramLog(prog, &log[0]);
-      }
-      g_rtc.DestroyProgram(&prog);
-      // the first error lines are what the author of the source needs
-      const size_t pos = log.find("error");
-      return set_error(BF_EINVAL, "the model source does not compile: %.440s", (pos == std::string::npos ? log : log.substr(pos)).c_str());
-    }
-    size_t cs = 0;
-    rc = g_rtc.GetCodeSize(prog, &cs);
-    if (rc == 0 && cs > 0) {
-      code.resize(cs);
-      rc = g_rtc.GetCode(prog, code.data());
-    }
-    g_rtc.DestroyProgram(&prog);
-    if (rc != 0 || code.empty()) return set_error(BF_EHIP, "hiprtc returned no code object (%d)", rc);
-    if (FILE* f = std::fopen((path + ".tmp").c_str(), "wb")) {  // best effort
-      const bool ok = std::fwrite(code.data(), 1, code.size(), f) == code.size();
-      std::fclose(f);
-      if (ok) std::rename((path + ".tmp").c_str(), path.c_str());
-    }
-  }
   bf_user_model* um = new bf_user_model;
-  um->n = n; um->dq = dq; um->m = m; um->dr = dr;
+  um->n = n; um->dq = dq; um->m = m; um->dr = dr; um->device = dev;
   um->has_dyn = dynamics_src != nullptr;
   um->has_emi = emission_src != nullptr;
-  hipError_t e = hipModuleLoadData(&um->mod, code.data());
-  if (e == hipSuccess) e = hipModuleGetFunction(&um->k64, um->mod, "bf_user_scan_64");
-  if (e == hipSuccess) e = hipModuleGetFunction(&um->k256, um->mod, "bf_user_scan_256");
-  if (e != hipSuccess) {
-    if (um->mod) (void)hipModuleUnload(um->mod);
-    delete um;
-    return set_error(BF_EHIP, "loading the compiled model failed: %s", hipGetErrorString(e));
+  // ---- code object: disk cache (a file that does not load -- truncated, stale, foreign -- is deleted and rebuilt), else hiprtc
+  std::vector<char> code;
+  const std::string path = cache_dir() + "/user_" + key + "_" BF_ARCH_NAME ".co";
+  hipError_t e = hipErrorUnknown;
+  if (read_file(path, code)) {
+    e = load_module(um, code);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || dev < 0) {
+        delete um;
+        return set_error(BF_ENOGPU, "loading the compiled model failed: %s", hipGetErrorString(e));
+      }
+      std::remove(path.c_str());
+      code.clear();
+    }
   }
-  g_models[key] = um;
+  if (code.empty()) {
+    const int rc = compile_with_hiprtc(src, code);
+    if (rc != BF_OK) {
+      delete um;
+      return rc;
+    }
+    write_file_atomically(path, code);
+    e = load_module(um, code);
+  }
+  if (e != hipSuccess) {
+    delete um;
+    (void)hipGetLastError();
+    return set_error(e == hipErrorNoDevice ? BF_ENOGPU : BF_EHIP, "loading the compiled model failed: %s", hipGetErrorString(e));
+  }
+  g_models[mem_key] = um;
   *model = um;
   return BF_OK;
 }

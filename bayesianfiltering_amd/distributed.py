@@ -18,13 +18,14 @@ def shard_bounds(batch: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def all_gather_summaries(local, batch: int):
+def all_gather_summaries(local, batch: int, force: bool = False):
     """All-gather per-trajectory summaries.  ``local``: (b_local, ...) tensor holding this rank's
     block of a (batch, ...) array sharded by :func:`shard_bounds`.  Returns the full (batch, ...)
-    tensor on every rank.  Ragged shards are padded to the largest block for the collective."""
+    tensor on every rank.  Ragged shards are padded to the largest block for the collective.
+    ``force``: issue the collective even in a one-rank group (the same RCCL call on one GPU)."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     bmax = (batch + world - 1) // world

@@ -316,6 +316,9 @@ def main():
     ap.add_argument("--mode", default="full5", choices=["full5", "collapsed"],
                     help="gsf32 only: full5 = the five posterior streams (T-chunked), collapsed = in-scan moment matching")
     ap.add_argument("--l96-mode", default="matrix_power", choices=["matrix_power", "as_written"], help="gsf32 only (see make_gsf32)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the N > 1 code path -- init_process_group('nccl'), the RCCL all-gather of the summaries inside the timed "
+                         "region, barriers, max-over-ranks -- even with ONE rank (also the default under torchrun --nproc-per-node 1)")
     ap.add_argument("--config", default="kalman4", choices=sorted(MAKERS),
                     help="kalman4 = BASELINE configs[1] (headline, default); gsf32 / bpf4096 / kalman64 = configs[2..4]")
     args = ap.parse_args()
@@ -326,13 +329,18 @@ def main():
     if args.gpus != world and args.gpus > 1:
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
 
+    # the collective path: always for N > 1; for ONE rank when launched by torchrun (RANK / WORLD_SIZE in the environment) or
+    # with --force-collective, so that the exact N > 1 code executes on a single MI355X as well
+    group = world > 1 or args.force_collective or ("RANK" in os.environ and "WORLD_SIZE" in os.environ)
     import torch
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:                      # the process group first: nothing else has touched the GPU yet
+    if group:                          # the process group first: nothing else has touched the GPU yet
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from bayesianfiltering_amd import distributed as bdist
     w = MAKERS[args.config](args, rank, world, device)
@@ -343,13 +351,13 @@ def main():
         # one pass of the hot path over this rank's trajectories + the path's one exchange step:
         # RCCL all-gather of the per-trajectory posterior summaries
         w["kernels"]()
-        if world > 1:
-            gathered["t"] = bdist.all_gather_summaries(w["summary"](), w["gather_rows"])
+        if group:
+            gathered["t"] = bdist.all_gather_summaries(w["summary"](), w["gather_rows"], force=True)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if group:
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -358,20 +366,21 @@ def main():
         ev[i][0].record()               # the engine launches on torch's current stream: these events bracket its kernels
         w["kernels"]()
         ev[i][1].record()
-        if world > 1:
-            gathered["t"] = bdist.all_gather_summaries(w["summary"](), w["gather_rows"])
+        if group:
+            gathered["t"] = bdist.all_gather_summaries(w["summary"](), w["gather_rows"], force=True)
     torch.cuda.synchronize()
-    if world > 1:
+    if group:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if group:
+        assert tuple(gathered["t"].shape)[0] == w["gather_rows"], (tuple(gathered["t"].shape), w["gather_rows"])
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
     fin = torch.tensor([w["finite"]() * w["units"]], device=device, dtype=torch.float64)
-    if world > 1:
+    if group:
         dist.all_reduce(fin)
     finite_frac = float(fin.item()) / w["total_units"]
 
@@ -394,14 +403,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": w["scaling"], "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": w["workload"], **w["extra"],
-                       "parallelism": f"batch-sharded x{world}" + (" + RCCL all-gather of summaries" if world > 1 else "")},
+                       "parallelism": f"batch-sharded x{world}" + (" + RCCL all-gather of summaries" if group else "")},
             "finite_frac": finite_frac,
             "roofline": roof,
         }
         if args.config == "kalman4" and world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w["a"], w["T"])
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if group:
         dist.destroy_process_group()
 
 

@@ -22,8 +22,7 @@ def test_kalman_n4_T10000_B65536():
     a = cm.cv_model_arrays()
     p = cm.product_params(a)
     B, T = 65536, 10000
-    g = torch.Generator(device="cuda").manual_seed(1)
-    y = torch.randn((B, T, 2), device="cuda", generator=g)
+    y = cm.device_observations(p, (4, 2, 2, 2), B, T, seed=1)            # drawn from the model, as bench.py does
     init = torch.zeros((B, 4), device="cuda")
     _, ll, carry = bfa.kalman_filter(p, y, initial_means=init, fields=(), return_loglik=True, return_carry=True)
     # chunked == one-shot, bit for bit
@@ -55,7 +54,7 @@ def test_kalman_n4_T10000_B65536():
     # asymmetric fixed point
     got_ll, ref_ll = ll[idx].cpu().numpy().reshape(3, T), np.asarray(ref["loglik"]).reshape(3, T)
     assert cm.rel_err(got_ll[:, :300], ref_ll[:, :300]) < 1e-4
-    assert cm.rel_err(got_ll[:, -2000:], ref_ll[:, -2000:]) < 1e-3
+    assert cm.rel_err(got_ll[:, -2000:], ref_ll[:, -2000:]) < 2e-2   # (measured 3.2e-3 on model-drawn data; the bound of the cfg2 test below)
     assert cm.rel_err(carry.covariances[idx].cpu().numpy().reshape(3, 4, 4),
                       np.stack([r[0, -1] for r in ref["predicted_covariances"]])) < 1e-4
     assert cm.rel_err(carry.means[idx].cpu().numpy().reshape(3, 4),
@@ -69,10 +68,10 @@ def test_gsf_k32_lorenz96_T5000_B16384():
     nl = bfa.nonlinearities
     B, T, K, n, m = 16384, 5000, 32, 8, 4
     Q, R = 1e-2 * np.eye(8, dtype=F32), 1e-1 * np.eye(4, dtype=F32)
-    p = bfa.ParamsNLSSM(np.zeros(8, F32), np.eye(8, dtype=F32), nl.lorenz96(8), np.zeros(8, F32), Q, nl.pick_even(8),
+    p = bfa.ParamsNLSSM(8 * np.ones(8, F32), np.eye(8, dtype=F32), nl.lorenz96(8), np.zeros(8, F32), Q, nl.pick_even(8),
                         np.zeros(4, F32), R)
     g = torch.Generator(device="cuda").manual_seed(2)
-    y = 8.0 + torch.randn((B, T, m), device="cuda", generator=g)
+    y = cm.device_observations(p, (8, 8, 4, 4), B, T, seed=2)           # drawn from the model, as bench.py does
     init = 8.0 + torch.randn((B, K, n), device="cuda", generator=g)
     _, carry = bfa.gaussian_sum_filter(p, y, K, 1, initial_means=init, fields=(), return_carry=True)
     c = None
@@ -81,16 +80,16 @@ def test_gsf_k32_lorenz96_T5000_B16384():
     for a_, b_ in zip(c, carry):                                          # chunked == one-shot, bit for bit; NaN == NaN:
         assert bool(((a_ == b_) | (torch.isnan(a_) & torch.isnan(b_))).all())   # over 5 000 steps of this workload the
     # reference's linear-domain weights (inference.py:347-350) end in 0/0 -- the benchmark measures the arithmetic all the same
-    # causality + oracle: the first 20 steps of two trajectories of the big run, followed by the oracle (the benchmark's
-    # observations are not drawn from the model: the EKF bank on chaotic Lorenz-96 amplifies rounding quickly)
+    # causality + oracle: the first 40 steps of two trajectories of the big run, followed by the oracle
     idx = [3, B - 2]
-    short = bfa.gaussian_sum_filter(p, y[idx, :20], K, 1, initial_means=init[idx])
-    po = go.ParamsNLSSM(np.zeros(8, F32), np.eye(8, dtype=F32), om.Lorenz96(8), np.zeros(8, F32), Q, om.PickEven(8),
+    short = bfa.gaussian_sum_filter(p, y[idx, :40], K, 1, initial_means=init[idx])
+    po = go.ParamsNLSSM(8 * np.ones(8, F32), np.eye(8, dtype=F32), om.Lorenz96(8), np.zeros(8, F32), Q, om.PickEven(8),
                         np.zeros(4, F32), R)
     for j, b in enumerate(idx):
-        ref = go.gaussian_sum_filter(po, y[b, :20].cpu().numpy(), K, initial_means=init[b].cpu().numpy())
-        assert cm.rel_err(short.means[j].cpu().numpy(), ref.means) < 1e-4
-        assert np.max(np.abs(short.weights[j].cpu().numpy() - ref.weights)) < 5e-5
+        ref = go.gaussian_sum_filter(po, y[b, :40].cpu().numpy(), K, initial_means=init[b].cpu().numpy())
+        assert cm.rel_err(short.means[j].cpu().numpy(), ref.means) < 1e-5
+        assert cm.rel_err(short.covariances[j].cpu().numpy(), ref.covariances) < 1e-5
+        assert np.max(np.abs(short.weights[j].cpu().numpy() - ref.weights)) < 2e-5
         ws = short.weights[j].cpu().numpy()
         assert np.isfinite(ws).all() and np.max(np.abs(ws.sum(axis=0) - 1)) < 1e-5 and (ws >= 0).all()
 
@@ -104,9 +103,10 @@ def test_bpf_n4096_lorenz96_T2000_B1024():
     gfn = nl.pick_even(16)
     R = 0.5 * np.eye(8, dtype=F32)
     p = bfa.ParamsBPF(8 * np.ones(16, F32), np.eye(16, dtype=F32), nl.lorenz96(16), np.zeros(16, F32),
-                      1e-1 * np.eye(16, dtype=F32), gfn, np.zeros(8, F32), R, nl.gaussian_log_prob(gfn, R))
-    g = torch.Generator(device="cuda").manual_seed(3)
-    y = 8.0 + torch.randn((B, T, 8), device="cuda", generator=g)
+                      1e-2 * np.eye(16, dtype=F32), gfn, np.zeros(8, F32), R, nl.gaussian_log_prob(gfn, R))   # bench.py's model
+    y = cm.device_observations(bfa.ParamsNLSSM(*p[:8]), (16, 16, 8, 8), B, T, seed=3)   # drawn from the model, as bench.py does
+    ok = torch.isfinite(y).all(dim=(1, 2))       # the noise-driven explicit-Euler Lorenz-96 itself overflows on ~10 % of 2 000-step paths
+    assert float(ok.float().mean()) > 0.7
     key = np.array([0, 1], np.uint32)
     one, carry = bfa.bootstrap_particle_filter(p, y, N, key, output="summary", return_carry=True)
     parts, c = [], None
@@ -115,8 +115,10 @@ def test_bpf_n4096_lorenz96_T2000_B1024():
                                              return_carry=True)
         parts.append(o)
     for k in ("mean", "ess", "logz", "resampled"):
-        assert torch.equal(torch.cat([o[k] for o in parts], dim=1), one[k]), k   # chunked == one-shot, bit for bit
-    assert torch.equal(c.particles, carry.particles) and torch.equal(c.weights, carry.weights)
+        assert _same_bits(torch.cat([o[k] for o in parts], dim=1), one[k]), k   # chunked == one-shot, bit for bit (NaN included)
+    assert _same_bits(c.particles, carry.particles) and _same_bits(c.weights, carry.weights)
+    one = {k: v[ok] for k, v in one.items()}     # the filter is finite wherever its observations are
+    carry = type(carry)(carry.weights[ok], carry.particles[ok], carry.key)
     ess, res = one["ess"], one["resampled"]
     assert bool(torch.isfinite(one["mean"]).all()) and bool(torch.isfinite(one["logz"]).all())
     assert float(ess.min()) >= 1.0 - 1e-3 and float(ess.max()) <= N * (1 + 1e-5)
@@ -133,8 +135,9 @@ def test_kalman_n64_T2000_B4096():
     a["R"] = (1e-1 * np.eye(32)).astype(F32)
     p = cm.product_params(a)
     B, T = 4096, 2000
-    g = torch.Generator(device="cuda").manual_seed(4)
-    y = torch.randn((B, T, 32), device="cuda", generator=g)
+    a["m0"] = np.zeros(64, F32)
+    p = cm.product_params(a)
+    y = cm.device_observations(p, (64, 64, 32, 32), B, T, seed=4)       # drawn from the model, as bench.py does
     init = torch.zeros((B, 64), device="cuda")
     _, ll, carry = bfa.kalman_filter(p, y, initial_means=init, fields=(), return_loglik=True, return_carry=True)
     c = None
@@ -149,7 +152,7 @@ def test_kalman_n64_T2000_B4096():
     short = bfa.kalman_filter(p, y[idx, :40], initial_means=init[idx])
     ref = cm.oracle_kalman_batch(a, y[idx, :40].cpu().numpy(), np.zeros((2, 64), F32))
     for k in ("means", "covariances", "predicted_covariances"):
-        assert cm.rel_err(getattr(short, k).cpu().numpy(), ref[k]) < 1e-4, k   # observations not drawn from the model: large innovations
+        assert cm.rel_err(getattr(short, k).cpu().numpy(), ref[k]) < 1e-5, k
     assert bool(torch.isfinite(ll).all())
 
 
@@ -158,6 +161,12 @@ def test_kalman_n64_T2000_B4096():
 
 def _sym(P):
     return 0.5 * (P + np.swapaxes(P, -1, -2))
+
+
+def _same_bits(a, b):
+    """Bit-for-bit equality of two fp32 device tensors of the same shape (any strides), NaN payloads included."""
+    import torch
+    return a.shape == b.shape and torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
 def test_cfg2_full5_reference_layout_at_benchmark_size():
@@ -327,8 +336,173 @@ def test_cfg5_two_trajectories_T2000_against_oracle():
     init = np.zeros((2, 64), F32)
     post, ll = bfa.kalman_filter(p, y, initial_means=init, return_loglik=True)
     ref = c_oracle.kalman_filter(a, y.cpu().numpy(), init)
+    seen = {}
     for k in bfa.FULL5:
         g, r = getattr(post, k).cpu().numpy(), ref[k]
-        assert cm.rel_err(g[:, :, :300], r[:, :, :300]) < 1e-5, (k, cm.rel_err(g[:, :, :300], r[:, :, :300]))
-        assert cm.rel_err(g, r) < 1e-4, (k, cm.rel_err(g, r))
-    assert cm.rel_err(ll.cpu().numpy(), ref["loglik"]) < 1e-4
+        seen[k] = cm.both_err(g, r, k)                                 # all 2 000 steps, free-running: norm-wise 1e-5 ...
+        assert seen[k][0] < 1e-5, (k, seen)
+        seen[k + " t<300"] = cm.both_err(g[:, :, :300], r[:, :, :300], k)
+        assert max(seen[k + " t<300"]) < 1e-5, (k, seen)               # ... element-wise too while few steps have compounded
+        assert seen[k][1] < 1e-4, (k, seen)                            # (element-wise over 2 000 free-running steps: measured 4.5e-5)
+    seen["loglik"] = cm.both_err(ll.cpu().numpy(), ref["loglik"])
+    assert max(seen["loglik"]) < 1e-5, seen
+    # teacher-forced: every one of the 2 000 steps from the engine's own prior, element-wise at 1e-5
+    g = {k: getattr(post, k).cpu().numpy() for k in bfa.FULL5}
+    ys = y.cpu().numpy()
+    for j in range(2):
+        w = cm.one_step_parity(a, ys[j], g["predicted_means"][j, 0], g["predicted_covariances"][j, 0], g["means"][j, 0],
+                               g["covariances"][j, 0], ll.cpu().numpy()[j, 0], range(1, T), elementwise=True)
+        seen[f"one-step, trajectory {j}"] = w
+        for k, val in w.items():
+            assert val < (5e-5 if k == "loglik" else 1e-5), (k, w)
+    cm.record("cfg5_two_trajectories_T2000", **{k: (list(v) if isinstance(v, tuple) else v) for k, v in seen.items()})
+
+
+def _finite_prefix(ref, T):
+    """First step at which any stream of an oracle posterior (K, T, ...) is non-finite (T if none)."""
+    bad = np.zeros(T, bool)
+    for k in ("weights", "means", "covariances", "predicted_means", "predicted_covariances"):
+        v = np.asarray(getattr(ref, k))
+        bad |= ~np.isfinite(v).reshape(v.shape[0], T, -1).all(axis=(0, 2))
+    return int(np.argmax(bad)) if bad.any() else T
+
+
+@pytest.mark.parametrize("lmode", ["as_written", "matrix_power"])
+def test_cfg3_full5_reference_layout_at_benchmark_size(lmode):
+    """configs[2] exactly as bench.py runs it (bench.py: make_gsf32): gsf_scan_kernel<8,4,2,EMIT_STAGED,L96_PICK>, FULL5,
+    contiguous reference layout [B][K][T][E], B = 16 384, K = 32, one 500-step chunk (152 GB of posterior, the largest single
+    allocation in the repo) and the carry into a second chunk that reuses the buffers, observations drawn from the model.
+    * whole trajectories (first / wave and workgroup edges / middle / last) x all five streams against
+      oracle.gaussian_sum_filter (inference.py:333-371) while finite: `as_written` (nonlinearities.py:48 literally, a
+      contraction: finite throughout) over both chunks = 1 000 steps; `matrix_power` (chaotic) for t < 300;
+    * every element of every stream equal between the 500-step launch and 2 x 250 steps through the carry;
+    * the strided emitter on slices of the batch equal to the staged emitter bit for bit."""
+    import torch
+    import bayesianfiltering_amd as bfa
+    from bayesianfiltering_amd import _lib
+    nl = bfa.nonlinearities
+    B, K, n, m, Tc = 16384, 32, 8, 4, 500
+    two = lmode == "as_written"
+    T = 2 * Tc if two else Tc
+    Q, R = 1e-2 * np.eye(8, dtype=F32), 1e-1 * np.eye(4, dtype=F32)
+    p = bfa.ParamsNLSSM(8 * np.ones(8, F32), np.eye(8, dtype=F32), nl.lorenz96(8, mode=lmode), np.zeros(8, F32), Q, nl.pick_even(8),
+                        np.zeros(4, F32), R)
+    po = go.ParamsNLSSM(8 * np.ones(8, F32), np.eye(8, dtype=F32), om.Lorenz96(8, mode=lmode), np.zeros(8, F32), Q, om.PickEven(8),
+                        np.zeros(4, F32), R)
+    y = cm.device_observations(p, (8, 8, 4, 4), B, T, seed=2000)
+    g = torch.Generator(device="cuda").manual_seed(20)
+    init = 8.0 + torch.randn((B, K, n), device="cuda", generator=g)
+    post, carry = bfa.gaussian_sum_filter(p, y[:, :Tc], K, 1, initial_means=init, return_carry=True)     # the benchmarked launch
+    assert tuple(post.covariances.shape) == (B, K, Tc, n, n) and all(getattr(post, k).is_contiguous() for k in bfa.FULL5)
+
+    idx = [0, 3, 4, 255, 256, B // 2 + 17, B - 2, B - 1]
+    got = {k: getattr(post, k)[idx].cpu().numpy() for k in bfa.FULL5}
+
+    # ---- 2 x 250 through the carry == the 500-step launch, every element of every stream (and the carry)
+    c = None
+    for t0 in (0, Tc // 2):
+        half, c = bfa.gaussian_sum_filter(p, y[:, t0:t0 + Tc // 2], K, 1, initial_means=init, carry=c, return_carry=True)
+        for k in bfa.FULL5:
+            assert _same_bits(getattr(post, k)[:, :, t0:t0 + Tc // 2], getattr(half, k)), (k, t0)
+        del half
+    for a_, b_ in zip(c, carry):
+        assert _same_bits(a_, b_)
+    # ---- strided emitter on slices of the batch == staged emitter
+    lib = _lib.require_gpu()
+    for lo in (0, B // 2 - 128, B - 256):
+        sl = slice(lo, lo + 256)
+        _lib.check(lib.bf_set_option(b"kf_emit_mode", 0))
+        try:
+            alt = bfa.gaussian_sum_filter(p, y[sl, :Tc], K, 1, initial_means=init[sl])
+        finally:
+            _lib.check(lib.bf_set_option(b"kf_emit_mode", -1))
+        for k in bfa.FULL5:
+            assert _same_bits(getattr(post, k)[sl], getattr(alt, k)), (k, lo)
+        del alt
+    # ---- the second chunk from the carry, into the same buffers (bench.py: out=reuse)
+    if two:
+        post, carry = bfa.gaussian_sum_filter(p, y[:, Tc:], K, 1, initial_means=init, carry=carry, out=post, return_carry=True)
+        got = {k: np.concatenate([got[k], getattr(post, k)[idx].cpu().numpy()], axis=2) for k in bfa.FULL5}
+    del post
+    torch.cuda.empty_cache()
+
+    # ---- whole trajectories against the oracle
+    ys, ims = y[idx].cpu().numpy(), init[idx].cpu().numpy()
+    seen, bad = {}, []
+
+    def check(tag, k, e, bound):
+        seen[f"{tag} | {k}"] = list(e)
+        if not max(e) < bound:
+            bad.append((tag, k, e, bound))
+
+    # free-running: `as_written` is a contraction -- all 1 000 steps at 1e-5, norm-wise and element-wise; `matrix_power` is
+    # chaotic: an EKF bank on it amplifies a last-bit difference by ~10^3 within 300 steps (measured: means 4e-4, in the
+    # oracle against itself in float64 just the same), so free-running parity is asserted while it is meaningful (t < 40)
+    # and only recorded beyond
+    To = T if two else 300
+    for j, b in enumerate(idx):
+        ref = go.gaussian_sum_filter(po, ys[j, :To], K, initial_means=ims[j])
+        tf = _finite_prefix(ref, To)
+        seen[f"trajectory {b} | finite steps of the oracle"] = tf
+        if tf < (To if two else 100):
+            bad.append((b, "oracle not finite", tf))
+        for k in bfa.FULL5:
+            for tag, hi, asserted in (("all t", tf, two), ("t<40", min(tf, 40), True)):
+                g_, r_ = got[k][j][:, :hi], np.asarray(getattr(ref, k))[:, :hi]
+                e = (float(np.max(np.abs(g_ - r_))),) if k == "weights" else cm.both_err(g_, r_, k)
+                if asserted:
+                    check(f"free-running {tag}, trajectory {b}", k, e, 2e-5 if k == "weights" else 1e-5)
+                else:
+                    seen[f"free-running {tag} (recorded), trajectory {b} | {k}"] = list(e)
+    # teacher-forced: EVERY step of every chosen trajectory, the oracle's scan body applied to the engine's own carry
+    for j, b in enumerate(idx):
+        w = cm.gsf_one_step_parity(po, K, ys[j], {k: got[k][j] for k in bfa.FULL5}, range(1, T))
+        seen[f"one-step, trajectory {b} | steps skipped (non-finite prior)"] = w.pop("skipped")
+        for k, e in w.items():
+            check(f"one-step all t, trajectory {b}", k, e, 2e-5 if k == "weights" else 1e-5)
+    cm.record(f"cfg3_full5_B16384_{lmode}", **seen)
+    assert not bad, bad
+
+
+def test_cfg5_full5_chunks_of_100_at_benchmark_size():
+    """configs[4] exactly as bench.py runs it (bench.py: make_kalman64): kf_scan_mfma5_kernel<64,32>, FULL5, reference layout,
+    B = 32 768, T-chunks of 100 through the carry (109 GB per chunk), observations drawn from the model.
+    * chunked == one-shot on EVERY element of a 200-step window: the one-shot posterior of 200 steps (218 GB at this batch)
+      is taken half a batch at a time (the kernel is one workgroup per trajectory: halving the grid changes no arithmetic)
+      and each half is compared with the two full-batch 100-step launches, bit for bit;
+    * four whole trajectories (first / second / middle / last) x five streams + log-likelihood over the window against
+      the oracle's C port (oracle/c/kf_oracle.c; inference.py:51-105, utils.py:256-259)."""
+    import torch
+    import bayesianfiltering_amd as bfa
+    import bench
+    a = bench.random_stable_lgssm(64, 32, seed=64)                      # bench.py's own model (SURVEY.md 8d cfg5)
+    p = cm.product_params(a)
+    B, Tc, n = 32768, 100, 64
+    T = 2 * Tc
+    y = cm.device_observations(p, (64, 64, 32, 32), B, T, seed=5000)
+    init = torch.zeros((B, n), device="cuda")
+    idx = [0, 1, B // 2 + 17, B - 1]
+    got = None
+    for h in range(2):
+        hs = slice(h * (B // 2), (h + 1) * (B // 2))
+        one, ll1 = bfa.kalman_filter(p, y[hs], initial_means=init[hs], return_loglik=True)        # 200 steps, half the batch
+        post, carry = None, None
+        chunks = []
+        for t0 in (0, Tc):                                                                         # bench.py's launches
+            post, llc, carry = bfa.kalman_filter(p, y[:, t0:t0 + Tc], initial_means=init, carry=carry, out=post,
+                                                 return_loglik=True, return_carry=True)
+            for k in bfa.FULL5:
+                assert _same_bits(getattr(one, k)[:, :, t0:t0 + Tc], getattr(post, k)[hs]), (k, h, t0)
+            assert _same_bits(ll1[:, :, t0:t0 + Tc], llc[hs]), (h, t0)
+            if h == 0:
+                chunks.append({**{k: getattr(post, k)[idx].cpu().numpy() for k in bfa.FULL5}, "loglik": llc[idx].cpu().numpy()})
+            del llc
+        if h == 0:
+            got = {k: np.concatenate([c_[k] for c_ in chunks], axis=2) for k in chunks[0]}
+        del one, ll1, post
+        torch.cuda.empty_cache()
+    ref = c_oracle.kalman_filter(a, y[idx].cpu().numpy(), np.zeros((len(idx), n), F32))
+    seen = {k: list(cm.both_err(got[k], ref[k], k)) for k in list(bfa.FULL5) + ["loglik"]}
+    cm.record("cfg5_full5_B32768_chunks_of_100", **seen)
+    for k, e in seen.items():
+        assert max(e) < 1e-5, (k, seen)

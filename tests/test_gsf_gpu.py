@@ -1,6 +1,8 @@
 """GPU parity of the Gaussian-sum / EKF kernel (bf_gsf_ekf_f32) against the NumPy oracle and the
-golden fixtures.  Tolerance: 1e-5 relative (north_star) on means / covariances; weights are
-compared absolutely (they are in [0, 1])."""
+golden fixtures.  Tolerance: 1e-5 relative (north_star) on means / covariances -- norm-wise AND element-wise with an rms
+floor per vector / matrix (tests/common.py: elem_err); weights are compared absolutely (they are in [0, 1]).  Measured
+margins (BF_RECORD_PARITY=1, round 3): every assertion of this file <= 3e-6 norm-wise except the two scalar models noted
+at their test."""
 import numpy as np
 import pytest
 
@@ -18,17 +20,18 @@ def _nl():
     return bfa, bfa.nonlinearities
 
 
-def _check(post, ref, ll=None, ref_ll=None, tol=TOL, wtol=2e-5):
+def _check(post, ref, ll=None, ref_ll=None, tol=TOL, wtol=2e-5, etol=1e-4):
     for k in FIELDS:
         got = getattr(post, k).cpu().numpy()
         exp = getattr(ref, k) if hasattr(ref, "_fields") else ref[k]
         assert got.shape == exp.shape, k
-        assert cm.rel_err(got, exp) < tol, (k, cm.rel_err(got, exp))
+        e = cm.both_err(got, exp, k)
+        assert e[0] < tol and e[1] < etol * (tol / TOL), (k, e)
     w = post.weights.cpu().numpy()
     we = ref.weights if hasattr(ref, "_fields") else ref["weights"]
     assert np.max(np.abs(w - we)) < wtol
     if ll is not None:
-        assert cm.rel_err(ll.cpu().numpy(), ref_ll) < 3e-5
+        assert cm.rel_err(ll.cpu().numpy(), ref_ll) < 1e-5
 
 
 def _mode(mode):
@@ -87,7 +90,7 @@ def test_bot_with_inputs_nonpow2_components():
     ref = _oracle_batch(po, ys, K, init, inputs.reshape(T, 1))
     post = bfa.gaussian_sum_filter(pp, ys, K, 1, inputs, initial_means=init)
     assert tuple(post.means.shape) == (B, K, T, 4)
-    _check(post, ref, tol=3e-5)
+    _check(post, ref)
 
 
 def test_single_linear_component_equals_kalman_kernel():
@@ -109,7 +112,7 @@ def test_default_initial_means_follow_prngkey0_draw():
     ys = cm.simulate_batch(a, 1, 16, seed=5)[0]
     post = bfa.gaussian_sum_filter(cm.product_params(a), ys, 3)          # reference signature, no extras
     ref = go.gaussian_sum_filter(cm.oracle_params(a), ys, 3)
-    _check(post, ref, tol=3e-5)
+    _check(post, ref)
 
 
 @pytest.mark.parametrize("K,n", [(32, 8), (100, 4), (64, 4), (40, 8), (3, 4)])
@@ -131,7 +134,7 @@ def test_many_components(K, n):
     init = rng.normal(size=(B, K, n)).astype(F32)
     ref = _oracle_batch(po, ys, K, init)
     post = bfa.gaussian_sum_filter(pp, ys, K, 1, initial_means=init)
-    _check(post, ref, tol=3e-5)
+    _check(post, ref)
     _mode(0)
     try:
         post0 = bfa.gaussian_sum_filter(pp, ys, K, 1, initial_means=init)
@@ -157,7 +160,7 @@ def test_stochastic_volatility_switching_emission():
     init = np.random.default_rng(1).normal(size=(K, 3)).astype(F32)
     ref = go.gaussian_sum_filter(po, ys, K, initial_means=init, inputs=inputs.reshape(T, 1))
     post = bfa.gaussian_sum_filter(pp, ys, K, 1, inputs, initial_means=init)
-    _check(post, ref, tol=3e-5)
+    _check(post, ref)
 
 
 def test_scalar_growth_and_sine_models():
@@ -172,7 +175,7 @@ def test_scalar_growth_and_sine_models():
     xs, ys = go.sample_ssm(po, otf.PRNGKey(1), T, u.reshape(T, 1))
     init = np.array([[0.5], [-0.5], [1.5]], F32)
     # |f'(x)| reaches 25.5 for the growth model: ulp-level differences (v_rcp_f32 vs IEEE division)
-    # are amplified step after step, in the oracle as much as here
+    # are amplified step after step, in the oracle as much as here (measured 4.1e-5 over the 20 steps, round 3)
     _check(bfa.gaussian_sum_filter(pp, ys, K, 1, u, initial_means=init),
            go.gaussian_sum_filter(po, ys, K, initial_means=init, inputs=u.reshape(T, 1)), tol=2e-4)
     # f1 / g1: sin(w0 x) + q, c x.x + r.  (w0 = 10 as in the notebook is a chaotic map -- |f'| up to 10
@@ -240,7 +243,7 @@ def test_staged_partial_rows_and_single_trajectory_waves():
         post = bfa.gaussian_sum_filter(pp, ys, K, 1, initial_means=init)
     finally:
         _mode(-1)
-    _check(post, ref, tol=3e-5)
+    _check(post, ref)
 
 
 def _opt(name, value):
@@ -281,8 +284,8 @@ def test_structured_lorenz96_instances(n, lanes, lmode):
             _mode(-1)
             _opt(b"kf_lanes", 0)
             _opt(b"gsf_structured", 1)
-    _check(res[1, -1], ref, tol=3e-5)
-    _check(res[0, -1], ref, tol=3e-5)
+    _check(res[1, -1], ref)
+    _check(res[0, -1], ref)
     for k in FIELDS + ("weights",):
         a, b = getattr(res[1, -1], k).cpu().numpy(), getattr(res[1, 0], k).cpu().numpy()
         assert np.array_equal(a, b), k                      # staged == strided stores, bit for bit
@@ -323,11 +326,11 @@ def test_time_varying_covariances():
             post = bfa.gaussian_sum_filter(pp_tv, ys, K, 1, initial_means=init)
         finally:
             _mode(-1)
-        _check(post, ref, tol=3e-5)
+        _check(post, ref)
     # only Q varies / only R varies
     for kw in ({"dynamics_noise_covariance": Qt}, {"emission_noise_covariance": Rt}):
         ref1 = _oracle_batch(po._replace(**kw), ys, K, init)
-        _check(bfa.gaussian_sum_filter(pp._replace(**kw), ys, K, 1, initial_means=init), ref1, tol=3e-5)
+        _check(bfa.gaussian_sum_filter(pp._replace(**kw), ys, K, 1, initial_means=init), ref1)
     # wrong number of steps
     with pytest.raises(bfa.BayesFiltError):
         bfa.gaussian_sum_filter(pp._replace(dynamics_noise_covariance=Qt[:5]), ys, K, 1, initial_means=init)
@@ -367,14 +370,14 @@ def test_collapsed_mode_matches_collapse_of_the_streams(case):
     finally:
         _opt(b"gsf_structured", 1)
         _opt(b"kf_lanes", 0)
-    _check(post, ref, tol=3e-5)
+    _check(post, ref)
     assert tuple(cmean.shape) == (B, T, n) and tuple(ccov.shape) == (B, T, n, n)
     for b in range(B):
         for t in range(T):
             mu, Sg = go.collapse(ref["means"][b, :, t].astype(np.float64), ref["covariances"][b, :, t].astype(np.float64),
                                  ref["weights"][b, :, t].astype(np.float64))
-            assert cm.rel_err(cmean[b, t].cpu().numpy(), mu) < 3e-5
-            assert cm.rel_err(ccov[b, t].cpu().numpy(), Sg) < 3e-5
+            assert cm.rel_err(cmean[b, t].cpu().numpy(), mu) < 1e-5
+            assert cm.rel_err(ccov[b, t].cpu().numpy(), Sg) < 1e-5
     # with no per-component streams requested the same numbers come back
     assert all(getattr(only[0], k) is None for k in FIELDS + ("weights",))
     assert np.array_equal(only[1][0].cpu().numpy(), cmean.cpu().numpy())
@@ -400,5 +403,5 @@ def test_staged_path_when_T_is_not_a_multiple_of_four():
     ref = _oracle_batch(po, ys[:2], K, init[:2])
     for k in FIELDS + ("weights",):
         assert np.array_equal(getattr(res[2][0], k).cpu().numpy(), getattr(res[0][0], k).cpu().numpy()), k
-        assert cm.rel_err(getattr(res[2][0], k).cpu().numpy()[:2], ref[k]) < 3e-5 or k == "weights", k
+        assert cm.rel_err(getattr(res[2][0], k).cpu().numpy()[:2], ref[k]) < 1e-5 or k == "weights", k
     assert np.array_equal(res[2][1].cpu().numpy(), res[0][1].cpu().numpy())

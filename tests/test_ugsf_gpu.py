@@ -52,7 +52,7 @@ def test_linear_model_matches_oracle_and_the_kalman_filter(uparams):
     ref, ref_ll = _oracle_batch(po, go.ParamsUKF(*uparams), ys, K, init)
     post, ll = bfa.unscented_gaussian_sum_filter(pp, up, ys, K, 1, initial_means=init, return_loglik=True)
     assert tuple(post.means.shape) == (B, K, T, 4) and tuple(post.covariances.shape) == (B, K, T, 4, 4)
-    _check(post, ref, tol=2e-5)
+    _check(post, ref, tol=1e-5)
     assert cm.rel_err(ll.cpu().numpy(), ref_ll) < 5e-5
     ekf = bfa.gaussian_sum_filter(pp, ys, K, 1, initial_means=init)
     for k in FIELDS:
@@ -78,7 +78,7 @@ def test_bearings_only_tracking_with_inputs():
     init = (mu0 + 0.05 * rng.normal(size=(B, K, 4))).astype(F32)
     ref, _ = _oracle_batch(po, go.ParamsUKF(1, 0, 0), ys, K, init, inputs.reshape(T, 1))
     post = bfa.unscented_gaussian_sum_filter(pp, bfa.ParamsUKF(1, 0, 0), ys, K, 1, inputs, initial_means=init)
-    _check(post, ref, tol=2e-5)
+    _check(post, ref, tol=1e-5)
     # the scan in two chunks through the carry reproduces the single scan bit for bit
     p1, c1 = bfa.unscented_gaussian_sum_filter(pp, bfa.ParamsUKF(1, 0, 0), ys[:, :10], K, 1, inputs[:10], initial_means=init,
                                                return_carry=True)
@@ -99,7 +99,7 @@ def test_lorenz63_quadratic_and_scalar_models():
     init = (np.array([0.0, 1.0, 1.05], F32) + np.random.default_rng(3).normal(size=(K, 3))).astype(F32)
     for up in ((1.0, 0.0, 0.0), (1.0, 2.0, 0.5)):
         ref = go.unscented_gaussian_sum_filter(po, go.ParamsUKF(*up), ys, K, initial_means=init)
-        _check(bfa.unscented_gaussian_sum_filter(pp, bfa.ParamsUKF(*up), ys, K, 1, initial_means=init), ref, tol=2e-5)
+        _check(bfa.unscented_gaussian_sum_filter(pp, bfa.ParamsUKF(*up), ys, K, 1, initial_means=init), ref, tol=1e-5)
     # scalar state: sin dynamics with the quadratic emission (f1 / g1 of Experiment_TSP_2023.ipynb, w0 = 1.5)
     po = go.ParamsNLSSM(np.zeros(1, F32), np.eye(1, dtype=F32), om.Sine(1, 1.5), np.zeros(1, F32), 0.1 * np.eye(1, dtype=F32),
                         om.Quadratic(1, 0.5), np.zeros(1, F32), 0.5 * np.eye(1, dtype=F32))
@@ -108,7 +108,7 @@ def test_lorenz63_quadratic_and_scalar_models():
     ys = go.sample_ssm(po, otf.PRNGKey(5), T)[1]
     init = np.array([[0.4], [-0.6], [1.0]], F32)
     ref = go.unscented_gaussian_sum_filter(po, go.ParamsUKF(1, 0, 0), ys, 3, initial_means=init)
-    _check(bfa.unscented_gaussian_sum_filter(pp, bfa.ParamsUKF(1, 0, 0), ys, 3, 1, initial_means=init), ref, tol=2e-5)
+    _check(bfa.unscented_gaussian_sum_filter(pp, bfa.ParamsUKF(1, 0, 0), ys, 3, 1, initial_means=init), ref, tol=1e-5)
 
 
 def test_stochastic_volatility_non_additive_noise():
@@ -127,7 +127,7 @@ def test_stochastic_volatility_non_additive_noise():
     init = np.random.default_rng(1).normal(size=(K, 2)).astype(F32)
     ref = go.unscented_gaussian_sum_filter(po, go.ParamsUKF(1, 0, 0), ys, K, initial_means=init, inputs=inputs.reshape(T, 1))
     post = bfa.unscented_gaussian_sum_filter(pp, bfa.ParamsUKF(1, 0, 0), ys, K, 1, inputs, initial_means=init)
-    _check(post, ref, tol=2e-5)
+    _check(post, ref, tol=1e-5)
 
 
 def test_lorenz96_eight_states_and_many_components():
@@ -141,7 +141,7 @@ def test_lorenz96_eight_states_and_many_components():
     for K in (2, 100):   # K = 100: 128 lanes per trajectory, the reweight continues through LDS
         init = np.random.default_rng(K).normal(size=(B, K, 8)).astype(F32)
         ref, _ = _oracle_batch(po, go.ParamsUKF(1, 0, 0), ys, K, init)
-        _check(bfa.unscented_gaussian_sum_filter(pp, bfa.ParamsUKF(1, 0, 0), ys, K, 1, initial_means=init), ref, tol=2e-5)
+        _check(bfa.unscented_gaussian_sum_filter(pp, bfa.ParamsUKF(1, 0, 0), ys, K, 1, initial_means=init), ref, tol=2e-5)   # measured 1.8e-5 at K = 100 (unscented transform of the chaotic map, 12 steps)
 
 
 def test_errors():
@@ -166,7 +166,7 @@ def test_golden_bearings_only_fixture(golden_dir):
                          1e-3 * np.eye(2, dtype=F32), nl.bearing_range(), np.zeros(2, F32), np.diag([1e-3, 1e-2]).astype(F32))
     post = bfa.unscented_gaussian_sum_filter(pp, bfa.ParamsUKF(*d["uparams"]), d["emissions"], 4, 1, d["inputs"],
                                              initial_means=d["initial_means"])
-    _check(post, d, tol=2e-5)
+    _check(post, d, tol=1e-5)
 
 
 def test_time_varying_covariances():
@@ -197,8 +197,8 @@ def test_time_varying_covariances():
         ref, ref_ll = _oracle_batch(po._replace(**kw), go.ParamsUKF(*up), ys, K, init)
         post, ll = bfa.unscented_gaussian_sum_filter(pp._replace(**kw), bfa.ParamsUKF(*up), ys, K, 1, initial_means=init,
                                                      return_loglik=True)
-        _check(post, ref, tol=3e-5)
-        assert cm.rel_err(ll.cpu().numpy(), ref_ll) < 5e-5
+        _check(post, ref, tol=1e-5)
+        assert cm.rel_err(ll.cpu().numpy(), ref_ll) < 1e-5
         ekf = bfa.gaussian_sum_filter(pp._replace(**kw), ys, K, 1, initial_means=init)
         for k in FIELDS:
             assert cm.rel_err(getattr(post, k).cpu().numpy(), getattr(ekf, k).cpu().numpy()) < 1e-4, k
@@ -219,4 +219,4 @@ def test_time_varying_covariances():
     ys2 = go.sample_ssm(po2._replace(emission_noise_covariance=R), otf.PRNGKey(3), T2, inputs.reshape(T2, 1))[1]
     init2 = rng.normal(size=(K2, 2)).astype(F32)
     ref2 = go.unscented_gaussian_sum_filter(po2, go.ParamsUKF(1, 0, 0), ys2, K2, initial_means=init2, inputs=inputs.reshape(T2, 1))
-    _check(bfa.unscented_gaussian_sum_filter(pp2, bfa.ParamsUKF(1, 0, 0), ys2, K2, 1, inputs, initial_means=init2), ref2, tol=3e-5)
+    _check(bfa.unscented_gaussian_sum_filter(pp2, bfa.ParamsUKF(1, 0, 0), ys2, K2, 1, inputs, initial_means=init2), ref2, tol=1e-5)

@@ -211,3 +211,96 @@ def test_user_model_errors_and_cache():
     # the particle / unscented / augmented kernels take registry functions only
     with pytest.raises(_lib.BayesFiltError):
         bfa.unscented_gaussian_sum_filter(base._replace(dynamics_function=f), bfa.ParamsUKF(1, 0, 0), ys, 1, initial_means=np.zeros((1, 1), F32))
+
+
+LINEAR_SRC = """
+template <class T> __device__ void dynamics(const T* x, const T* q, T u, const float* th, T* out) {
+  for (int i = 0; i < BF_N; ++i) {
+    T s = th[i * BF_N] * x[0];
+    for (int j = 1; j < BF_N; ++j) s = s + th[i * BF_N + j] * x[j];
+    out[i] = s + q[i];
+  }
+}
+"""
+
+
+def test_user_model_with_more_than_64_kib_of_lds():
+    """n = 48: the dual-number scratch + the covariance tiles need ~ 91 KiB of dynamic LDS -- the module-function launch above
+    the 64 KiB default (launch_user_kernel).  A dense linear map written as source against the oracle's C port."""
+    import bayesianfiltering_amd as bfa
+    nl = bfa.nonlinearities
+    n, m, B, T = 48, 4, 3, 12
+    a = cm.random_stable_lgssm(n, m, seed=48)
+    a["G"] = np.eye(n, dtype=F32)
+    from oracle import c_oracle
+    ys = cm.simulate_batch(a, B, T, seed=48)
+    init = np.tile(a["m0"], (B, 1))
+    ref = c_oracle.kalman_filter(a, ys, init)
+    reg = cm.product_params(a)
+    usr = reg._replace(dynamics_function=nl.user_dynamics(LINEAR_SRC, n, theta=a["A"].reshape(-1)))
+    post = bfa.gaussian_sum_filter(usr, ys, 1, 1, initial_means=init.reshape(B, 1, n))
+    for k in FIELDS[1:]:
+        assert max(cm.both_err(getattr(post, k).cpu().numpy(), ref[k])) < 1e-5, k
+
+
+def test_user_model_handle_must_match_the_model(monkeypatch):
+    """bf_model.user is compiled for fixed (n, dq, m, dr) and for the functions it was given: a handle that does not match
+    the bf_model it is attached to is refused with BF_EINVAL before anything is launched (the JIT kernel indexes LDS with
+    its compile-time dimensions)."""
+    import bayesianfiltering_amd as bfa
+    from bayesianfiltering_amd import _lib, inference
+    nl = bfa.nonlinearities
+    Q, R = 0.1 * np.eye(3, dtype=F32), np.eye(1, dtype=F32)
+    m0, P0 = np.array([0.0, 1.0, 1.05], F32), np.eye(3, dtype=F32)
+    usr = bfa.ParamsNLSSM(m0, P0, nl.user_dynamics(L63_SRC, 3, theta=[10.0, 28.0, 2.667, 0.01]), np.zeros(3, F32), Q,
+                          nl.quadratic(3, 0.05), np.zeros(1, F32), R)
+    ys = np.zeros((6, 1), F32)
+    im = np.zeros((1, 3), F32)
+    bfa.gaussian_sum_filter(usr, ys, 1, initial_means=im)                      # the matching handle runs
+    real = inference._compile_user_model
+    # (a) a handle compiled for other dimensions
+    monkeypatch.setattr(inference, "_compile_user_model", lambda d, e, n, dq, m, dr: real(d, e, n + 1, dq + 1, m, dr))
+    with pytest.raises(_lib.BayesFiltError) as e:
+        bfa.gaussian_sum_filter(usr, ys, 1, initial_means=im)
+    assert e.value.code == _lib.BF_EINVAL and "compiled for" in str(e.value)
+    # (b) dyn_id = BF_FN_USER on a handle that holds an emission only
+    monkeypatch.setattr(inference, "_compile_user_model", lambda d, e, n, dq, m, dr: real(None, QUAD_SRC, n, dq, m, dr))
+    with pytest.raises(_lib.BayesFiltError) as e:
+        bfa.gaussian_sum_filter(usr, ys, 1, initial_means=im)
+    assert e.value.code == _lib.BF_EINVAL and "without dynamics source" in str(e.value)
+    # (c) a handle that holds a function the model does not ask for
+    monkeypatch.setattr(inference, "_compile_user_model", lambda d, e, n, dq, m, dr: real(L63_SRC, QUAD_SRC, n, dq, m, dr))
+    with pytest.raises(_lib.BayesFiltError) as e:
+        bfa.gaussian_sum_filter(usr, ys, 1, initial_means=im)
+    assert e.value.code == _lib.BF_EINVAL and "emi_id must be BF_FN_USER" in str(e.value)
+
+
+def test_corrupt_jit_cache_file_is_rebuilt(tmp_path):
+    """A truncated code object under the cache's final name (a crashed writer, a stale file from another ROCm) is deleted
+    and recompiled, not reported for good.  Child processes: the cache directory is read from the environment at first use."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import ctypes as C, sys
+sys.path.insert(0, {root!r})
+from bayesianfiltering_amd import _lib
+lib = _lib.require_gpu()
+src = b"template <class T> __device__ void dynamics(const T* x, const T* q, T u, const float* th, T* out) {{ out[0] = x[0] * 0.5f + q[0]; }}"
+h = C.c_void_p()
+rc = lib.bf_user_model_create(src, None, 1, 1, 1, 1, C.byref(h))
+assert rc == _lib.BF_OK, (rc, lib.bf_last_error())
+print("created")
+"""
+    env = dict(os.environ, BAYESFILT_CACHE_DIR=str(tmp_path))
+    run = lambda: subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    r = run()
+    assert r.returncode == 0 and "created" in r.stdout, (r.stdout, r.stderr)
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".co")]
+    assert len(files) == 1 and not [f for f in os.listdir(tmp_path) if f.endswith(".tmp")]
+    good = (tmp_path / files[0]).read_bytes()
+    (tmp_path / files[0]).write_bytes(good[: len(good) // 3])
+    r = run()
+    assert r.returncode == 0 and "created" in r.stdout, (r.stdout, r.stderr)
+    assert (tmp_path / files[0]).read_bytes() == good
