@@ -56,6 +56,7 @@ int launch_resample(const float* d_w, const uint32_t* d_keys, long long B, int N
 // process-wide tuning options: atomics, each read once at the top of a call (a launch never sees a torn mix)
 extern std::atomic<int> g_bpf_variant;
 extern std::atomic<int> g_bpf_hbm_mode;
+extern std::atomic<int> g_bpf_spec;
 extern std::atomic<int> g_gsf_structured;
 extern std::atomic<int> g_kf_mfma_variant;
 static std::atomic<int> g_kf_emit_mode{-1};  // -1 = choose from the layout
@@ -170,6 +171,11 @@ int bf_set_option(const char* name, int value) {
   if (name && std::strcmp(name, "bpf_hbm_mode") == 0) {
     if (value < 0 || value > 2) return bf::set_error(BF_EINVAL, "bpf_hbm_mode must be 0, 1 or 2");
     bf::g_bpf_hbm_mode = value;
+    return BF_OK;
+  }
+  if (name && std::strcmp(name, "bpf_spec") == 0) {
+    if (value < 0 || value > 6) return bf::set_error(BF_EINVAL, "bpf_spec must be 0 ... 6");
+    bf::g_bpf_spec = value;
     return BF_OK;
   }
   return bf::set_error(BF_EINVAL, "unknown option '%s'", name ? name : "(null)");

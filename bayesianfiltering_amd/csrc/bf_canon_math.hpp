@@ -28,15 +28,10 @@ __host__ __device__ __forceinline__ uint32_t canon_f_bits(float f) {
   return c.u;
 }
 
-__host__ __device__ inline float canon_log(float x) {
+// canon_log for a POSITIVE, NORMAL, FINITE argument: the arithmetic of canon_log without its special cases (call sites that
+// can prove the precondition -- erf_inv's 1 - x^2 with |x| < 1 -- skip a dozen compares, selects and their branches).
+__host__ __device__ __forceinline__ float canon_log_core(float x) {
 #pragma clang fp contract(off)
-  if (!(x > 0.0f)) return x == 0.0f ? -__builtin_inff() : __builtin_nanf("");
-  if (x == __builtin_inff()) return x;
-  float adj = 0.0f;
-  if (x < 1.17549435e-38f) {  // subnormal: scale by 2^24 first
-    x = x * 16777216.0f;
-    adj = 16.635532333438686f;
-  }
   const uint32_t ix = canon_f_bits(x);
   int e = (int)((ix >> 23) & 0xFFu) - 126;                                  // x = m 2^e, m in [0.5, 1)
   const float m = canon_bits_f((ix & 0x007FFFFFu) | 0x3F000000u);
@@ -58,9 +53,16 @@ __host__ __device__ inline float canon_log(float x) {
   const float ef = (float)e;
   y = __builtin_fmaf(ef, -2.12194440e-4f, y);
   y = __builtin_fmaf(-0.5f, z, y);
-  float r = f + y;
-  r = __builtin_fmaf(ef, 0.693359375f, r);
-  return adj != 0.0f ? r - adj : r;
+  const float r = f + y;
+  return __builtin_fmaf(ef, 0.693359375f, r);
+}
+
+__host__ __device__ inline float canon_log(float x) {
+#pragma clang fp contract(off)
+  if (!(x > 0.0f)) return x == 0.0f ? -__builtin_inff() : __builtin_nanf("");
+  if (x == __builtin_inff()) return x;
+  if (x < 1.17549435e-38f) return canon_log_core(x * 16777216.0f) - 16.635532333438686f;  // subnormal: scale by 2^24 first
+  return canon_log_core(x);
 }
 
 __host__ __device__ inline float canon_exp(float x) {

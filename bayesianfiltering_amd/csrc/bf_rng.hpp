@@ -93,13 +93,176 @@ __host__ __device__ __forceinline__ float erfinv_f32(float x) {
   return fabsf(x) == 1.0f ? x * __builtin_inff() : p * x;
 }
 
+// erfinv_f32 for |x| < 1 with 1 - x^2 a normal number (every argument jax.random.normal's map produces: |u| <= 0.99999994):
+// the same operations, bit for bit, minus the special cases -- the log without its argument checks, the central polynomial
+// evaluated for every lane and the tail (|x| > 0.9966, 3 draws in 1000) behind ONE rarely taken branch instead of a
+// two-sided one, no |x| = 1 select.
+__host__ __device__ __forceinline__ float erfinv_open_f32(float x) {
+#pragma clang fp contract(off)
+  const float t = x * x;
+  const float a = 1.0f - t;
+  const float w0 = -canon_log_core(a);
+  float w = w0 - 2.5f;
+  float p = 2.81022636e-08f;
+  p = __builtin_fmaf(p, w, 3.43273939e-07f);
+  p = __builtin_fmaf(p, w, -3.5233877e-06f);
+  p = __builtin_fmaf(p, w, -4.39150654e-06f);
+  p = __builtin_fmaf(p, w, 0.00021858087f);
+  p = __builtin_fmaf(p, w, -0.00125372503f);
+  p = __builtin_fmaf(p, w, -0.00417768164f);
+  p = __builtin_fmaf(p, w, 0.246640727f);
+  p = __builtin_fmaf(p, w, 1.50140941f);
+  if (__builtin_expect(!(w0 < 5.0f), 0)) {
+    w = __builtin_sqrtf(w0) - 3.0f;
+    p = -0.000200214257f;
+    p = __builtin_fmaf(p, w, 0.000100950558f);
+    p = __builtin_fmaf(p, w, 0.00134934322f);
+    p = __builtin_fmaf(p, w, -0.00367342844f);
+    p = __builtin_fmaf(p, w, 0.00573950773f);
+    p = __builtin_fmaf(p, w, -0.0076224613f);
+    p = __builtin_fmaf(p, w, 0.00943887047f);
+    p = __builtin_fmaf(p, w, 1.00167406f);
+    p = __builtin_fmaf(p, w, 2.83297682f);
+  }
+  return p * x;
+}
+
 // jax.random.normal's map: u = max(lo, unit * (1 - lo) + lo), lo = nextafter(-1, 0); sqrt(2) * erf_inv(u)
 __host__ __device__ __forceinline__ float bits_to_normal(uint32_t bits) {
 #pragma clang fp contract(off)
   const float lo = -0.99999994f;
   float u = __builtin_fmaf(bits_to_unit(bits), 1.0f - lo, lo);  // (1 - lo) = 2.0f in binary32: the product is exact
-  u = u > lo ? u : lo;
-  return 1.41421356237309515f * erfinv_f32(u);
+  u = u > lo ? u : lo;   // |u| <= 0.99999994: 1 - u^2 >= 1.19e-7, a normal number
+  return 1.41421356237309515f * erfinv_open_f32(u);
 }
+
+// The tail branch of erfinv_open_f32 alone (w0 = -log(1 - x^2) >= 5), for callers that evaluate the central branch elsewhere.
+__host__ __device__ __forceinline__ float erfinv_tail_poly(float w0) {
+#pragma clang fp contract(off)
+  const float w = __builtin_sqrtf(w0) - 3.0f;
+  float p = -0.000200214257f;
+  p = __builtin_fmaf(p, w, 0.000100950558f);
+  p = __builtin_fmaf(p, w, 0.00134934322f);
+  p = __builtin_fmaf(p, w, -0.00367342844f);
+  p = __builtin_fmaf(p, w, 0.00573950773f);
+  p = __builtin_fmaf(p, w, -0.0076224613f);
+  p = __builtin_fmaf(p, w, 0.00943887047f);
+  p = __builtin_fmaf(p, w, 1.00167406f);
+  p = __builtin_fmaf(p, w, 2.83297682f);
+  return p;
+}
+
+#ifdef __HIPCC__
+// threefry2x32(k0, k1, C0, C1) and bits_to_normal of both output words as ONE hand-scheduled gfx950 instruction sequence:
+// the operations of the C++ functions above, one for one and in their order (the bits are the same: tests/test_bpf_gpu.py,
+// the compile-time instance against the run-time one and both against the oracle), written out because the compiler, given
+// sixteen of these chains per particle and four particles per thread inside a 128-register budget, hoists their ~40 literal
+// constants into registers, interleaves the chains and pays with hundreds of spills.  As an opaque block it needs 12 vector
+// registers, holds every constant as an instruction literal and keeps its two normals' polynomial chains interleaved (two
+// independent chains per wave: a dependent gfx950 VALU instruction issues 8 cycles after its producer).
+//   rounds:   x0 += x1; x1 = rotl(x1, R) [v_alignbit_b32 by 32 - R]; x1 ^= x0;   key injection: x0 += ks[a]; x1 += ks[b] + i
+//   normal:   unit = bits >> 9 | 1.0f, - 1; u = max(fma(unit, 2, lo), lo); a = 1 - u u; canon_log_core(a); w = -2.5 - log;
+//             central erf_inv polynomial p(w)  ->  outputs p, log(a) and u; the caller takes the rare tail branch and the
+//             final products in C++ (erfinv_tail_poly).
+#define BF_TFR(R_) "v_add_u32 %[x0], %[x0], %[x1]\n\tv_alignbit_b32 %[x1], %[x1], %[x1], " #R_ "\n\tv_xor_b32 %[x1], %[x1], %[x0]\n\t"
+#define BF_TFA BF_TFR(19) BF_TFR(17) BF_TFR(6) BF_TFR(26)
+#define BF_TFB BF_TFR(15) BF_TFR(3) BF_TFR(16) BF_TFR(8)
+#define BF_TFI(KA_, KB_, I_) "v_add_u32 %[x0], %[x0], %[" #KA_ "]\n\tv_add3_u32 %[x1], %[x1], %[" #KB_ "], " #I_ "\n\t"
+// bits (register X_, dies) -> u (U_), a = 1 - u^2 (R_), m - 1 or 2 m - 1 (F_), unbiased exponent as float (Z_); Y_ scratch.
+// (m - 1) + (small ? m : 0): m - 1 lies in [-0.5, -2^-24], so adding +0 is the identity on its bits, as adding -0 is in the
+// C++ form's `small ? (m - 1) + m : m - 1`; the select cannot take a literal next to its implicit vcc read.)
+#define BF_NRM_HEAD(X_, U_, R_, F_, Y_, Z_)                                  \
+  "v_lshrrev_b32 %[" #U_ "], 9, %[" #X_ "]\n\t"                              \
+  "v_or_b32 %[" #U_ "], 1.0, %[" #U_ "]\n\t"                                 \
+  "v_add_f32 %[" #U_ "], -1.0, %[" #U_ "]\n\t"                               \
+  "v_fmaak_f32 %[" #U_ "], 2.0, %[" #U_ "], 0xbf7fffff\n\t"                  \
+  "v_max_f32 %[" #U_ "], 0xbf7fffff, %[" #U_ "]\n\t"                         \
+  "v_mul_f32 %[" #R_ "], %[" #U_ "], %[" #U_ "]\n\t"                         \
+  "v_sub_f32 %[" #R_ "], 1.0, %[" #R_ "]\n\t"                                \
+  "v_and_b32 %[" #F_ "], 0x7fffff, %[" #R_ "]\n\t"                           \
+  "v_or_b32 %[" #F_ "], 0.5, %[" #F_ "]\n\t"                                 \
+  "v_lshrrev_b32 %[" #Z_ "], 23, %[" #R_ "]\n\t"                             \
+  "v_cmp_gt_f32 vcc, 0x3f3504f3, %[" #F_ "]\n\t"                             \
+  "v_add_f32 %[" #Y_ "], -1.0, %[" #F_ "]\n\t"                               \
+  "v_cndmask_b32 %[" #F_ "], 0, %[" #F_ "], vcc\n\t"                         \
+  "v_subbrev_co_u32 %[" #Z_ "], vcc, 0, %[" #Z_ "], vcc\n\t"                 \
+  "v_add_f32 %[" #F_ "], %[" #Y_ "], %[" #F_ "]\n\t"                         \
+  "v_add_u32 %[" #Z_ "], 0xffffff82, %[" #Z_ "]\n\t"                         \
+  "v_cvt_f32_i32 %[" #Z_ "], %[" #Z_ "]\n\t"
+#define BF_2(A_, B_) A_ B_
+// one Horner step of both chains: y = y f + K
+#define BF_HORNER2(YA_, FA_, YB_, FB_, K_)                                                      \
+  "v_fmaak_f32 %[" #YA_ "], %[" #YA_ "], %[" #FA_ "], " #K_ "\n\t"                              \
+  "v_fmaak_f32 %[" #YB_ "], %[" #YB_ "], %[" #FB_ "], " #K_ "\n\t"
+template <int C0, int C1>
+__device__ __forceinline__ void threefry_two_normals_gfx950(uint32_t k0, uint32_t k1, uint32_t k2, float& z0, float& z1) {
+#pragma clang fp contract(off)
+  uint32_t x0, x1;
+  float ua, ra, fa, ya, za, pa, ub, rb, fb, yb, zb, pb;
+  asm volatile(
+      "v_add_u32 %[x0], %[c0], %[k0]\n\t"
+      "v_add_u32 %[x1], %[c1], %[k1]\n\t"
+      BF_TFA BF_TFI(k1, k2, 1) BF_TFB BF_TFI(k2, k0, 2) BF_TFA BF_TFI(k0, k1, 3) BF_TFB BF_TFI(k1, k2, 4) BF_TFA BF_TFI(k2, k0, 5)
+      BF_NRM_HEAD(x0, ua, ra, fa, ya, za)
+      BF_NRM_HEAD(x1, ub, rb, fb, yb, zb)
+      // canon_log_core polynomial, both chains
+      "v_mov_b32 %[ya], 0x3d9021bb\n\t"
+      "v_mov_b32 %[yb], 0x3d9021bb\n\t"
+      BF_HORNER2(ya, fa, yb, fb, 0xbdebd1b8) BF_HORNER2(ya, fa, yb, fb, 0x3def251a) BF_HORNER2(ya, fa, yb, fb, 0xbdfe5d4f)
+      BF_HORNER2(ya, fa, yb, fb, 0x3e11e9bf) BF_HORNER2(ya, fa, yb, fb, 0xbe2aae50) BF_HORNER2(ya, fa, yb, fb, 0x3e4cceac)
+      BF_HORNER2(ya, fa, yb, fb, 0xbe7ffffc) BF_HORNER2(ya, fa, yb, fb, 0x3eaaaaaa)
+      "v_mul_f32 %[ya], %[ya], %[fa]\n\t"
+      "v_mul_f32 %[yb], %[yb], %[fb]\n\t"
+      "v_mul_f32 %[pa], %[fa], %[fa]\n\t"
+      "v_mul_f32 %[pb], %[fb], %[fb]\n\t"
+      "v_mul_f32 %[ya], %[ya], %[pa]\n\t"
+      "v_mul_f32 %[yb], %[yb], %[pb]\n\t"
+      "v_fmac_f32 %[ya], 0xb95e8083, %[za]\n\t"
+      "v_fmac_f32 %[yb], 0xb95e8083, %[zb]\n\t"
+      "v_fmac_f32 %[ya], -0.5, %[pa]\n\t"
+      "v_fmac_f32 %[yb], -0.5, %[pb]\n\t"
+      "v_add_f32 %[ra], %[fa], %[ya]\n\t"
+      "v_add_f32 %[rb], %[fb], %[yb]\n\t"
+      "v_fmac_f32 %[ra], 0x3f318000, %[za]\n\t"
+      "v_fmac_f32 %[rb], 0x3f318000, %[zb]\n\t"
+      // w = -2.5 - log(a); central erf_inv polynomial, both chains
+      "v_sub_f32 %[fa], 0xc0200000, %[ra]\n\t"
+      "v_sub_f32 %[fb], 0xc0200000, %[rb]\n\t"
+      "v_mov_b32 %[pa], 0x32f16588\n\t"
+      "v_mov_b32 %[pb], 0x32f16588\n\t"
+      BF_HORNER2(pa, fa, pb, fb, 0x34b84b36) BF_HORNER2(pa, fa, pb, fb, 0xb66c7357) BF_HORNER2(pa, fa, pb, fb, 0xb6935ac1)
+      BF_HORNER2(pa, fa, pb, fb, 0x396532db) BF_HORNER2(pa, fa, pb, fb, 0xbaa45408) BF_HORNER2(pa, fa, pb, fb, 0xbb88e4ef)
+      BF_HORNER2(pa, fa, pb, fb, 0x3e7c8f63) BF_HORNER2(pa, fa, pb, fb, 0x3fc02e2f)
+      : [x0] "=&v"(x0), [x1] "=&v"(x1), [ua] "=&v"(ua), [ra] "=&v"(ra), [fa] "=&v"(fa), [ya] "=&v"(ya), [za] "=&v"(za), [pa] "=&v"(pa),
+        [ub] "=&v"(ub), [rb] "=&v"(rb), [fb] "=&v"(fb), [yb] "=&v"(yb), [zb] "=&v"(zb), [pb] "=&v"(pb)
+      : [k0] "v"(k0), [k1] "v"(k1), [k2] "v"(k2), [c0] "n"(C0), [c1] "n"(C1)
+      : "vcc");
+  const float wa = -ra, wb = -rb;
+  if (__builtin_expect(!(wa < 5.0f), 0)) pa = erfinv_tail_poly(wa);
+  if (__builtin_expect(!(wb < 5.0f), 0)) pb = erfinv_tail_poly(wb);
+  z0 = 1.41421356237309515f * (pa * ua);
+  z1 = 1.41421356237309515f * (pb * ub);
+}
+#undef BF_TFR
+#undef BF_TFA
+#undef BF_TFB
+#undef BF_TFI
+#undef BF_NRM_HEAD
+#undef BF_2
+#undef BF_HORNER2
+#endif
+
+// One Threefry block and the two standard normals its words map to, as a REAL function (never inlined) for kernels whose
+// straight-line bodies would otherwise carry dozens of copies of these ~135 instructions: one copy in the instruction cache,
+// a dozen registers inside, and the caller's register allocation sees a call instead of sixteen interleaved chains.
+struct F32x2 {
+  float x, y;
+};
+#ifdef __HIPCC__
+__device__ __attribute__((noinline)) inline F32x2 threefry_two_normals(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1) {
+  const U32x2 o = threefry2x32(k0, k1, c0, c1);
+  return F32x2{bits_to_normal(o.x), bits_to_normal(o.y)};
+}
+#endif
 
 }  // namespace bf

@@ -78,7 +78,7 @@ __device__ __forceinline__ void resample_indices(const float* wn, const bool* va
   }
   float excl_wave = 0.f;  // inclusive scan value at the end of the previous wave
   if constexpr (NW > 1) {
-    lds_barrier();
+    // (red[16 ...) was last read in the previous call, barriers ago: no barrier before the write)
     if (lane == 63) red[16 + wave] = v;
     lds_barrier();
     float r = (lane < NW) ? red[16 + lane] : 0.f;
@@ -113,7 +113,7 @@ __device__ __forceinline__ void resample_indices(const float* wn, const bool* va
     const int bs = (p / (2 * s)) * (2 * s);
     c[p] = ((bs == 0) ? E : c[bs - 1]) + tsum[p];
   }
-  lds_barrier();
+  // (the CDF's last readers -- the previous call's searches -- are barriers back: no barrier before the write)
   BF_UNROLL for (int p = 0; p < PPT; ++p) cdf[tid * PPT + p] = c[p];
   lds_barrier();
   const float total = cdf[NP - 1];
@@ -179,14 +179,71 @@ __device__ __forceinline__ float wave_tree_dpp_lane63(float v, OP op) {
   return v;
 }
 
+// x_i ~ MVN(m0, P0) with key number i + 1 of split(key, N + 1) (inference.py:1369-1373): z = normal(key_i, (n,)),
+// x = m0 + chol(P0) z, the row's fma chain with c ascending -- the arithmetic of the inlined form, in rolled loops.
+template <int N, int DQ, int M>
+__device__ __attribute__((noinline)) void draw_initial_particle(const BpfModel<N, DQ, M>* __restrict__ mdl, uint32_t k0, uint32_t k1,
+                                                                uint32_t i, uint32_t NP, float* __restrict__ out) {
+  const U32x2 ki = threefry_split(k0, k1, i + 1u, NP + 1u);
+  float z[N];
+#pragma unroll 1
+  for (int d = 0; d < N; ++d) z[d] = bits_to_normal(threefry_bits(ki.x, ki.y, (uint32_t)d, (uint32_t)N));
+#pragma unroll 1
+  for (int d = 0; d < N; ++d) {
+    float s = 0.f;
+#pragma unroll 1
+    for (int c = 0; c <= d; ++c) s = __builtin_fmaf(mdl->L0[d * N + c], z[c], s);
+    out[d] = mdl->m0[d] + s;
+  }
+}
+
+template <int J, int H, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (J < H) {
+    f(std::integral_constant<int, J>{});
+    static_for<J + 1, H>(f);
+  }
+}
+
 // NaN-propagating maximum (jnp.max semantics)
 __device__ __forceinline__ float nanmax(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); }
 
+// Every launch parameter in ONE struct: it is the kernel's only argument, so its layout IS the kernarg segment's, and the
+// time loop re-reads the fields it needs from there (scalar loads through the constant cache, at the point of use) instead
+// of holding ~75 scalar registers of pointers and strides live across a 20 000-instruction loop body -- which the register
+// allocator answered with 700+ scalar spills into vector lanes and, from there, vector spills to scratch.
+template <int N, int DQ, int M>
+struct BpfArgs {
+  CView y;
+  const float* uptr;
+  long long u_sB, u_sT;
+  BpfCarry carry;
+  BpfOut out;
+  long long B, T;
+  int NP;
+  float ess_threshold;
+  int resampler;
+  uint32_t key0, key1;
+};
+
 template <int N, int DQ, int M, int PPT, int NW, class SP = SpecRuntime>
 __global__ void __launch_bounds__(64 * NW)
-bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const float* __restrict__ uptr, long long u_sB,
-                long long u_sT, BpfCarry carry, BpfOut out, long long B, long long T, int NP, float ess_threshold,
-                int resampler, uint32_t key0, uint32_t key1) {
+bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, const BpfArgs<N, DQ, M> args_by_value) {
+  // `ka[fresh()]`: the argument struct as it lies in the kernarg segment (behind the model pointer, which stays a
+  // `__restrict__` parameter of its own: that is what lets the compiler read the model with scalar loads), behind an
+  // offset the compiler cannot see through (always 0), so that a field read inside the time loop is a fresh scalar load
+  // there and not a register held since entry
+  static_assert(alignof(BpfArgs<N, DQ, M>) == 8, "kernarg layout: the struct follows the 8-byte model pointer");
+  typedef const char __attribute__((address_space(4))) * KernargBytes;   // (the constant address space: scalar loads)
+  const BpfArgs<N, DQ, M>* const ka = (const BpfArgs<N, DQ, M>*)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + 8);
+  auto fresh = []() __attribute__((always_inline)) {
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return z;
+  };
+  (void)args_by_value;
+  const long long T = ka->T;
+  const int NP = ka->NP;
   constexpr int NT = 64 * NW;
   constexpr int CAP = NT * PPT;                 // particle slots (power of two)
   constexpr int DCH = (PPT >= 16) ? 1 : ((N >= 8) ? 8 : N);  // state dimensions gathered per LDS pass
@@ -198,17 +255,23 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* cdf = lds;                 // CAP floats
-  float* red = lds + CAP;           // 2 * 16 floats of cross-wave scratch
-  float* tile = lds + CAP + 64;     // CAP * DCH floats (gather tile; also N-vector reductions)
+  float* red = lds + CAP;           // cross-wave scratch: [0, 16) and [32, 48) the two slot groups of block_reduce, [16, 32) the CDF's wave totals
+  float* mpart = lds + CAP + 64;    // NW * N floats: per-wave partial sums of the weighted-mean summary
+  float* tile = mpart + ((NW * N + 3) & ~3);   // CAP * DCH floats (gather tile)
 
   // ---- workgroup reductions in the oracle's adjacent-pair tree order
+  // ONE barrier per reduction: the wave totals go to one of two slot groups, alternately -- a wave that runs ahead into the
+  // next reduction writes the OTHER group, and by the time a group is written again every wave has passed the barrier that
+  // followed its last reads
+  int rslot = 0;
   auto block_reduce = [&](float v, auto op) {  // v already reduced over the thread's own slots
     v = wave_tree_dpp_lane63(v, op);
     if constexpr (NW > 1) {
+      float* rs = red + 32 * rslot;
+      rslot ^= 1;
+      if (lane == 63) rs[wave] = v;
       lds_barrier();
-      if (lane == 63) red[wave] = v;
-      lds_barrier();
-      float r = (lane < NW) ? red[lane] : red[0];
+      float r = (lane < NW) ? rs[lane] : rs[0];
       BF_UNROLL for (int off = 1; off < NW; off <<= 1) r = op(r, __shfl_xor(r, off, 64));
       v = __shfl(r, 0, 64);
     } else {
@@ -223,20 +286,28 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
     return t[0];
   };
   auto fadd = [](float a, float c) { return a + c; };
+  auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+  auto uniform_u = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
 
   // ---- state
   float x[PPT][N], w[PPT];
   uint32_t k0, k1;
   bool valid[PPT];
   BF_UNROLL for (int p = 0; p < PPT; ++p) valid[p] = (tid * PPT + p) < NP;
-  if (carry.key_in) {
-    k0 = carry.key_in[b * 2];
-    k1 = carry.key_in[b * 2 + 1];
-  } else {
-    k0 = key0;
-    k1 = key1;
+  {
+    const BpfCarry carry = ka->carry;
+    if (carry.key_in) {
+      k0 = carry.key_in[b * 2];
+      k1 = carry.key_in[b * 2 + 1];
+    } else {
+      k0 = ka->key0;
+      k1 = ka->key1;
+    }
+    k0 = uniform_u(k0);
+    k1 = uniform_u(k1);
   }
-  if (carry.x_in) {
+  if (ka->carry.x_in) {
+    const BpfCarry carry = ka->carry;
     BF_UNROLL for (int p = 0; p < PPT; ++p) {
       const int i = valid[p] ? tid * PPT + p : 0;
       BF_UNROLL for (int d = 0; d < N; ++d) x[p][d] = carry.x_in[(b * NP + i) * N + d];
@@ -244,16 +315,13 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
     }
   } else {
     // inference.py:1369-1373: keys = split(key, N+1); next_key = keys[0]; x_i ~ MVN(m0, P0) with keys[1+i]
+    // (once per trajectory, in a real function with rolled loops: inlined and unrolled its N (N + 1) / 2 scalar loads of
+    // chol(P0) alone cost the whole kernel several vector registers of spilled scalars)
     BF_UNROLL for (int p = 0; p < PPT; ++p) {
       const uint32_t i = valid[p] ? (uint32_t)(tid * PPT + p) : 0u;
-      const U32x2 ki = threefry_split(k0, k1, i + 1u, (uint32_t)NP + 1u);
-      float z[N];
-      BF_UNROLL for (int d = 0; d < N; ++d) z[d] = bits_to_normal(threefry_bits(ki.x, ki.y, (uint32_t)d, (uint32_t)N));
-      BF_UNROLL for (int d = 0; d < N; ++d) {
-        float s = 0.f;
-        BF_UNROLL for (int c = 0; c <= d; ++c) s = __builtin_fmaf(mdl.L0[d * N + c], z[c], s);
-        x[p][d] = mdl.m0[d] + s;
-      }
+      float x0[N];
+      draw_initial_particle<N, DQ, M>(mdlp, k0, k1, i, (uint32_t)NP, x0);
+      BF_UNROLL for (int d = 0; d < N; ++d) x[p][d] = x0[d];
       w[p] = valid[p] ? 1.0f / (float)NP : 0.f;
     }
     const U32x2 nk = threefry_split(k0, k1, 0u, (uint32_t)NP + 1u);
@@ -261,12 +329,25 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
     k1 = nk.y;
   }
 
+#ifdef BF_BPF_PHASE_TIMERS  // debug build: per-phase wall-clock ticks (10 ns) of every wave of workgroup 0 (scripts/bpf_phase_probe.py)
+  long long tim[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = (long long)__builtin_amdgcn_s_memrealtime();
+#define BF_TICK(I_) { const long long now_ = (long long)__builtin_amdgcn_s_memrealtime(); tim[I_] += now_ - tlast; tlast = now_; }
+#else
+#define BF_TICK(I_)
+#endif
   for (long long t = 0; t < T; ++t) {
     // canonical arithmetic of the weight path (bf_canon_math.hpp): products are rounded before they enter a tree or a sum
 #pragma clang fp contract(off)
+    BF_TICK(7)
     float yv[M];
-    BF_UNROLL for (int a = 0; a < M; ++a) yv[a] = y.p[b * y.sB + t * y.sT + a * y.sE];
-    const float u0 = uptr ? uptr[b * u_sB + t * u_sT] : 0.f;
+    float u0;
+    {
+      const BpfArgs<N, DQ, M>& a_ = ka[fresh()];
+      const CView y = a_.y;
+      BF_UNROLL for (int a = 0; a < M; ++a) yv[a] = y.p[b * y.sB + t * y.sT + a * y.sE];
+      u0 = a_.uptr ? a_.uptr[b * a_.u_sB + t * a_.u_sT] : 0.f;
+    }
 
     // ---- propagate (inference.py:1342-1345, models.py:82-84) and log-weight (:1348-1349)
     const U32x2 nk = threefry_split(k0, k1, 0u, (uint32_t)NP + 1u);  // next_key = keys[0]
@@ -274,37 +355,93 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
     BF_UNROLL for (int p = 0; p < PPT; ++p) {
       const uint32_t i = valid[p] ? (uint32_t)(tid * PPT + p) : 0u;
       const U32x2 ki = threefry_split(k0, k1, i + 1u, (uint32_t)NP + 1u);
-      float q[DQ], xn[N];
+      float xn[N];
       // the model is re-read (scalar loads through the constant cache) for every particle instead of being held: hoisted
       // out of the time loop its matrices occupy several hundred scalar registers, which spill through vector lanes and
       // from there to scratch (1024 x 4 geometry: 492 -> 82 spilled VGPRs, 52 -> 42 ms at cfg4's shape, B = 1024, T = 100)
-      // (a SpecFixed instance reads a few dozen fields only: they stay in scalar registers across particles and steps)
       int zoff = 0;
-      if constexpr (!SP::fixed) asm volatile("" : "+s"(zoff));
+      asm volatile("" : "+s"(zoff));
       const BpfModel<N, DQ, M>& mdl = mdlp[zoff];
-      draw_dynamics_noise<N, DQ, M, SP>(mdl, ki, q);
-      dyn_value<N, DQ, M, SP>(mdl, x[p], q, u0, xn);
-      BF_UNROLL for (int d = 0; d < N; ++d) x[p][d] = xn[d];
-      const float llp = emission_loglik<N, DQ, M, SP>(mdl, xn, u0, yv);
+      float llp;
+      if constexpr (SP::fixed && DQ == N) {
+        if constexpr (SP::g_identity && SP::lq_diag) {
+          // identity noise input, diagonal chol(Q): the noise-free part first (the old state dies there), then every Threefry
+          // block's two normals are scaled and added as they arrive -- x' = g(x) + (q0 + L_dd z_d), the operations of
+          // draw_dynamics_noise + dyn_value one by one -- so that neither a q vector nor a z vector is ever live; the
+          // scheduling fences keep the compiler from starting all blocks at once (16 chains in flight cost ~60 VGPRs)
+          dyn_base_t<N, DQ, BpfModel<N, DQ, M>, SP>(mdl, x[p], u0, xn);
+          __builtin_amdgcn_sched_barrier(0);
+          constexpr int h = (DQ + 1) / 2;
+          if constexpr (SP::impl == 0) {
+            // the hand-scheduled block (bf_rng.hpp): Threefry + both normals in 12 registers, constants as literals
+            const uint32_t ks2 = ki.x ^ ki.y ^ 0x1BD11BDAu;
+            static_for<0, h>([&](auto jc) __attribute__((always_inline)) {
+              constexpr int j = decltype(jc)::value;
+              float za, zb;
+              threefry_two_normals_gfx950<j, (h + j < DQ) ? h + j : 0>(ki.x, ki.y, ks2, za, zb);
+              x[p][j] = xn[j] + (mdl.q0[j] + mdl.LQd[j] * za);
+              if constexpr (h + j < DQ) x[p][h + j] = xn[h + j] + (mdl.q0[h + j] + mdl.LQd[h + j] * zb);
+              // the two results are consumed HERE: the empty asm pins the new state entries to this point (without it the
+              // compiler sinks the last three operations towards their first use, past the following blocks, and keeps every
+              // block's polynomial values and u alive -- 32 registers -- until then)
+              if constexpr (h + j < DQ) asm volatile("" : "+v"(x[p][j]), "+v"(x[p][h + j]));
+              else asm volatile("" : "+v"(x[p][j]));
+            });
+          } else {
+            BF_UNROLL for (int j = 0; j < h; ++j) {
+              if constexpr (SP::impl == 1) {
+                const F32x2 z = threefry_two_normals(ki.x, ki.y, (uint32_t)j, (h + j < DQ) ? (uint32_t)(h + j) : 0u);
+                x[p][j] = xn[j] + (mdl.q0[j] + mdl.LQd[j] * z.x);
+                if (h + j < DQ) x[p][h + j] = xn[h + j] + (mdl.q0[h + j] + mdl.LQd[h + j] * z.y);
+              } else {
+                const U32x2 o = threefry2x32(ki.x, ki.y, (uint32_t)j, (h + j < DQ) ? (uint32_t)(h + j) : 0u);
+                x[p][j] = xn[j] + (mdl.q0[j] + mdl.LQd[j] * bits_to_normal(o.x));
+                if (h + j < DQ) x[p][h + j] = xn[h + j] + (mdl.q0[h + j] + mdl.LQd[h + j] * bits_to_normal(o.y));
+              }
+              constexpr int period = SP::impl == 2 ? 2 : SP::impl == 3 ? 4 : SP::impl == 4 ? 64 : 1;
+              if ((j + 1) % period == 0) __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          llp = emission_loglik<N, DQ, M, SP>(mdl, x[p], u0, yv);
+        } else {
+          float q[DQ];
+          draw_dynamics_noise<N, DQ, M, SP>(mdl, ki, q);
+          dyn_value<N, DQ, M, SP>(mdl, x[p], q, u0, xn);
+          BF_UNROLL for (int d = 0; d < N; ++d) x[p][d] = xn[d];
+          llp = emission_loglik<N, DQ, M, SP>(mdl, xn, u0, yv);
+        }
+      } else {
+        float q[DQ];
+        draw_dynamics_noise<N, DQ, M, SP>(mdl, ki, q);
+        dyn_value<N, DQ, M, SP>(mdl, x[p], q, u0, xn);
+        BF_UNROLL for (int d = 0; d < N; ++d) x[p][d] = xn[d];
+        llp = emission_loglik<N, DQ, M, SP>(mdl, xn, u0, yv);
+      }
       ll[p] = valid[p] ? llp : -__builtin_inff();
       // one particle at a time: interleaving the PPT independent Threefry / erfinv chains overruns the
       // 128-VGPR budget of the 1024-thread geometry and spills
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    BF_TICK(0)
     // ---- reweight (inference.py:1350-1353)
-    const float mx = block_reduce(thread_tree(ll, nanmax), nanmax);
+    // (workgroup-wide results are the same in every lane: telling the compiler so keeps them -- and everything computed from
+    // them and the key, the three `split`s of this step included -- in scalar registers and on the scalar unit)
+    const float mx = uniform(block_reduce(thread_tree(ll, nanmax), nanmax));
+    BF_TICK(1)
     float e[PPT];
     BF_UNROLL for (int p = 0; p < PPT; ++p) e[p] = valid[p] ? canon_exp(ll[p] - mx) * w[p] : 0.f;
-    const float tot = block_reduce(thread_tree(e, fadd), fadd);
+    const float tot = uniform(block_reduce(thread_tree(e, fadd), fadd));
+    BF_TICK(2)
     float wn[PPT], w2[PPT];
     BF_UNROLL for (int p = 0; p < PPT; ++p) {
       wn[p] = valid[p] ? e[p] / tot : 0.f;
       w2[p] = wn[p] * wn[p];
     }
-    const float ess = 1.0f / block_reduce(thread_tree(w2, fadd), fadd);
-    const bool do_resample = ess < ess_threshold * (float)NP;  // inference.py:1356 (NaN compares false)
+    const float ess = 1.0f / uniform(block_reduce(thread_tree(w2, fadd), fadd));
+    const bool do_resample = ess < ka[fresh()].ess_threshold * (float)NP;  // inference.py:1356 (NaN compares false)
 
+    BF_TICK(3)
     int anc[PPT];
     BF_UNROLL for (int p = 0; p < PPT; ++p) anc[p] = tid * PPT + p;
     if (do_resample) {
@@ -313,10 +450,11 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
       const U32x2 kn = threefry_split(nk.x, nk.y, 1u, 2u);
       // gather through LDS, DCH dimensions per pass.  The first pass is staged BEFORE the ancestors are drawn: those
       // DCH x PPT state registers are then dead while the CDF, the uniforms and the searches run.
-      // Tile layout: one record of DCH floats per particle, particle i = tid * PPT + p at record p * NT + tid -- the
-      // lanes of a wave write consecutive records (16-byte stores, every bank once per 8 lanes), and a drawn ancestor is
-      // fetched as DCH / 4 16-byte reads instead of DCH dword reads DCH banks apart.  (Dimensions that are not multiples
-      // of four keep the dimension-major dword layout.)
+      // Tile layout: DCH / 4 planes of 16-byte records, particle i = tid * PPT + p at record p * NT + tid of every plane --
+      // the lanes of a wave write consecutive 16-byte records (conflict-free; with the planes interleaved record by record
+      // the 32-byte lane stride made every store two-way conflicted), and a drawn ancestor is fetched as DCH / 4 16-byte
+      // reads instead of DCH dword reads DCH banks apart.  (Dimensions that are not multiples of four keep the
+      // dimension-major dword layout.)
       constexpr bool VEC = (DCH % 4 == 0) && (N % 4 == 0);
       typedef float f32x4 __attribute__((ext_vector_type(4)));
       auto put = [&](int d0) __attribute__((always_inline)) {
@@ -324,7 +462,7 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
           f32x4* t4 = reinterpret_cast<f32x4*>(tile);
           BF_UNROLL for (int p = 0; p < PPT; ++p) BF_UNROLL for (int v = 0; v < DCH / 4; ++v)
               if (d0 + 4 * v < N)
-                t4[(p * NT + tid) * (DCH / 4) + v] = f32x4{x[p][d0 + 4 * v], x[p][d0 + 4 * v + 1], x[p][d0 + 4 * v + 2], x[p][d0 + 4 * v + 3]};
+                t4[v * CAP + p * NT + tid] = f32x4{x[p][d0 + 4 * v], x[p][d0 + 4 * v + 1], x[p][d0 + 4 * v + 2], x[p][d0 + 4 * v + 3]};
         } else {
           BF_UNROLL for (int p = 0; p < PPT; ++p) BF_UNROLL for (int d = 0; d < DCH; ++d)
               if (d0 + d < N) tile[d * CAP + tid * PPT + p] = x[p][d0 + d];
@@ -337,7 +475,7 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
             const int rec = (anc[p] % PPT) * NT + anc[p] / PPT;
             BF_UNROLL for (int v = 0; v < DCH / 4; ++v)
                 if (d0 + 4 * v < N) {
-                  const f32x4 t = t4[rec * (DCH / 4) + v];
+                  const f32x4 t = t4[v * CAP + rec];
                   x[p][d0 + 4 * v] = t.x; x[p][d0 + 4 * v + 1] = t.y; x[p][d0 + 4 * v + 2] = t.z; x[p][d0 + 4 * v + 3] = t.w;
                 }
           }
@@ -346,9 +484,10 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
               if (d0 + d < N) x[p][d0 + d] = tile[d * CAP + anc[p]];
         }
       };
-      lds_barrier();
+      // (the tile's last readers -- the previous resampling step's second gather pass -- are at least three barriers back)
       put(0);
-      resample_indices<PPT, NW>(wn, valid, NP, kc, resampler, cdf, red, anc);  // (its barriers publish the tile)
+      resample_indices<PPT, NW>(wn, valid, NP, kc, ka[fresh()].resampler, cdf, red, anc);  // (its barriers publish the tile)
+      BF_TICK(4)
       get(0);
       BF_UNROLL for (int d0 = DCH; d0 < N; d0 += DCH) {
         lds_barrier();
@@ -365,8 +504,10 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
       k1 = nk.y;
     }
 
+    BF_TICK(5)
     // ---- emit
-    BF_UNROLL for (int p = 0; p < PPT; ++p) if (valid[p]) {
+    const BpfOut out = ka[fresh()].out;
+    if (out.w || out.anc || out.x) BF_UNROLL for (int p = 0; p < PPT; ++p) if (valid[p]) {
       const long long i = tid * PPT + p;
       if (out.w) out.w[b * out.w_sB + i * out.w_sN + t * out.w_sT] = w[p];
       if (out.anc) out.anc[b * out.w_sB + i * out.w_sN + t * out.w_sT] = anc[p];
@@ -379,12 +520,12 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
         BF_UNROLL for (int p = 0; p < PPT; ++p) s = fmaf(w[p], x[p][d], s);
         part[d] = wave_sum_dpp_lane63(s);
       }
-      lds_barrier();
-      if (lane == 63) BF_UNROLL for (int d = 0; d < N; ++d) tile[wave * N + d] = part[d];
+      // (mpart's last readers are the previous step's, the three reduction barriers back)
+      if (lane == 63) BF_UNROLL for (int d = 0; d < N; ++d) mpart[wave * N + d] = part[d];
       lds_barrier();
       if (tid < N) {
         float s = 0.f;
-        for (int wv = 0; wv < NW; ++wv) s += tile[wv * N + tid];
+        for (int wv = 0; wv < NW; ++wv) s += mpart[wv * N + tid];
         out.mean[(b * T + t) * N + tid] = s;
       }
     }
@@ -393,8 +534,17 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
       if (out.logz) out.logz[b * T + t] = mx + canon_log(tot);
       if (out.resampled) out.resampled[b * T + t] = do_resample ? 1.0f : 0.0f;
     }
+    BF_TICK(6)
   }
 
+  const BpfCarry carry = ka[fresh()].carry;
+#ifdef BF_BPF_PHASE_TIMERS
+  if (b == 0 && lane == 0 && carry.w_out) {
+    BF_UNROLL for (int i = 0; i < 8; ++i) carry.w_out[wave * 8 + i] = (float)tim[i];
+    return;
+  }
+  if (b == 0) return;
+#endif
   BF_UNROLL for (int p = 0; p < PPT; ++p) if (valid[p]) {
     const long long i = tid * PPT + p;
     if (carry.x_out) BF_UNROLL for (int d = 0; d < N; ++d) carry.x_out[(b * NP + i) * N + d] = x[p][d];
@@ -407,26 +557,33 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const floa
 }
 
 // ---------------------------------------------------------------------------------------
-template <int N, int DQ, int M, int PPT, int NW>
+template <int N, int DQ, int M, int PPT, int NW, class SP = SpecRuntime>
 static inline int launch_bpf_cfg(const BpfModel<N, DQ, M>* d_mdl, const bf_cstream* y, const bf_cstream* u, long long B,
                           long long T, int NP, float ess, int resampler, const uint32_t key[2], const BpfCarry& cr,
                           const BpfOut& out, hipStream_t stream) {
   constexpr int CAP = 64 * NW * PPT;
   constexpr int DCH = (PPT >= 16) ? 1 : ((N >= 8) ? 8 : N);
-  const size_t lds_bytes = sizeof(float) * (size_t)(CAP + 64 + CAP * DCH);
+  const size_t lds_bytes = sizeof(float) * (size_t)(CAP + 64 + ((NW * N + 3) & ~3) + CAP * DCH);
   if (lds_bytes > 160 * 1024) return set_error(BF_EUNSUPPORTED, "particle tile exceeds the 160 KiB LDS");
-  CView yv{y->ptr, y->sB, y->sT, y->sE};
-  auto kern = bpf_scan_kernel<N, DQ, M, PPT, NW>;
+  BpfArgs<N, DQ, M> a;
+  std::memset(&a, 0, sizeof(a));
+  a.y = CView{y->ptr, y->sB, y->sT, y->sE};
+  a.uptr = (u && u->ptr) ? u->ptr : nullptr;
+  a.u_sB = u ? u->sB : 0;
+  a.u_sT = u ? u->sT : 0;
+  a.carry = cr; a.out = out; a.B = B; a.T = T; a.NP = NP; a.ess_threshold = ess; a.resampler = resampler;
+  a.key0 = key[0]; a.key1 = key[1];
+  auto kern = bpf_scan_kernel<N, DQ, M, PPT, NW, SP>;
   if (lds_bytes > 64 * 1024)
     BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64 * NW), lds_bytes, stream, d_mdl, yv, (u && u->ptr) ? u->ptr : nullptr,
-                     u ? u->sB : 0, u ? u->sT : 0, cr, out, B, T, NP, ess, resampler, key[0], key[1]);
+  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64 * NW), lds_bytes, stream, d_mdl, a);
   BF_HIP_CHECK(hipGetLastError());
   return BF_OK;
 }
 
 extern std::atomic<int> g_bpf_variant;   // tuning hook (bf_set_option "bpf_variant")
 extern std::atomic<int> g_bpf_hbm_mode;  // bf_set_option "bpf_hbm_mode": 0 = choose, 1 = workgroup per trajectory, 2 = per chunk
+extern std::atomic<int> g_bpf_spec;      // bf_set_option "bpf_spec": 1 = compile-time model structure where an instance exists (default), 0 = off
 
 // bpf_big.hpp / bpf_wide.hpp: particle counts beyond the in-register capacities (declared here, defined after the kernels there)
 template <int N, int DQ, int M>
@@ -450,29 +607,41 @@ static inline int launch_bpf_dims(const bf_bpf_model* bp, const bf_cstream* y, c
   // in-register kernel takes ~19 us per 1024 particles on its one CU); the workgroup-per-chunk kernels of bpf_wide.hpp
   // spread the particles over the CUs at ~25 us of launches per step
   const bool spread = NP > 2048 && B <= 32 && g_bpf_hbm_mode != 1;
-  // smallest compiled particle capacity that holds NP
-  if (spread) rc = launch_bpf_hbm_dims<N, DQ, M>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
-  else if (NP <= 64) rc = launch_bpf_cfg<N, DQ, M, 1, 1>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
-  else if (NP <= 256) rc = launch_bpf_cfg<N, DQ, M, 1, 4>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
-  else if (NP <= 1024) rc = launch_bpf_cfg<N, DQ, M, 1, 16>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
-  else if (NP <= 4096) {
-    // two geometries for the largest capacity: 1024 threads x 4 particles (128-VGPR budget, variant 0, the default) or
-    // 512 threads x 8 particles (256-VGPR budget, variant 1).  Measured at cfg4's shape (B = 1024, T = 100, every step
-    // resamples): 1024 x 4 = 41.9 ms, 512 x 8 = 50.8 ms; without the per-particle re-read of the model (see the kernel)
-    // 52.3 / 44.4 ms -- the 128-VGPR geometry was the one that spilled.  Of the 42 ms, 29 are propagation + weights
-    // (ess_threshold = 0) and 13 the resampling branch, two thirds of it the two gather passes through the LDS tile
-    // (scripts/bpf_probe.py).  A rolled particle loop (registers rotated by one particle per trip, 16 KB of code instead
-    // of 130 KB) is slower, 44 / 78 ms: the unrolled trips overlap each other's dependent Threefry / erf_inv chains.
-    if (g_bpf_variant == 1) rc = launch_bpf_cfg<N, DQ, M, 8, 8>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
-    else rc = launch_bpf_cfg<N, DQ, M, 4, 16>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
+  if (spread) return launch_bpf_hbm_dims<N, DQ, M>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
+  // smallest compiled particle capacity that holds NP, for the model's structure as a run-time (SpecRuntime) or compile-time
+  // (SpecFixed) property
+  auto by_capacity = [&](auto spec) -> int {
+    using SP = decltype(spec);
+    if (NP <= 64) return launch_bpf_cfg<N, DQ, M, 1, 1, SP>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
+    if (NP <= 256) return launch_bpf_cfg<N, DQ, M, 1, 4, SP>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
+    if (NP <= 1024) return launch_bpf_cfg<N, DQ, M, 1, 16, SP>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
+    if (NP <= 4096) {
+      // two geometries for the largest capacity: 1024 threads x 4 particles (128-VGPR budget, variant 0, the default) or
+      // 512 threads x 8 particles (256-VGPR budget, variant 1)
+      if (g_bpf_variant == 1) return launch_bpf_cfg<N, DQ, M, 8, 8, SP>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
+      return launch_bpf_cfg<N, DQ, M, 4, 16, SP>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
+    }
+    if (NP <= 16384 && N <= 4 && DQ <= 4) {
+      // small states: 16 particles per thread still fit the registers (1024 threads x 16; the gather goes one
+      // state dimension at a time so that CDF + tile stay within the LDS)
+      if constexpr (N <= 4 && DQ <= 4) return launch_bpf_cfg<N, DQ, M, 16, 16, SP>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
+    }
+    return launch_bpf_hbm_dims<N, DQ, M>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);  // particles in HBM (bpf_big.hpp, bpf_wide.hpp)
+  };
+  // The structure BASELINE configs[3] has -- Lorenz-96 dynamics with identity noise input, diagonal chol(Q), an emission
+  // that selects the even states, diagonal chol(R) -- as a compile-time instance (bf_set_option "bpf_spec" = 0 turns it
+  // off; results are bit-identical either way: tests/test_bpf_gpu.py)
+  if constexpr (N == DQ && N >= 8 && 2 * M <= N + 1) {
+    if (g_bpf_spec != 0 && h.dyn_id == DYN_LORENZ96 && h.emi_id == EMI_LINEAR && h.g_identity && h.lq_diag && h.lr_diag && h.h_pick && NP <= 4096) {
+      if (g_bpf_spec == 2) return by_capacity(SpecFixed<DYN_LORENZ96, EMI_LINEAR, true, true, true, true, 1>{});
+      if (g_bpf_spec == 3) return by_capacity(SpecFixed<DYN_LORENZ96, EMI_LINEAR, true, true, true, true, 2>{});
+      if (g_bpf_spec == 4) return by_capacity(SpecFixed<DYN_LORENZ96, EMI_LINEAR, true, true, true, true, 3>{});
+      if (g_bpf_spec == 5) return by_capacity(SpecFixed<DYN_LORENZ96, EMI_LINEAR, true, true, true, true, 4>{});
+      if (g_bpf_spec == 6) return by_capacity(SpecFixed<DYN_LORENZ96, EMI_LINEAR, true, true, true, true, 5>{});
+      return by_capacity(SpecFixed<DYN_LORENZ96, EMI_LINEAR, true, true, true, true>{});
+    }
   }
-  else if (NP <= 16384 && N <= 4 && DQ <= 4) {
-    // small states: 16 particles per thread still fit the registers (1024 threads x 16; the gather goes one
-    // state dimension at a time so that CDF + tile stay within the LDS)
-    if constexpr (N <= 4 && DQ <= 4) rc = launch_bpf_cfg<N, DQ, M, 16, 16>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
-  }
-  else rc = launch_bpf_hbm_dims<N, DQ, M>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);  // particles in HBM (bpf_big.hpp, bpf_wide.hpp)
-  return rc;
+  return by_capacity(SpecRuntime{});
 }
 
 }  // namespace bf

@@ -21,6 +21,7 @@ struct BpfModel {
   float Hm[M * N];    // linear emission
   float q0[DQ];
   float LQ[DQ * DQ];  // chol(Q), lower
+  float LQd[DQ];      // its diagonal, contiguous (one wide scalar load when lq_diag)
   float hb[M];        // emission bias term evaluated at r_eval (H_r r_eval)
   float LR[M * M];    // chol(R_lp), lower, of the log-prob covariance
   float rdLR[M];      // 1 / diag(LR)
@@ -36,9 +37,10 @@ struct BpfModel {
 struct SpecRuntime {
   static constexpr bool fixed = false;
 };
-template <int DYN, int EMI, bool G_ID, bool LQ_DIAG, bool LR_DIAG, bool H_PICK>
+template <int DYN, int EMI, bool G_ID, bool LQ_DIAG, bool LR_DIAG, bool H_PICK, int IMPL = 0>
 struct SpecFixed {
   static constexpr bool fixed = true;
+  static constexpr int impl = IMPL;   // 0: everything inline; 1: Threefry block + its two normals as a called function
   static constexpr int dyn_id = DYN, emi_id = EMI;
   static constexpr bool g_identity = G_ID, lq_diag = LQ_DIAG, lr_diag = LR_DIAG, h_pick = H_PICK;
 };
@@ -56,10 +58,10 @@ BF_SPEC_GET(lr_diag, bool)
 BF_SPEC_GET(h_pick, bool)
 #undef BF_SPEC_GET
 
-// value of f(x, q, u) for the registry dynamics (additive noise through F_q); MDL is any model struct
-// with the fields dyn_id, dth, A, Gm, g_identity
+// noise-free part g(x, u) of the registry dynamics f(x, q, u) = g(x, u) + F_q q; MDL is any model struct with the fields
+// dyn_id, dth, A
 template <int N, int DQ, class MDL, class SP = SpecRuntime>
-__device__ __forceinline__ void dyn_value_t(const MDL& p, const float* x, const float* q, float u0, float* out) {
+__device__ __forceinline__ void dyn_base_t(const MDL& p, const float* x, float u0, float* out) {
   // canonical arithmetic (bf_canon_math.hpp): every operation rounded on its own, in the order written -- the order
   // of the test oracle's NumPy expressions -- and fused multiply-adds only where spelled out (mv)
 #pragma clang fp contract(off)
@@ -108,6 +110,13 @@ __device__ __forceinline__ void dyn_value_t(const MDL& p, const float* x, const 
       break;
     default: BF_UNROLL for (int i = 0; i < N; ++i) out[i] = x[i]; break;
   }
+}
+
+// f(x, q, u) = g(x, u) + F_q q: the noise-free part above, then the noise through F_q (identity for most registry functions)
+template <int N, int DQ, class MDL, class SP = SpecRuntime>
+__device__ __forceinline__ void dyn_value_t(const MDL& p, const float* x, const float* q, float u0, float* out) {
+#pragma clang fp contract(off)
+  dyn_base_t<N, DQ, MDL, SP>(p, x, u0, out);
   if (spec_g_identity<SP>(p)) {
     if constexpr (DQ == N) BF_UNROLL for (int i = 0; i < N; ++i) out[i] += q[i];
   } else {
@@ -330,9 +339,11 @@ static inline int fill_bpf_model(const bf_bpf_model* bp, BpfModel<N, DQ, M>& e) 
   for (int i = 0; i < DQ; ++i) e.q0[i] = p->q0 ? p->q0[i] : 0.f;
   if (cholesky_lower(p->Q, DQ, e.LQ) != 0) return set_error(BF_EINVAL, "dynamics noise covariance is not positive definite");
   e.lq_diag = 1;
-  for (int i = 0; i < DQ; ++i)
+  for (int i = 0; i < DQ; ++i) {
+    e.LQd[i] = e.LQ[i * DQ + i];
     for (int k = 0; k < i; ++k)
       if (e.LQ[i * DQ + k] != 0.f) e.lq_diag = 0;
+  }
   if (cholesky_lower(bp->lp_cov, M, e.LR) != 0) return set_error(BF_EINVAL, "log-prob covariance is not positive definite");
   e.lr_diag = 1;
   for (int i = 0; i < M; ++i)

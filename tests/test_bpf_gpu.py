@@ -433,3 +433,43 @@ def test_constant_covariance_log_prob_rejects_stochastic_volatility():
         nl.gaussian_log_prob(nl.stoch_vol(3), np.eye(3, dtype=F32))
     with pytest.raises(ValueError):
         nl.stoch_vol_log_prob(nl.linear_emission(np.eye(3, dtype=F32)), np.eye(3, dtype=F32))
+
+
+@pytest.mark.parametrize("n,N", [(8, 100), (8, 1000), (16, 4096), (16, 700)])
+def test_compile_time_model_instance_equals_the_run_time_one(n, N):
+    """The Lorenz-96 / selection-emission / diagonal-covariance structure of BASELINE configs[3] runs on an instance whose
+    model structure is a compile-time property (ssm_device.hpp: SpecFixed; bf_set_option "bpf_spec" = 1, the default) --
+    noise added as each Threefry block's normals arrive, no per-particle switch.  Same operations in the same order: every
+    weight, particle, ancestor and summary equal to the run-time instance's bits (non-zero noise bias, non-uniform diagonal
+    covariances, noise-bias evaluation point of the log-density included), one-shot and through the carry."""
+    import torch
+    bfa, nl = _bfa()
+    from bayesianfiltering_amd import _lib
+    lib = _lib.require_gpu()
+    rng = np.random.default_rng(n + N)
+    m, T, B = n // 2, 9, 3
+    Q = np.diag(rng.uniform(0.02, 0.2, size=n)).astype(F32)
+    R = np.diag(rng.uniform(0.3, 0.8, size=m)).astype(F32)
+    q0 = (0.05 * rng.normal(size=n)).astype(F32)
+    r0 = (0.05 * rng.normal(size=m)).astype(F32)
+    g = nl.pick_even(n)
+    pp = bfa.ParamsBPF(8 * np.ones(n, F32), np.eye(n, dtype=F32), nl.lorenz96(n), q0, Q, g, r0, R, nl.gaussian_log_prob(g, R, r0))
+    ys = cm.device_observations(bfa.ParamsNLSSM(*pp[:8]), (n, n, m, m), B, T, seed=n).cpu().numpy()
+    key = np.array([3, 7], np.uint32)
+    res = {}
+    for spec in (1, 0):
+        _lib.check(lib.bf_set_option(b"bpf_spec", spec))
+        try:
+            res[spec] = bfa.bootstrap_particle_filter(pp, ys, N, key, output="both", return_ancestors=True, return_carry=True)
+            h1, c1 = bfa.bootstrap_particle_filter(pp, ys[:, :4], N, key, output="both", return_carry=True)
+            h2, c2 = bfa.bootstrap_particle_filter(pp, ys[:, 4:], N, None, output="both", carry=c1, return_carry=True)
+            for k in ("weights", "particles", "mean", "ess", "logz", "resampled"):
+                tdim = 2 if k in ("weights", "particles") else 1
+                assert torch.equal(torch.cat([h1[k], h2[k]], dim=tdim), res[spec][0][k]), (spec, k)     # chunked == one-shot
+        finally:
+            _lib.check(lib.bf_set_option(b"bpf_spec", 1))
+    assert float(res[1][0]["resampled"].mean()) > 0
+    for k in res[1][0]:
+        assert torch.equal(res[1][0][k], res[0][0][k]), k
+    assert torch.equal(res[1][1].particles, res[0][1].particles) and torch.equal(res[1][1].weights, res[0][1].weights)
+    assert torch.equal(res[1][1].key, res[0][1].key)
