@@ -174,7 +174,7 @@ int bf_set_option(const char* name, int value) {
     return BF_OK;
   }
   if (name && std::strcmp(name, "bpf_spec") == 0) {
-    if (value < 0 || value > 6) return bf::set_error(BF_EINVAL, "bpf_spec must be 0 ... 6");
+    if (value < 0 || value > 1) return bf::set_error(BF_EINVAL, "bpf_spec must be 0 or 1");
     bf::g_bpf_spec = value;
     return BF_OK;
   }

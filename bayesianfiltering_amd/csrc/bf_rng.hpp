@@ -252,17 +252,4 @@ __device__ __forceinline__ void threefry_two_normals_gfx950(uint32_t k0, uint32_
 #undef BF_HORNER2
 #endif
 
-// One Threefry block and the two standard normals its words map to, as a REAL function (never inlined) for kernels whose
-// straight-line bodies would otherwise carry dozens of copies of these ~135 instructions: one copy in the instruction cache,
-// a dozen registers inside, and the caller's register allocation sees a call instead of sixteen interleaved chains.
-struct F32x2 {
-  float x, y;
-};
-#ifdef __HIPCC__
-__device__ __attribute__((noinline)) inline F32x2 threefry_two_normals(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1) {
-  const U32x2 o = threefry2x32(k0, k1, c0, c1);
-  return F32x2{bits_to_normal(o.x), bits_to_normal(o.y)};
-}
-#endif
-
 }  // namespace bf

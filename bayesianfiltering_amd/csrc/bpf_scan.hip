@@ -13,7 +13,7 @@ template <int PPT, int NW>
 __global__ void __launch_bounds__(64 * NW)
 resample_kernel(const float* __restrict__ w, const uint32_t* __restrict__ keys, int NP, int resampler, int* __restrict__ idx) {
   constexpr int CAP = 64 * NW * PPT;
-  __shared__ float cdf[CAP];
+  __shared__ float cdf[cdf_words(CAP)];
   __shared__ float red[64];
   const int tid = threadIdx.x;
   const long long b = blockIdx.x;

@@ -61,6 +61,12 @@ struct BpfOut {
 // with the CDF in lax.associative_scan order (== Brent-Kung: thread tree, wave up-sweep,
 // cross-wave scan, down-sweeps) so that it matches the test oracle (cumsum_assoc) bit for bit.
 // resampler 1 = systematic positions (i + u0) / N instead of N independent uniforms.
+// CDF entry i lives at LDS word i + (i >> 6): the bisection's first levels probe entries a power of two apart -- in a plain
+// array those are different addresses of ONE bank (levels 1 ... 5: 2- to 32-way conflicts on every probe); the skew of one
+// word per 64 spreads them over the banks.
+__device__ __forceinline__ int cdf_at(int i) { return i + (i >> 6); }
+__host__ __device__ constexpr int cdf_words(int cap) { return cap + (cap >> 6); }
+
 template <int PPT, int NW>
 __device__ __forceinline__ void resample_indices(const float* wn, const bool* valid, int NP, U32x2 kc, int resampler,
                                                  float* cdf, float* red, int* anc) {
@@ -114,9 +120,9 @@ __device__ __forceinline__ void resample_indices(const float* wn, const bool* va
     c[p] = ((bs == 0) ? E : c[bs - 1]) + tsum[p];
   }
   // (the CDF's last readers -- the previous call's searches -- are barriers back: no barrier before the write)
-  BF_UNROLL for (int p = 0; p < PPT; ++p) cdf[tid * PPT + p] = c[p];
+  BF_UNROLL for (int p = 0; p < PPT; ++p) cdf[cdf_at(tid * PPT + p)] = c[p];
   lds_barrier();
-  const float total = cdf[NP - 1];
+  const float total = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cdf[cdf_at(NP - 1)])));
   float u_sys = 0.f;
   if (resampler == 1) u_sys = bits_to_unit(threefry_bits(kc.x, kc.y, 0u, 1u));
   float r[PPT];
@@ -134,7 +140,7 @@ __device__ __forceinline__ void resample_indices(const float* wn, const bool* va
   BF_UNROLL for (int p = 0; p < PPT; ++p) pos[p] = 0;
   for (int step = CAP >> 1; step >= 1; step >>= 1) {
     float probe[PPT];
-    BF_UNROLL for (int p = 0; p < PPT; ++p) probe[p] = cdf[pos[p] + step - 1];
+    BF_UNROLL for (int p = 0; p < PPT; ++p) probe[p] = cdf[cdf_at(pos[p] + step - 1)];
     BF_UNROLL for (int p = 0; p < PPT; ++p) pos[p] += (probe[p] < r[p]) ? step : 0;
   }
   BF_UNROLL for (int p = 0; p < PPT; ++p) anc[p] = pos[p] < NP - 1 ? pos[p] : NP - 1;
@@ -197,6 +203,22 @@ __device__ __attribute__((noinline)) void draw_initial_particle(const BpfModel<N
   }
 }
 
+// The xor-butterfly (adjacent-pair tree) over the first NWV <= 16 lanes of a row, result in every one of them, on the vector
+// ALU: partners at distance 1, 2 by quad permutes, 4, 8 by the two row mirrors (every lane of a finished group holds the
+// group's value, so any lane of the neighbouring group serves).  op is commutative: the bits of the butterfly.
+template <int NWV, class OP>
+__device__ __forceinline__ float row_tree_dpp(float v, OP op) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x),
+                                                                 decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  if constexpr (NWV > 1) v = op(v, dpp(v, std::integral_constant<int, 0xB1>{}));   // quad_perm [1, 0, 3, 2]
+  if constexpr (NWV > 2) v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}));   // quad_perm [2, 3, 0, 1]
+  if constexpr (NWV > 4) v = op(v, dpp(v, std::integral_constant<int, 0x141>{}));  // row_half_mirror
+  if constexpr (NWV > 8) v = op(v, dpp(v, std::integral_constant<int, 0x140>{}));  // row_mirror
+  return v;
+}
+
 template <int J, int H, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (J < H) {
@@ -254,12 +276,15 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, const BpfArgs<N, DQ
   const long long b = blockIdx.x;
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* cdf = lds;                 // CAP floats
-  float* red = lds + CAP;           // cross-wave scratch: [0, 16) and [32, 48) the two slot groups of block_reduce, [16, 32) the CDF's wave totals
-  float* mpart = lds + CAP + 64;    // NW * N floats: per-wave partial sums of the weighted-mean summary
+  constexpr int CW = (cdf_words(CAP) + 3) & ~3;
+  float* cdf = lds;                 // CAP floats, skewed (cdf_at)
+  float* red = lds + CW;            // cross-wave scratch: [0, 16) and [32, 48) the two slot groups of block_reduce, [16, 32) the CDF's wave totals
+  float* mpart = lds + CW + 64;     // NW * N floats: per-wave partial sums of the weighted-mean summary
   float* tile = mpart + ((NW * N + 3) & ~3);   // CAP * DCH floats (gather tile)
 
   // ---- workgroup reductions in the oracle's adjacent-pair tree order
+  auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+  auto uniform_u = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
   // ONE barrier per reduction: the wave totals go to one of two slot groups, alternately -- a wave that runs ahead into the
   // next reduction writes the OTHER group, and by the time a group is written again every wave has passed the barrier that
   // followed its last reads
@@ -272,12 +297,11 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, const BpfArgs<N, DQ
       if (lane == 63) rs[wave] = v;
       lds_barrier();
       float r = (lane < NW) ? rs[lane] : rs[0];
-      BF_UNROLL for (int off = 1; off < NW; off <<= 1) r = op(r, __shfl_xor(r, off, 64));
-      v = __shfl(r, 0, 64);
+      v = uniform(row_tree_dpp<NW>(r, op));   // the xor-butterfly over the NW wave totals, on the vector ALU; lane 0's copy
     } else {
-      v = __shfl(v, 63, 64);
+      v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
     }
-    return v;
+    return v;   // the same value in every lane, and known to the compiler as such (a scalar register)
   };
   auto thread_tree = [&](const float* e, auto op) {  // adjacent-pair tree over the PPT own slots
     float t[PPT];
@@ -286,8 +310,6 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, const BpfArgs<N, DQ
     return t[0];
   };
   auto fadd = [](float a, float c) { return a + c; };
-  auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
-  auto uniform_u = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
 
   // ---- state
   float x[PPT][N], w[PPT];
@@ -387,19 +409,12 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, const BpfArgs<N, DQ
               if constexpr (h + j < DQ) asm volatile("" : "+v"(x[p][j]), "+v"(x[p][h + j]));
               else asm volatile("" : "+v"(x[p][j]));
             });
-          } else {
+          } else {   // the same in plain C++ (kept for reference builds: SpecFixed<..., 1>)
             BF_UNROLL for (int j = 0; j < h; ++j) {
-              if constexpr (SP::impl == 1) {
-                const F32x2 z = threefry_two_normals(ki.x, ki.y, (uint32_t)j, (h + j < DQ) ? (uint32_t)(h + j) : 0u);
-                x[p][j] = xn[j] + (mdl.q0[j] + mdl.LQd[j] * z.x);
-                if (h + j < DQ) x[p][h + j] = xn[h + j] + (mdl.q0[h + j] + mdl.LQd[h + j] * z.y);
-              } else {
-                const U32x2 o = threefry2x32(ki.x, ki.y, (uint32_t)j, (h + j < DQ) ? (uint32_t)(h + j) : 0u);
-                x[p][j] = xn[j] + (mdl.q0[j] + mdl.LQd[j] * bits_to_normal(o.x));
-                if (h + j < DQ) x[p][h + j] = xn[h + j] + (mdl.q0[h + j] + mdl.LQd[h + j] * bits_to_normal(o.y));
-              }
-              constexpr int period = SP::impl == 2 ? 2 : SP::impl == 3 ? 4 : SP::impl == 4 ? 64 : 1;
-              if ((j + 1) % period == 0) __builtin_amdgcn_sched_barrier(0);
+              const U32x2 o = threefry2x32(ki.x, ki.y, (uint32_t)j, (h + j < DQ) ? (uint32_t)(h + j) : 0u);
+              x[p][j] = xn[j] + (mdl.q0[j] + mdl.LQd[j] * bits_to_normal(o.x));
+              if (h + j < DQ) x[p][h + j] = xn[h + j] + (mdl.q0[h + j] + mdl.LQd[h + j] * bits_to_normal(o.y));
+              __builtin_amdgcn_sched_barrier(0);
             }
           }
           llp = emission_loglik<N, DQ, M, SP>(mdl, x[p], u0, yv);
@@ -427,18 +442,18 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, const BpfArgs<N, DQ
     // ---- reweight (inference.py:1350-1353)
     // (workgroup-wide results are the same in every lane: telling the compiler so keeps them -- and everything computed from
     // them and the key, the three `split`s of this step included -- in scalar registers and on the scalar unit)
-    const float mx = uniform(block_reduce(thread_tree(ll, nanmax), nanmax));
+    const float mx = block_reduce(thread_tree(ll, nanmax), nanmax);
     BF_TICK(1)
     float e[PPT];
     BF_UNROLL for (int p = 0; p < PPT; ++p) e[p] = valid[p] ? canon_exp(ll[p] - mx) * w[p] : 0.f;
-    const float tot = uniform(block_reduce(thread_tree(e, fadd), fadd));
+    const float tot = block_reduce(thread_tree(e, fadd), fadd);
     BF_TICK(2)
     float wn[PPT], w2[PPT];
     BF_UNROLL for (int p = 0; p < PPT; ++p) {
       wn[p] = valid[p] ? e[p] / tot : 0.f;
       w2[p] = wn[p] * wn[p];
     }
-    const float ess = 1.0f / uniform(block_reduce(thread_tree(w2, fadd), fadd));
+    const float ess = 1.0f / block_reduce(thread_tree(w2, fadd), fadd);
     const bool do_resample = ess < ka[fresh()].ess_threshold * (float)NP;  // inference.py:1356 (NaN compares false)
 
     BF_TICK(3)
@@ -563,7 +578,7 @@ static inline int launch_bpf_cfg(const BpfModel<N, DQ, M>* d_mdl, const bf_cstre
                           const BpfOut& out, hipStream_t stream) {
   constexpr int CAP = 64 * NW * PPT;
   constexpr int DCH = (PPT >= 16) ? 1 : ((N >= 8) ? 8 : N);
-  const size_t lds_bytes = sizeof(float) * (size_t)(CAP + 64 + ((NW * N + 3) & ~3) + CAP * DCH);
+  const size_t lds_bytes = sizeof(float) * (size_t)(((cdf_words(CAP) + 3) & ~3) + 64 + ((NW * N + 3) & ~3) + CAP * DCH);
   if (lds_bytes > 160 * 1024) return set_error(BF_EUNSUPPORTED, "particle tile exceeds the 160 KiB LDS");
   BpfArgs<N, DQ, M> a;
   std::memset(&a, 0, sizeof(a));
@@ -633,11 +648,6 @@ static inline int launch_bpf_dims(const bf_bpf_model* bp, const bf_cstream* y, c
   // off; results are bit-identical either way: tests/test_bpf_gpu.py)
   if constexpr (N == DQ && N >= 8 && 2 * M <= N + 1) {
     if (g_bpf_spec != 0 && h.dyn_id == DYN_LORENZ96 && h.emi_id == EMI_LINEAR && h.g_identity && h.lq_diag && h.lr_diag && h.h_pick && NP <= 4096) {
-      if (g_bpf_spec == 2) return by_capacity(SpecFixed<DYN_LORENZ96, EMI_LINEAR, true, true, true, true, 1>{});
-      if (g_bpf_spec == 3) return by_capacity(SpecFixed<DYN_LORENZ96, EMI_LINEAR, true, true, true, true, 2>{});
-      if (g_bpf_spec == 4) return by_capacity(SpecFixed<DYN_LORENZ96, EMI_LINEAR, true, true, true, true, 3>{});
-      if (g_bpf_spec == 5) return by_capacity(SpecFixed<DYN_LORENZ96, EMI_LINEAR, true, true, true, true, 4>{});
-      if (g_bpf_spec == 6) return by_capacity(SpecFixed<DYN_LORENZ96, EMI_LINEAR, true, true, true, true, 5>{});
       return by_capacity(SpecFixed<DYN_LORENZ96, EMI_LINEAR, true, true, true, true>{});
     }
   }

@@ -3,6 +3,7 @@
 // emission log-density need, and the host code that fills them from the C-ABI structs.
 #pragma once
 #include <cstring>
+#include <type_traits>
 #include "bf_common.hpp"
 #include "bf_rng.hpp"
 #include "kf_math.hpp"
@@ -40,7 +41,7 @@ struct SpecRuntime {
 template <int DYN, int EMI, bool G_ID, bool LQ_DIAG, bool LR_DIAG, bool H_PICK, int IMPL = 0>
 struct SpecFixed {
   static constexpr bool fixed = true;
-  static constexpr int impl = IMPL;   // 0: everything inline; 1: Threefry block + its two normals as a called function
+  static constexpr int impl = IMPL;   // 0: Threefry + normals as the hand-scheduled block of bf_rng.hpp; 1: plain C++
   static constexpr int dyn_id = DYN, emi_id = EMI;
   static constexpr bool g_identity = G_ID, lq_diag = LQ_DIAG, lr_diag = LR_DIAG, h_pick = H_PICK;
 };
@@ -187,6 +188,14 @@ __device__ __forceinline__ void emi_value(const BpfModel<N, DQ, M>& p, const flo
   BF_UNROLL for (int a = 0; a < M; ++a) hx[a] += p.hb[a];
 }
 
+template <int J, int H, class F>
+__device__ __forceinline__ void ssm_static_for(F&& f) {
+  if constexpr (J < H) {
+    f(std::integral_constant<int, J>{});
+    ssm_static_for<J + 1, H>(f);
+  }
+}
+
 // q = q0 + chol(Q) normal(key_i, (dq,)) (gaussfiltax/models.py:82-83): accumulated column by column as the normals
 // arrive (per entry the same fma chain as the row-wise product, c ascending from 0), so no z vector stays live.
 // normal(key, (dq,)): Threefry block j yields entries j and h + j.
@@ -196,13 +205,16 @@ __device__ __forceinline__ void draw_dynamics_noise(const BpfModel<N, DQ, M>& md
   const bool lq_diag = spec_lq_diag<SP>(mdl);
   float zhi[h];
   BF_UNROLL for (int d = 0; d < DQ; ++d) q[d] = 0.f;
-  BF_UNROLL for (int j = 0; j < h; ++j) {
-    const U32x2 o = threefry2x32(ki.x, ki.y, (uint32_t)j, (h + j < DQ) ? (uint32_t)(h + j) : 0u);
-    const float zj = bits_to_normal(o.x);
-    zhi[j] = (h + j < DQ) ? bits_to_normal(o.y) : 0.f;
+  const uint32_t ks2 = ki.x ^ ki.y ^ 0x1BD11BDAu;
+  ssm_static_for<0, h>([&](auto jc) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value;
+    // the hand-scheduled block of bf_rng.hpp: threefry2x32(ki, j, h + j) and bits_to_normal of both words, same bits
+    float zj, zh;
+    threefry_two_normals_gfx950<j, (h + j < DQ) ? h + j : 0>(ki.x, ki.y, ks2, zj, zh);
+    zhi[j] = (h + j < DQ) ? zh : 0.f;
     if (lq_diag) q[j] = mdl.LQ[j * DQ + j] * zj;
     else BF_UNROLL for (int d = j; d < DQ; ++d) q[d] = __builtin_fmaf(mdl.LQ[d * DQ + j], zj, q[d]);
-  }
+  });
   BF_UNROLL for (int j = 0; h + j < DQ; ++j) {
     if (lq_diag) q[h + j] = mdl.LQ[(h + j) * DQ + h + j] * zhi[j];
     else BF_UNROLL for (int d = h + j; d < DQ; ++d) q[d] = __builtin_fmaf(mdl.LQ[d * DQ + h + j], zhi[j], q[d]);

@@ -274,7 +274,7 @@ def make_bpf4096(args, rank, world, device):
     def finite():
         return float(torch.isfinite(st["out"]["mean"]).all(dim=(1, 2)).float().mean())
 
-    prof, src = profiled("r02_pmc_bpf4096.json")
+    prof, src = profiled("r03_pmc_bpf4096.json")
     ipp = (prof or {}).get("valu_wave_inst_per_particle_step_x64")   # SQ_INSTS_VALU per launch / particle-steps per launch x 64 lanes
     bps = 4 * m + 4 * (n + 3)
 
@@ -282,11 +282,15 @@ def make_bpf4096(args, rank, world, device):
         r = {"bound": "valu", "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
              "kernel": "bpf_scan_kernel<16,16,8,PPT=4,NW=16>", "bytes_per_step": bps, "particle_steps_per_s": N * B * T / (ms * 1e-3),
              "note": "integer / fp32 VALU work (Threefry, canonical erf_inv / exp), no matrix products and ~100 B of HBM per step: the "
-                     "bound is VALU issue, 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction"}
+                     "bound is VALU issue, 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (the guide's figure).  Measured on "
+                     "this part (profiles/r03_valu_issue_probe.txt, four waves per SIMD): 2.5 cycles for v_add_u32 / v_xor_b32, 2.7-2.9 for "
+                     "v_fma_f32 / v_fmaak_f32, 4.3 for v_alignbit_b32 / v_add3_u32 (a Threefry round = 9.3 cycles, not 6): the kernel's "
+                     "instruction mix averages ~2.9 cycles per instruction -- frac_issue_cost_weighted prices the same count at that"}
         if ipp:
             r["achieved"] = ipp / 64.0 * N * B * T / (ms * 1e-3) / 1e9
             r["valu_inst_per_particle_step"] = ipp
             r["valu_inst_source"] = src
+            r["frac_issue_cost_weighted"] = r["achieved"] / (256 * 4 * 2.4 / 2.9)
         else:
             r["achieved"] = None
         return r

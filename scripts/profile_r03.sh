@@ -1,0 +1,60 @@
+#!/bin/bash
+# Round-3 evidence runs on the GPU box (via gpurun).  usage: scripts/profile_r03.sh what...   (what = bpfpmc bpfstats headline others kalman64pmc ...)
+# Small summaries land in gpurun_out/prof_r03/ and are copied into profiles/ by hand.
+root=${GRAFT_REPO_ROOT:-/root/repo}
+out=$root/gpurun_out/prof_r03
+mkdir -p $out
+what="$*"
+cd /tmp && export TMPDIR=/tmp
+
+stats() {  # stats <dir> <dest csv>: the heaviest kernels of a kernel-trace run
+  f=$(find $1 -name "*kernel_stats.csv" | head -1)
+  python3 - "$f" "$2" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+with open(sys.argv[2], "w") as g:
+    w = csv.DictWriter(g, fieldnames=rows[0].keys()); w.writeheader()
+    for r in rows[:8]: w.writerow(r)
+for r in rows[:4]: print("   ", r["Name"][:110], r["Calls"], r["AverageNs"], r["Percentage"])
+PY
+}
+
+pmc() {  # pmc <tag> <kernel substring> <json dest> <extra json> -- <program args...>: separate passes of a few counters each
+  tag=$1; kern=$2; dest=$3; extra=$4; shift 5
+  i=0
+  for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" \
+             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" \
+             "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_IFETCH" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES"; do
+    i=$((i+1))
+    rocprofv3 --pmc $set --output-format csv -d $out/pmc_${tag}_$i -- "$@" > $out/pmc_${tag}_$i.log 2>&1 || echo "pass $i failed (see $out/pmc_${tag}_$i.log)"
+  done
+  python3 - "$out" "$tag" "$kern" "$dest" "$extra" <<'PY'
+import csv, glob, json, collections, sys
+out, tag, kern, dest, extra = sys.argv[1:6]
+summary = {"tag": tag, "kernel": kern, "pmc": {}}
+summary.update(json.loads(extra) if extra else {})
+for f in glob.glob(out + "/pmc_%s_*/**/*counter_collection.csv" % tag, recursive=True):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if kern in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        summary["pmc"][k] = {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)}
+json.dump(summary, open(dest, "w"), indent=1)
+print(json.dumps({k: v["mean_per_dispatch"] for k, v in summary["pmc"].items()}))
+PY
+  rm -rf $out/pmc_${tag}_[0-9]*
+}
+
+if [[ $what == *bpfpmc* ]]; then
+  echo "== particle filter PMC (scripts/bpf_probe3.py, B=1024 T=100)"
+  export PB=1024 PT=100 PREP=1 PSETS="spec=1"
+  pmc bpf bpf_scan_kernel $out/pmc_bpf4096.json '{"script": "scripts/bpf_probe3.py PB=1024 PT=100 PSETS=spec=1", "particle_steps_per_dispatch": 419430400}' -- python3 $root/scripts/bpf_probe3.py
+fi
+if [[ $what == *bpfstats* ]]; then
+  echo "== bpf4096 bench under kernel trace"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/t_bpf -- python3 $root/bench.py --config bpf4096 --steps 2 --warmup 1 > $out/bpf4096.log 2>&1
+  grep -h '"metric"' $out/bpf4096.log > $out/bpf4096_bench_line.json; cut -c1-300 $out/bpf4096_bench_line.json
+  stats $out/t_bpf $out/bpf4096_kernel_stats.csv; rm -rf $out/t_bpf
+fi
