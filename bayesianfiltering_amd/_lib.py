@@ -86,6 +86,7 @@ SYMBOLS = {
     "bf_last_error": (C.c_char_p, []),
     "bf_device_count": (C.c_int, []),
     "bf_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "bf_set_call_option": (C.c_int, [C.c_char_p, C.c_int]),
     "bf_bytes_per_step": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(bf_out_desc)]),
     "bf_gsf_ekf_f32": (C.c_int, [C.POINTER(bf_model), C.POINTER(bf_cstream), C.POINTER(bf_cstream), C.c_int64, C.c_int64,
                                  C.c_int32, C.POINTER(bf_carry), C.POINTER(bf_out_desc), C.c_void_p]),
@@ -156,3 +157,11 @@ def require_gpu():
     if lib.bf_device_count() < 1:
         raise BayesFiltError(BF_ENOGPU, "no gfx950 (MI355X) device visible; the filters only run on the HIP path")
     return lib
+
+
+def arm_call_options(lib, options):
+    """Per-call overrides of the tuning options (bf_set_call_option): ``options`` is a dict name -> int; they apply to the
+    next filter entry point called on this thread and to that call only."""
+    if options:
+        for k, v in options.items():
+            check(lib.bf_set_call_option(k.encode() if isinstance(k, str) else k, int(v)))

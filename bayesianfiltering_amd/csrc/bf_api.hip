@@ -53,14 +53,19 @@ int launch_sample_ssm(const bf_bpf_model* bp, const uint32_t* d_keys, const bf_c
 int launch_resample(const float* d_w, const uint32_t* d_keys, long long B, int NP, int resampler, int* d_idx,
                     hipStream_t stream);
 
-// process-wide tuning options: atomics, each read once at the top of a call (a launch never sees a torn mix)
-extern std::atomic<int> g_bpf_variant;
-extern std::atomic<int> g_bpf_hbm_mode;
-extern std::atomic<int> g_bpf_spec;
-extern std::atomic<int> g_gsf_structured;
-extern std::atomic<int> g_kf_mfma_variant;
-static std::atomic<int> g_kf_emit_mode{-1};  // -1 = choose from the layout
-static std::atomic<int> g_kf_lanes{0};       // 0 = default lanes per trajectory for the (n, m) pair
+CallOverrides& call_overrides() {
+  static thread_local CallOverrides c = {};
+  return c;
+}
+
+// tuning options: process-wide defaults (atomics) with per-call overrides (bf_common.hpp: Option)
+extern Option g_bpf_variant;
+extern Option g_bpf_hbm_mode;
+extern Option g_bpf_spec;
+extern Option g_gsf_structured;
+extern Option g_kf_mfma_variant;
+static Option g_kf_emit_mode{-1, OPT_KF_EMIT_MODE};  // -1 = choose from the layout
+static Option g_kf_lanes{0, OPT_KF_LANES};       // 0 = default lanes per trajectory for the (n, m) pair
 // op 0 log, 1 exp, 2 bits -> normal, 3 sin, 4 cos, 5 atan2(in[i], in[n + i])
 __host__ __device__ inline float canon_eval_one(int op, const float* in, long long n, long long i) {
   const float x = in[i];
@@ -80,8 +85,8 @@ __global__ void canon_eval_kernel(int op, const float* __restrict__ in, long lon
   out[i] = canon_eval_one(op, in, n, i);
 }
 
-static std::atomic<int> g_kf_small_mode{1};   // bf_set_option "kf_small_mode": 1 = one-wave matrix-core kernel for 9 <= n <= 32 (default), 0 = off
-static std::atomic<int> g_force_generic{0};  // 1 = run the run-time-dimension kernel even where a compiled instance exists
+static Option g_kf_small_mode{1, OPT_KF_SMALL_MODE};   // bf_set_option "kf_small_mode": 1 = one-wave matrix-core kernel for 9 <= n <= 32 (default), 0 = off
+static Option g_force_generic{0, OPT_FORCE_GENERIC};  // 1 = run the run-time-dimension kernel even where a compiled instance exists
 
 // A shape / option the compiled instances do not cover falls through to the run-time-dimension kernel
 // (generic_scan.hip); if that cannot run it either, both reasons are reported.
@@ -132,54 +137,59 @@ int bf_device_count(void) {
   return ok;
 }
 
-int bf_set_option(const char* name, int value) {
+static int set_option_impl(const char* name, int value, bool this_call_only) {
+  auto assign = [&](bf::Option& o) {
+    if (this_call_only) {
+      bf::CallOverrides& c = bf::call_overrides();
+      c.value[o.id] = value;
+      c.armed[o.id] = true;
+    } else {
+      o = value;
+    }
+    return BF_OK;
+  };
   if (name && std::strcmp(name, "kf_emit_mode") == 0) {
     if (value < -1 || value > 2) return bf::set_error(BF_EINVAL, "kf_emit_mode must be -1..2");
-    bf::g_kf_emit_mode = value;
-    return BF_OK;
+    return assign(bf::g_kf_emit_mode);
   }
   if (name && std::strcmp(name, "kf_lanes") == 0) {
     if (value < 0 || value > 64 || (value & (value - 1)) != 0) return bf::set_error(BF_EINVAL, "kf_lanes must be 0 or a power of two <= 64");
-    bf::g_kf_lanes = value;
-    return BF_OK;
+    return assign(bf::g_kf_lanes);
   }
   if (name && std::strcmp(name, "kf_mfma_variant") == 0) {
     if (value < 1 || value > 5) return bf::set_error(BF_EINVAL, "kf_mfma_variant must be 1 ... 5");
-    bf::g_kf_mfma_variant = value;
-    return BF_OK;
+    return assign(bf::g_kf_mfma_variant);
   }
   if (name && std::strcmp(name, "kf_small_mode") == 0) {
     if (value < 0 || value > 1) return bf::set_error(BF_EINVAL, "kf_small_mode must be 0 or 1");
-    bf::g_kf_small_mode = value;
-    return BF_OK;
+    return assign(bf::g_kf_small_mode);
   }
   if (name && std::strcmp(name, "force_generic") == 0) {
     if (value < 0 || value > 1) return bf::set_error(BF_EINVAL, "force_generic must be 0 or 1");
-    bf::g_force_generic = value;
-    return BF_OK;
+    return assign(bf::g_force_generic);
   }
   if (name && std::strcmp(name, "gsf_structured") == 0) {
     if (value < 0 || value > 1) return bf::set_error(BF_EINVAL, "gsf_structured must be 0 or 1");
-    bf::g_gsf_structured = value;
-    return BF_OK;
+    return assign(bf::g_gsf_structured);
   }
   if (name && std::strcmp(name, "bpf_variant") == 0) {
     if (value < 0 || value > 1) return bf::set_error(BF_EINVAL, "bpf_variant must be 0 or 1");
-    bf::g_bpf_variant = value;
-    return BF_OK;
+    return assign(bf::g_bpf_variant);
   }
   if (name && std::strcmp(name, "bpf_hbm_mode") == 0) {
     if (value < 0 || value > 2) return bf::set_error(BF_EINVAL, "bpf_hbm_mode must be 0, 1 or 2");
-    bf::g_bpf_hbm_mode = value;
-    return BF_OK;
+    return assign(bf::g_bpf_hbm_mode);
   }
   if (name && std::strcmp(name, "bpf_spec") == 0) {
     if (value < 0 || value > 1) return bf::set_error(BF_EINVAL, "bpf_spec must be 0 or 1");
-    bf::g_bpf_spec = value;
-    return BF_OK;
+    return assign(bf::g_bpf_spec);
   }
   return bf::set_error(BF_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
+
+int bf_set_option(const char* name, int value) { return set_option_impl(name, value, false); }
+
+int bf_set_call_option(const char* name, int value) { return set_option_impl(name, value, true); }
 
 int64_t bf_bytes_per_step(int32_t n, int32_t m, int32_t K, const bf_out_desc* out) {
   int64_t per = 0;
@@ -201,6 +211,7 @@ int64_t bf_bytes_per_step(int32_t n, int32_t m, int32_t K, const bf_out_desc* ou
 
 int bf_kalman_filter_f32(const bf_lgssm* model, const bf_cstream* y, int64_t B, int64_t T, const bf_carry* carry,
                          const bf_out_desc* out, void* stream) {
+  bf::CallOptionScope call_option_scope;
   if (out && (out->coll_mean.ptr || out->coll_cov.ptr))
     return bf::set_error(BF_EINVAL, "collapsed streams are produced by bf_gsf_ekf_f32 (with one component they equal means / covs)");
   if (!model || !y || !carry || !out) return bf::set_error(BF_EINVAL, "NULL argument");
@@ -230,6 +241,7 @@ int bf_kalman_filter_f32(const bf_lgssm* model, const bf_cstream* y, int64_t B, 
 
 int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream* u, int64_t B, int64_t T, int32_t K,
                    const bf_carry* carry, const bf_out_desc* out, void* stream) {
+  bf::CallOptionScope call_option_scope;
   if (!model || !y || !carry || !out) return bf::set_error(BF_EINVAL, "NULL argument");
   if (B <= 0 || T <= 0 || K <= 0) return bf::set_error(BF_EINVAL, "B, T and K must be positive");
   if (model->n <= 0 || model->m <= 0 || model->dq <= 0 || model->dr <= 0)
@@ -247,6 +259,7 @@ int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream*
 
 int bf_ugsf_ukf_f32(const bf_model* model, const bf_ukf_params* uparams, const bf_cstream* y, const bf_cstream* u,
                     int64_t B, int64_t T, int32_t K, const bf_carry* carry, const bf_out_desc* out, void* stream) {
+  bf::CallOptionScope call_option_scope;
   if (!model || !uparams || !y || !carry || !out) return bf::set_error(BF_EINVAL, "NULL argument");
   if (B <= 0 || T <= 0 || K <= 0) return bf::set_error(BF_EINVAL, "B, T and K must be positive");
   if (model->n <= 0 || model->m <= 0 || model->dq <= 0 || model->dr <= 0)
@@ -261,6 +274,7 @@ int bf_ugsf_ukf_f32(const bf_model* model, const bf_ukf_params* uparams, const b
 int bf_agsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream* u, int64_t B, int64_t T,
                     const int32_t num_components[3], const uint32_t key[2], const float opt_args[2], const bf_carry* carry,
                     const bf_out_desc* out, int32_t* leaf_idx, int32_t variant, void* stream) {
+  bf::CallOptionScope call_option_scope;
   if (variant < 0 || variant > 2)
     return bf::set_error(BF_EINVAL, "variant must be 0 (speedy), 1 (container branches) or 2 (container branches + optimal resampling)");
   if (!model || !y || !carry || !out || !num_components || !key || !opt_args) return bf::set_error(BF_EINVAL, "NULL argument");
@@ -280,6 +294,7 @@ int bf_agsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream
 int bf_agsf_ukf_f32(const bf_model* model, const bf_ukf_params* uparams, const bf_cstream* y, const bf_cstream* u, int64_t B,
                     int64_t T, const int32_t num_components[3], const uint32_t key[2], const float opt_args[2],
                     const bf_carry* carry, const bf_out_desc* out, int32_t* leaf_idx, int32_t variant, void* stream) {
+  bf::CallOptionScope call_option_scope;
   if (variant != 0 && variant != 1) return bf::set_error(BF_EINVAL, "variant must be 0 (speedy) or 1 (container branches)");
   if (!model || !uparams || !y || !carry || !out || !num_components || !key || !opt_args) return bf::set_error(BF_EINVAL, "NULL argument");
   if (B <= 0 || T <= 0) return bf::set_error(BF_EINVAL, "B and T must be positive");
@@ -297,6 +312,7 @@ int bf_agsf_ukf_f32(const bf_model* model, const bf_ukf_params* uparams, const b
 
 int bf_optimal_resample_f32(const float* d_weights, const uint32_t key[2], int64_t B, int32_t M, int32_t N, int32_t* d_idx,
                             float* d_weights_out, void* stream) {
+  bf::CallOptionScope call_option_scope;
   if (!d_weights || !key || !d_idx || !d_weights_out) return bf::set_error(BF_EINVAL, "NULL argument");
   if (B <= 0 || M <= 0) return bf::set_error(BF_EINVAL, "B and M must be positive");
   return bf::launch_optimal_resample(d_weights, key, B, M, N, d_idx, d_weights_out, static_cast<hipStream_t>(stream));
@@ -304,6 +320,7 @@ int bf_optimal_resample_f32(const float* d_weights, const uint32_t key[2], int64
 
 int bf_collapse_f32(const bf_stream* weights, const bf_stream* means, const bf_stream* covs, int64_t B, int64_t T,
                     int32_t K, int32_t n, float* mean_out, float* cov_out, void* stream) {
+  bf::CallOptionScope call_option_scope;
   if (!weights || !means || !weights->ptr || !means->ptr) return bf::set_error(BF_EINVAL, "weights and means are required");
   if (cov_out && (!covs || !covs->ptr)) return bf::set_error(BF_EINVAL, "cov_out needs the covariance stream");
   if (B <= 0 || T <= 0 || K <= 0 || n <= 0) return bf::set_error(BF_EINVAL, "non-positive size");
@@ -314,6 +331,7 @@ int bf_collapse_f32(const bf_stream* weights, const bf_stream* means, const bf_s
 int bf_bpf_f32(const bf_bpf_model* model, const bf_cstream* y, const bf_cstream* u, int64_t B, int64_t T, int32_t N,
                const uint32_t key[2], float ess_threshold, int32_t resampler, const bf_bpf_carry* carry,
                const bf_bpf_out* out, void* stream) {
+  bf::CallOptionScope call_option_scope;
   if (!model || !y || !out || !key) return bf::set_error(BF_EINVAL, "NULL argument");
   if (B <= 0 || T <= 0 || N <= 0) return bf::set_error(BF_EINVAL, "B, T and N must be positive");
   if (!y->ptr) return bf::set_error(BF_EINVAL, "observations pointer is NULL");
@@ -325,6 +343,7 @@ int bf_bpf_f32(const bf_bpf_model* model, const bf_cstream* y, const bf_cstream*
 
 int bf_sample_ssm_f32(const bf_bpf_model* model, const uint32_t* d_keys, const bf_cstream* u, int64_t B, int64_t T,
                       float* d_states, float* d_emissions, void* stream) {
+  bf::CallOptionScope call_option_scope;
   if (!model || !d_keys || (!d_states && !d_emissions)) return bf::set_error(BF_EINVAL, "NULL argument");
   if (B <= 0 || T <= 0) return bf::set_error(BF_EINVAL, "B and T must be positive");
   if (!model->ssm.Q || !model->ssm.R || !model->m0 || !model->P0) return bf::set_error(BF_EINVAL, "Q, R, m0, P0 are required");
@@ -333,6 +352,7 @@ int bf_sample_ssm_f32(const bf_bpf_model* model, const uint32_t* d_keys, const b
 
 int bf_resample_f32(const float* d_w, const uint32_t* d_keys, int64_t B, int32_t N, int32_t resampler, int32_t* d_idx,
                     void* stream) {
+  bf::CallOptionScope call_option_scope;
   if (!d_w || !d_keys || !d_idx || B <= 0 || N <= 0) return bf::set_error(BF_EINVAL, "bad argument");
   return bf::launch_resample(d_w, d_keys, B, N, resampler, d_idx, static_cast<hipStream_t>(stream));
 }

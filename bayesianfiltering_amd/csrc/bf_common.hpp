@@ -21,6 +21,37 @@ int set_error(int code, const char* fmt, ...);
                              __FILE__, __LINE__);                                            \
   } while (0)
 
+// A tuning option: a process-wide default (bf_set_option) that ONE call can override (bf_set_call_option arms an override on
+// the calling thread; the next filter entry point on that thread reads it and disarms every override when it returns), so
+// that one caller's choices never leak into another caller's launches.  Reads behave like the std::atomic<int> it replaces.
+enum OptionId { OPT_KF_EMIT_MODE, OPT_KF_LANES, OPT_KF_MFMA_VARIANT, OPT_KF_SMALL_MODE, OPT_FORCE_GENERIC, OPT_GSF_STRUCTURED,
+                OPT_BPF_VARIANT, OPT_BPF_HBM_MODE, OPT_BPF_SPEC, OPT_COUNT };
+struct CallOverrides {
+  int value[OPT_COUNT];
+  bool armed[OPT_COUNT];
+};
+CallOverrides& call_overrides();   // thread-local
+struct Option {
+  std::atomic<int> global;
+  OptionId id;
+  Option(int v, OptionId i) : global(v), id(i) {}
+  int load() const {
+    const CallOverrides& c = call_overrides();
+    return c.armed[id] ? c.value[id] : global.load();
+  }
+  operator int() const { return load(); }
+  Option& operator=(int v) {
+    global = v;
+    return *this;
+  }
+};
+struct CallOptionScope {   // at the top of every filter entry point: overrides live for exactly this call
+  ~CallOptionScope() {
+    CallOverrides& c = call_overrides();
+    for (int i = 0; i < OPT_COUNT; ++i) c.armed[i] = false;
+  }
+};
+
 // Device-resident copy of a host constant block (model struct, per-step covariance table), cached by content and
 // uploaded stream-ordered through pinned staging: no host synchronisation, nothing to free (const_cache.hip).
 int device_constants(const void* host, size_t bytes, hipStream_t stream, const void** d_out);

@@ -4,9 +4,9 @@
 
 namespace bf {
 
-std::atomic<int> g_bpf_variant{0};   // tuning hook (bf_set_option "bpf_variant")
-std::atomic<int> g_bpf_hbm_mode{0};  // bf_set_option "bpf_hbm_mode"
-std::atomic<int> g_bpf_spec{1};      // bf_set_option "bpf_spec"
+Option g_bpf_variant{0, OPT_BPF_VARIANT};   // tuning hook (bf_set_option "bpf_variant")
+Option g_bpf_hbm_mode{0, OPT_BPF_HBM_MODE};  // bf_set_option "bpf_hbm_mode"
+Option g_bpf_spec{1, OPT_BPF_SPEC};      // bf_set_option "bpf_spec"
 
 // Stand-alone resampler: idx[b][:] = choice(key_b, N, (N,), p = w[b]) (the index draw of utils.py:210)
 template <int PPT, int NW>

@@ -596,9 +596,9 @@ static inline int launch_bpf_cfg(const BpfModel<N, DQ, M>* d_mdl, const bf_cstre
   return BF_OK;
 }
 
-extern std::atomic<int> g_bpf_variant;   // tuning hook (bf_set_option "bpf_variant")
-extern std::atomic<int> g_bpf_hbm_mode;  // bf_set_option "bpf_hbm_mode": 0 = choose, 1 = workgroup per trajectory, 2 = per chunk
-extern std::atomic<int> g_bpf_spec;      // bf_set_option "bpf_spec": 1 = compile-time model structure where an instance exists (default), 0 = off
+extern Option g_bpf_variant;   // tuning hook (bf_set_option "bpf_variant")
+extern Option g_bpf_hbm_mode;  // bf_set_option "bpf_hbm_mode": 0 = choose, 1 = workgroup per trajectory, 2 = per chunk
+extern Option g_bpf_spec;      // bf_set_option "bpf_spec": 1 = compile-time model structure where an instance exists (default), 0 = off
 
 // bpf_big.hpp / bpf_wide.hpp: particle counts beyond the in-register capacities (declared here, defined after the kernels there)
 template <int N, int DQ, int M>

@@ -15,7 +15,7 @@ BF_DECL(launch_gsf_group_e);
 #undef BF_DECL
 
 // n = 1..8 with m = 1..min(n, 4); `lanes` = 0 picks the default lanes per chain.
-std::atomic<int> g_gsf_structured{1};  // tuning / test hook (bf_set_option "gsf_structured")
+Option g_gsf_structured{1, OPT_GSF_STRUCTURED};  // tuning / test hook (bf_set_option "gsf_structured")
 
 int launch_gsf_ekf(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int K,
                    const bf_carry* carry, const bf_out_desc* out, hipStream_t stream, int force_mode, int lanes) {

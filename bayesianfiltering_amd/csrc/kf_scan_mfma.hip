@@ -42,7 +42,7 @@ static int mfma_variant_default() {  // BAYESFILT_MFMA_VARIANT=1..5 overrides th
   const int v = e ? std::atoi(e) : 5;
   return (v >= 1 && v <= 5) ? v : 5;
 }
-std::atomic<int> g_kf_mfma_variant{mfma_variant_default()};  // bf_set_option "kf_mfma_variant": 5 = products as three-term bf16 splits on the bf16 matrix pipe (default); 2 = fp32 MFMAs, gain-free update, factorization in VALU registers; 3 = factorization by rank-2 MFMAs; 4 = variant 2 at three workgroups per CU; 1 = round 1's kernel
+Option g_kf_mfma_variant{mfma_variant_default(), OPT_KF_MFMA_VARIANT};  // bf_set_option "kf_mfma_variant": 5 = products as three-term bf16 splits on the bf16 matrix pipe (default); 2 = fp32 MFMAs, gain-free update, factorization in VALU registers; 3 = factorization by rank-2 MFMAs; 4 = variant 2 at three workgroups per CU; 1 = round 1's kernel
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using lds_f = __attribute__((address_space(3))) float;

@@ -143,7 +143,7 @@ class FilterCarry(NamedTuple):
 
 def kalman_filter(params, emissions, *, initial_means=None, initial_covariances=None, carry=None,
                   fields: Sequence[str] = FULL5, layout: str = "reference", out=None,
-                  return_loglik: bool = False, return_carry: bool = False, device="cuda"):
+                  return_loglik: bool = False, return_carry: bool = False, device="cuda", options=None):
     """Batched Kalman filter == ``gaussian_sum_filter(params, y, num_components=1)`` of the
     reference for linear ``f(x,q,u) = A x + G q``, ``h(x,r,u) = H x + D r`` with the initial
     component mean given explicitly (the reference samples it from N(m0, P0) with PRNGKey(0),
@@ -222,6 +222,7 @@ def kalman_filter(params, emissions, *, initial_means=None, initial_covariances=
         cr.w_out, cr.m_out, cr.P_out = (t.data_ptr() for t in c_out)
 
     stream = torch.cuda.current_stream(y.device).cuda_stream
+    _lib.arm_call_options(lib, options)      # tuning options for THIS call only (bf_set_call_option)
     _lib.check(lib.bf_kalman_filter_f32(C.byref(mdl.c), C.byref(yd), B, T, C.byref(cr), C.byref(od),
                                         C.c_void_p(stream)))
 
@@ -333,7 +334,7 @@ def gaussian_sum_filter(params, emissions, num_components: int = 1, num_iter: in
                         initial_means=None, initial_covariances=None, carry=None,
                         fields: Sequence[str] = FULL5, layout: str = "reference", out=None,
                         return_loglik: bool = False, return_carry: bool = False, return_collapsed: bool = False,
-                        device="cuda", _uparams=None):
+                        device="cuda", options=None, _uparams=None):
     """Gaussian-sum filter (bank of K extended Kalman filters + weight update),
     gaussfiltax/inference.py:303-377, on the HIP engine.
 
@@ -415,6 +416,7 @@ def gaussian_sum_filter(params, emissions, num_components: int = 1, num_iter: in
         cr.w_out, cr.m_out, cr.P_out = (t.data_ptr() for t in c_out)
 
     stream = torch.cuda.current_stream(y.device).cuda_stream
+    _lib.arm_call_options(lib, options)      # tuning options for THIS call only (bf_set_call_option)
     if _uparams is None:
         _lib.check(lib.bf_gsf_ekf_f32(C.byref(mdl.c), C.byref(yd), C.byref(ud), B, T, K, C.byref(cr), C.byref(od),
                                       C.c_void_p(stream)))
@@ -619,7 +621,7 @@ class ParticleCarry(NamedTuple):
 
 def bootstrap_particle_filter(params, emissions, num_particles: int, key=None, inputs=None,
                               ess_threshold: float = 0.5, *, resampler: str = "multinomial", output: str = "full",
-                              carry=None, return_carry: bool = False, return_ancestors: bool = False, device="cuda"):
+                              carry=None, return_carry: bool = False, return_ancestors: bool = False, device="cuda", options=None):
     """Bootstrap particle filter, gaussfiltax/inference.py:1302-1380, on the HIP engine.
 
     Same positional signature as the reference (``key`` defaults to ``PRNGKey(0)``).  Returns the
@@ -715,6 +717,7 @@ def bootstrap_particle_filter(params, emissions, num_particles: int, key=None, i
         cr.w_out, cr.x_out, cr.key_out = c_out.weights.data_ptr(), c_out.particles.data_ptr(), c_out.key.data_ptr()
 
     stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.arm_call_options(lib, options)      # tuning options for THIS call only (bf_set_call_option)
     _lib.check(lib.bf_bpf_f32(C.byref(bm), C.byref(yd), C.byref(ud), B, T, NP, key_c, float(ess_threshold),
                               1 if resampler == "systematic" else 0, C.byref(cr), C.byref(od), C.c_void_p(stream)))
     if squeeze:

@@ -141,8 +141,17 @@ int bf_device_count(void);
  *   "bpf_variant":  workgroup geometry of the 4096-particle instance: 0 (default) = 1024 threads x 4 particles, 1 = 512 x 8.
  *   "bpf_hbm_mode": particle counts beyond the in-register capacities: 0 (default) = choose by batch
  *                   size, 1 = one workgroup per trajectory, 2 = one workgroup per 1024-particle chunk
- *                   (six launches per step; same results bit for bit). */
+ *                   (six launches per step; same results bit for bit).
+ *   "bpf_spec":     1 (default) = models whose structure has a compile-time instance (Lorenz-96 dynamics with identity noise
+ *                   input, diagonal chol(Q), selection emission, diagonal chol(R)) run on it; 0 = the run-time instance
+ *                   (same results bit for bit).
+ * bf_set_option changes the PROCESS-WIDE default.  A library or a thread that must not disturb -- or be disturbed by -- other
+ * callers uses bf_set_call_option instead: it arms the same option on the CALLING THREAD for the NEXT filter entry point
+ * called on that thread (bf_kalman_filter_f32, bf_gsf_ekf_f32, bf_ugsf_ukf_f32, bf_agsf_*, bf_bpf_f32, bf_sample_ssm_f32,
+ * bf_resample_f32, bf_optimal_resample_f32, bf_collapse_f32) and for that call only; every armed override is dropped when
+ * that call returns, whatever its status. */
 int bf_set_option(const char* name, int value);
+int bf_set_call_option(const char* name, int value);
 
 /* Batched Kalman filter: B independent trajectories, one component each (K = 1), T steps.
  * Replaces the lax.scan of gaussian_sum_filter (inference.py:333-371) with

@@ -58,3 +58,13 @@ if [[ $what == *bpfstats* ]]; then
   grep -h '"metric"' $out/bpf4096.log > $out/bpf4096_bench_line.json; cut -c1-300 $out/bpf4096_bench_line.json
   stats $out/t_bpf $out/bpf4096_kernel_stats.csv; rm -rf $out/t_bpf
 fi
+for w in bf32 ugsf agsf uagsf gsf_collapsed; do
+  if [[ " $what " == *" $w "* ]]; then
+    echo "== $w"
+    python3 $root/scripts/roofline_probe.py $w > $out/probe_$w.json 2> $out/probe_$w.err; cat $out/probe_$w.json
+    kern=$(python3 -c "import json,sys; print(json.load(open('$out/probe_$w.json'))['kernel'])")
+    rocprofv3 --kernel-trace --stats --output-format csv -d $out/t_$w -- python3 $root/scripts/roofline_probe.py $w > $out/t_$w.log 2>&1
+    stats $out/t_$w $out/${w}_kernel_stats.csv; rm -rf $out/t_$w
+    pmc $w $kern $out/pmc_$w.json "$(cat $out/probe_$w.json)" -- python3 $root/scripts/roofline_probe.py $w
+  fi
+done

@@ -120,3 +120,41 @@ def test_nan_observation_poisons_the_trajectory_and_only_it(n, m):
         assert np.array_equal(mm[b], mc[b]) and np.array_equal(ll.cpu().numpy()[b], ll_clean.cpu().numpy()[b])
     # the covariance recursion does not depend on the data: it stays finite
     assert np.isfinite(post.covariances.cpu().numpy()).all()
+
+
+def test_call_options_apply_to_one_call_only():
+    """bf_set_call_option (Python: options={...}): a tuning option armed for ONE call on the calling thread -- the next filter
+    entry point sees it, the one after does not, and the process-wide default (bf_set_option) is never touched: a library's
+    choice of kernel variant cannot change another caller's results-to-rounding."""
+    import threading
+    import torch
+    import bayesianfiltering_amd as bfa
+    from bayesianfiltering_amd import _lib
+    lib = _lib.require_gpu()
+    a = cm.random_stable_lgssm(4, 2, seed=3, bias=True)
+    p = cm.product_params(a)
+    ys = cm.simulate_batch(a, 7, 50, seed=3)
+    default = bfa.kalman_filter(p, ys, return_loglik=True)
+    once = bfa.kalman_filter(p, ys, return_loglik=True, options={"force_generic": 1})      # the run-time-dimension kernel, this call only
+    after = bfa.kalman_filter(p, ys, return_loglik=True)
+    _lib.check(lib.bf_set_option(b"force_generic", 1))
+    try:
+        glob = bfa.kalman_filter(p, ys, return_loglik=True)
+    finally:
+        _lib.check(lib.bf_set_option(b"force_generic", 0))
+    for k in bfa.FULL5:
+        assert torch.equal(getattr(once[0], k), getattr(glob[0], k)), k
+        assert torch.equal(getattr(after[0], k), getattr(default[0], k)), k
+    assert torch.equal(once[1], glob[1]) and torch.equal(after[1], default[1])
+    assert not torch.equal(once[0].covariances, default[0].covariances)       # (the two kernels round differently: the option did act)
+    # an override armed on ANOTHER thread is that thread's: this thread's next call is the default
+    t = threading.Thread(target=lambda: _lib.check(lib.bf_set_call_option(b"force_generic", 1)))
+    t.start(); t.join()
+    again = bfa.kalman_filter(p, ys, return_loglik=True)
+    assert torch.equal(again[0].covariances, default[0].covariances)
+    # armed overrides are dropped even when the call fails
+    _lib.check(lib.bf_set_call_option(b"force_generic", 1))
+    assert lib.bf_kalman_filter_f32(None, None, 1, 1, None, None, None) == _lib.BF_EINVAL
+    again = bfa.kalman_filter(p, ys, return_loglik=True)
+    assert torch.equal(again[0].covariances, default[0].covariances)
+    assert lib.bf_set_call_option(b"no_such_option", 1) == _lib.BF_EINVAL
