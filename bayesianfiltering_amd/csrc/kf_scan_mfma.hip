@@ -1428,10 +1428,10 @@ __device__ __forceinline__ float dot_terms32(const u32x4 (*x)[2], const float* v
   return s;
 }
 // one 32 x 32 accumulator tile of a [nr][nr] stream entry at (b, t)
-__device__ __forceinline__ void store_tile32(const SView& sv, long long b, long long t, int lane, const f32x16& acc, int nr) {
+__device__ __forceinline__ void store_tile32(const SView& sv, long long b, long long t, int lane, const f32x16& acc, int nr, int k = 0) {
   if (!sv.p) return;
   const int lr = lane & 31, lk = lane >> 5;
-  gl_f* base = per_step(sv.p + b * sv.sB + t * sv.sT);
+  gl_f* base = per_step(sv.p + b * sv.sB + k * sv.sK + t * sv.sT);
   const long long sE = sv.sE + (long long)opaque_szero();
   BF_UNROLL for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -1444,8 +1444,15 @@ __device__ __forceinline__ void store_tile32(const SView& sv, long long b, long 
 constexpr int BF32_PN_BYTES = 2 * 32 * 33 * 4;   // 8 448 >= 3 * 32 * 80
 constexpr int BF32_WAVE_LDS = BF32_PN_BYTES + 3 * 32 * 80 + 4 * 32 * 4;
 
+// MULTI: K >= 1 Gaussian-sum components of a LINEAR model per trajectory (inference.py:345-353 vmaps _condition_on / _predict
+// over the components): they take turns in the wave's tiles -- a component's predicted mean and covariance wait in HBM
+// (gm / gP: the caller's carry-out buffers or a scratch, L2-resident between turns) -- and the weight update runs over the
+// lanes (component k in lane k, K <= 64) in the oracle's adjacent-pair tree order.  TV: per-step G Q_t G^T / D R_t D^T tables
+// (_get_params(x, 2, t), inference.py:21,337-340) instead of the constants of Bf32Const.
+template <bool MULTI, bool TV>
 __global__ void __launch_bounds__(128, 2)
-kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry, OutViews out, long long B, long long T, int nr, int mr) {
+kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry, OutViews out, long long B, long long T, int nr, int mr,
+                    int K, float* __restrict__ gm, float* __restrict__ gP, const float* __restrict__ tvq, const float* __restrict__ tvr) {
   constexpr int PITCH = 80, TERM = 32 * PITCH, PS = 33;
   const int lane = threadIdx.x & 63;
   const int lr = lane & 31, lk = lane >> 5;
@@ -1474,18 +1481,46 @@ kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry,
   }
   const float dr0 = cst->Dr0[lr], gq0 = cst->Gq0[lr];
   f32x16 Pacc;
-  BF_UNROLL for (int r = 0; r < 16; ++r) {
-    const int row = c_row(r, lane);
-    Pacc[r] = (lr < nr && row < nr) ? carry.P_in[b * nr * nr + row * nr + lr] : 0.f;
+  float w;
+  if constexpr (!MULTI) {
+    BF_UNROLL for (int r = 0; r < 16; ++r) {
+      const int row = c_row(r, lane);
+      Pacc[r] = (lr < nr && row < nr) ? carry.P_in[b * nr * nr + row * nr + lr] : 0.f;
+    }
+    store_terms_transposed(Pn, TERM, PITCH, 0, 0, lane, Pacc);
+    sm[lr] = lr < nr ? carry.m_in[b * nr + lr] : 0.f;
+    w = carry.w_in ? carry.w_in[b] : 1.0f;
+  } else {
+    w = lane < K ? (carry.w_in ? carry.w_in[b * K + lane] : 1.0f / (float)K) : 0.f;   // component `lane`'s weight
   }
-  store_terms_transposed(Pn, TERM, PITCH, 0, 0, lane, Pacc);
-  sm[lr] = lr < nr ? carry.m_in[b * nr + lr] : 0.f;
-  float w = carry.w_in ? carry.w_in[b] : 1.0f;
+  float llk = 0.f;                       // MULTI: component `lane`'s log-likelihood of this step
+  const long long bk0 = b * (long long)K;
   float ynext = lr < mr ? y.p[b * y.sB + lr * y.sE] : 0.f;
   const float ll_pad = 0.5f * 1.8378770664093453f * (float)(32 - mr);
   wave_lds_order();
 
   for (long long t = 0; t < T; ++t) {
+    const float yv = ynext;
+    {
+      const long long tn = t + 1 < T ? t + 1 : t;
+      if (lr < mr) ynext = y.p[b * y.sB + tn * y.sT + lr * y.sE];
+    }
+    gl_cf* const drd_t = TV && tvr ? per_step(tvr + t * 1024) : per_step(cst->DRD);
+    gl_cf* const gqg_t = TV && tvq ? per_step(tvq + t * 1024) : per_step(cst->GQG);
+   for (int k = 0; k < (MULTI ? K : 1); ++k) {
+    if constexpr (MULTI) {   // this component's carried prior: the caller's at t = 0, the wave's own store of the previous step after
+      // (every lane reads back exactly the addresses it wrote: program order makes the values visible.  Fetching one turn
+      // ahead into 17 more registers was measured 28 % SLOWER: the wave already holds 48 operand registers of A and H)
+      const float* pin = t == 0 ? carry.P_in : gP;
+      const float* min_ = t == 0 ? carry.m_in : gm;
+      BF_UNROLL for (int r = 0; r < 16; ++r) {
+        const int row = c_row(r, lane);
+        Pacc[r] = (lr < nr && row < nr) ? pin[(bk0 + k) * nr * nr + row * nr + lr] : 0.f;
+      }
+      store_terms_transposed(Pn, TERM, PITCH, 0, 0, lane, Pacc);
+      if (lk == 0) sm[lr] = lr < nr ? min_[(bk0 + k) * nr + lr] : 0.f;   // (the lane that parked entry lr reads it back)
+      wave_lds_order();
+    }
     // ---- Z = P-^T H^T; H P- in fp32 for the forward substitution; innovation
     {
       f32x16 z = {0};
@@ -1498,9 +1533,6 @@ kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry,
       wave_lds_order();   // P-'s terms have been read: their buffer now takes H P (fp32) and, below, S
       BF_UNROLL for (int r = 0; r < 16; ++r) sHP[lr * PS + c_row(r, lane)] = z[r];
       store_terms_transposed(Zn, TERM, PITCH, 0, 0, lane, z);
-      const float yv = ynext;
-      const long long tn = t + 1 < T ? t + 1 : t;
-      if (lr < mr) ynext = y.p[b * y.sB + tn * y.sT + lr * y.sE];
       float s = dot_terms32(hop, sm, lk);
       s += __shfl_xor(s, 32, 64);
       sv[lr] = yv - (s + dr0);
@@ -1509,8 +1541,7 @@ kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry,
     // ---- S^T = H Z + (D R D^T)^T
     {
       f32x16 acc;
-      gl_cf* drd = per_step(cst->DRD);
-      BF_UNROLL for (int r = 0; r < 16; ++r) acc[r] = drd[lr * 32 + c_row(r, lane)];
+      BF_UNROLL for (int r = 0; r < 16; ++r) acc[r] = drd_t[lr * 32 + c_row(r, lane)];
       BF_UNROLL for (int c = 0; c < 2; ++c) {
         u32x4 bz[3];
         load_terms(bz, Zn, TERM, PITCH, lr, c, lk);
@@ -1534,11 +1565,15 @@ kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry,
       }
       const float cv = lk == 0 ? scv[lr] : 0.f;
       acc = mfma2(cv, cv, acc);
-      store_tile32(out.P, b, t, lane, acc, nr);
+      store_tile32(out.P, b, t, lane, acc, nr, MULTI ? k : 0);
       wave_lds_order();   // (W^T's terms are read before Y^T overwrites them below; P-'s before P+'s here)
       store_terms_transposed(Pn, TERM, PITCH, 0, 0, lane, acc);
-      if (out.m.p && lane < nr) out.m.p[b * out.m.sB + t * out.m.sT + lane * out.m.sE] = sm2[lane];
-      if (lane == 0) {
+      if (out.m.p && lane < nr) out.m.p[b * out.m.sB + (MULTI ? k : 0) * out.m.sK + t * out.m.sT + lane * out.m.sE] = sm2[lane];
+      if constexpr (MULTI) {
+        const float ll0 = rdlane(ll, 0);
+        if (lane == k) llk = ll0;
+        if (lane == 0 && out.ll.p) out.ll.p[b * out.ll.sB + k * out.ll.sK + t * out.ll.sT] = ll;
+      } else if (lane == 0) {
         w = reweight_single(ll, w);
         if (out.w.p) out.w.p[b * out.w.sB + t * out.w.sT] = w;
         if (out.ll.p) out.ll.p[b * out.ll.sB + t * out.ll.sT] = ll;
@@ -1562,9 +1597,8 @@ kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry,
     wave_lds_order();
     // ---- P- = Y A^T + G Q G^T; predicted streams
     {
-      gl_cf* gqg = per_step(cst->GQG);
       float gq[16];
-      BF_UNROLL for (int r = 0; r < 16; ++r) gq[r] = gqg[c_row(r, lane) * 32 + lr];
+      BF_UNROLL for (int r = 0; r < 16; ++r) gq[r] = gqg_t[c_row(r, lane) * 32 + lr];
       BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] = 0.f;
       BF_UNROLL for (int c = 0; c < 2; ++c) {
         u32x4 a[3];
@@ -1573,13 +1607,39 @@ kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry,
         Pacc = mfma_bf6(a, ba, Pacc);
       }
       BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] += gq[r];
-      store_tile32(out.pP, b, t, lane, Pacc, nr);
-      store_terms_transposed(Pn, TERM, PITCH, 0, 0, lane, Pacc);
-      if (out.pm.p && lane < nr) out.pm.p[b * out.pm.sB + t * out.pm.sT + lane * out.pm.sE] = sm[lane];
+      store_tile32(out.pP, b, t, lane, Pacc, nr, MULTI ? k : 0);
+      if constexpr (!MULTI) store_terms_transposed(Pn, TERM, PITCH, 0, 0, lane, Pacc);   // (MULTI: the next turn brings its own P-)
+      if (out.pm.p && lane < nr) out.pm.p[b * out.pm.sB + (MULTI ? k : 0) * out.pm.sK + t * out.pm.sT + lane * out.pm.sE] = sm[lane];
+      if constexpr (MULTI) {   // park the component's predicted mean / covariance until its next turn (also the carry out)
+        BF_UNROLL for (int r = 0; r < 16; ++r) {
+          const int row = c_row(r, lane);
+          if (lr < nr && row < nr) gP[(bk0 + k) * nr * nr + row * nr + lr] = Pacc[r];
+        }
+        if (lane < nr) gm[(bk0 + k) * nr + lane] = sm[lane];
+      }
     }
     wave_lds_order();
+   }
+    if constexpr (MULTI) {
+      // ---- weight update (inference.py:347-350): lls -= max; w = exp(lls) * w; w /= sum(w) over the lanes, adjacent-pair trees
+      // (lanes beyond K carry -inf / 0: the identities of the two trees)
+      float mx = lane < K ? llk : -__builtin_inff();
+      BF_UNROLL for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_xor(mx, off, 64);
+        mx = (mx != mx || o != o) ? __builtin_nanf("") : fmaxf(mx, o);   // jnp.max propagates NaN
+      }
+      const float e = lane < K ? expf(llk - mx) * w : 0.f;
+      float tot = e;
+      BF_UNROLL for (int off = 1; off < 64; off <<= 1) tot += __shfl_xor(tot, off, 64);
+      w = e / tot;
+      if (lane < K && out.w.p) out.w.p[b * out.w.sB + lane * out.w.sK + t * out.w.sT] = w;
+    }
   }
 
+  if constexpr (MULTI) {   // (gm / gP ARE the carry-out buffers when the caller asked for them)
+    if (carry.w_out && lane < K) carry.w_out[bk0 + lane] = w;
+    return;
+  }
   if (carry.P_out && lr < nr) BF_UNROLL for (int r = 0; r < 16; ++r) {
       const int row = c_row(r, lane);
       if (row < nr) carry.P_out[b * nr * nr + row * nr + lr] = Pacc[r];
@@ -1588,13 +1648,15 @@ kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry,
   if (carry.w_out && lane == 0) carry.w_out[b] = w;
 }
 
+// K = 1: bf_kalman_filter_f32; K >= 1: the Gaussian-sum filter of a linear model (bf_gsf_ekf_f32), components in turn.
 int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry, const bf_out_desc* out,
-                   hipStream_t stream) {
+                   hipStream_t stream, int K, bool multi) {
   constexpr int N = 32;
   const int nr = p->n, mr = p->m, dq = p->dq, dr = p->dr;
   if (nr > N || mr > N) return set_error(BF_EUNSUPPORTED, "one-wave matrix-core Kalman kernel: n <= 32 and m <= 32");
-  if (p->Q_steps > 1 || p->R_steps > 1)
-    return set_error(BF_EUNSUPPORTED, "time-varying Q/R are not supported on the matrix-core Kalman kernels");
+  if (K > 64) return set_error(BF_EUNSUPPORTED, "one-wave matrix-core kernel: at most 64 components (one per lane in the weight update)");
+  if ((p->Q_steps > 1 && p->Q_steps != T) || (p->R_steps > 1 && p->R_steps != T))
+    return set_error(BF_EINVAL, "time-varying covariances need one matrix per step (Q_steps / R_steps = T = %lld)", T);
   Bf32Const* h = new Bf32Const();
   std::memset(h, 0, sizeof(*h));
   auto Gat = [&](int i, int k) { return p->G ? p->G[i * dq + k] : (i == k ? 1.f : 0.f); };
@@ -1621,33 +1683,56 @@ int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
       float x = p->H[i * nr + j];
       for (int t3 = 0; t3 < 3; ++t3) { const unsigned short hb = bf(x); h->H3[t3][i * N + j] = hb; x -= fl(hb); }
     }
-  {  // (G Q) G^T and (D R) D^T, association of inference.py:69,:100
-    std::vector<float> GQ((size_t)nr * dq), DRm((size_t)mr * dr);
+  // (G Q) G^T and (D R) D^T, association of inference.py:69,:100, into a zero-padded 32 x 32 block
+  std::vector<float> GQ((size_t)nr * dq), DRm((size_t)mr * dr);
+  auto gqg_of = [&](const float* Q, float* dst) {
     for (int i = 0; i < nr; ++i)
       for (int l = 0; l < dq; ++l) {
         float s = 0.f;
-        for (int k = 0; k < dq; ++k) s = fmaf(Gat(i, k), p->Q[k * dq + l], s);
+        for (int k = 0; k < dq; ++k) s = fmaf(Gat(i, k), Q[k * dq + l], s);
         GQ[i * dq + l] = s;
       }
     for (int i = 0; i < nr; ++i)
       for (int j = 0; j < nr; ++j) {
         float s = 0.f;
         for (int l = 0; l < dq; ++l) s = fmaf(GQ[i * dq + l], Gat(j, l), s);
-        h->GQG[i * N + j] = s;
+        dst[i * N + j] = s;
       }
+  };
+  auto drd_of = [&](const float* R, float* dst) {
     for (int i = 0; i < mr; ++i)
       for (int l = 0; l < dr; ++l) {
         float s = 0.f;
-        for (int k = 0; k < dr; ++k) s = fmaf(Dat(i, k), p->R[k * dr + l], s);
+        for (int k = 0; k < dr; ++k) s = fmaf(Dat(i, k), R[k * dr + l], s);
         DRm[i * dr + l] = s;
       }
     for (int i = 0; i < mr; ++i)
       for (int j = 0; j < mr; ++j) {
         float s = 0.f;
         for (int l = 0; l < dr; ++l) s = fmaf(DRm[i * dr + l], Dat(j, l), s);
-        h->DRD[i * N + j] = s;
+        dst[i * N + j] = s;
       }
-    for (int i = mr; i < N; ++i) h->DRD[i * N + i] = 1.0f;   // padded observations: unit noise
+    for (int i = mr; i < N; ++i) dst[i * N + i] = 1.0f;   // padded observations: unit noise
+  };
+  gqg_of(p->Q, h->GQG);
+  drd_of(p->R, h->DRD);
+  // per-step tables (_get_params(x, 2, t), inference.py:21): T blocks of 32 x 32, through the constant cache like the model
+  const float *d_tvq = nullptr, *d_tvr = nullptr;
+  if (p->Q_steps > 1) {
+    std::vector<float> tab((size_t)T * N * N, 0.f);
+    for (long long t = 0; t < T; ++t) gqg_of(p->Q + (size_t)t * dq * dq, tab.data() + (size_t)t * N * N);
+    const void* dv = nullptr;
+    const int rc = device_constants(tab.data(), sizeof(float) * tab.size(), stream, &dv);
+    if (rc != BF_OK) { delete h; return rc; }
+    d_tvq = static_cast<const float*>(dv);
+  }
+  if (p->R_steps > 1) {
+    std::vector<float> tab((size_t)T * N * N, 0.f);
+    for (long long t = 0; t < T; ++t) drd_of(p->R + (size_t)t * dr * dr, tab.data() + (size_t)t * N * N);
+    const void* dv = nullptr;
+    const int rc = device_constants(tab.data(), sizeof(float) * tab.size(), stream, &dv);
+    if (rc != BF_OK) { delete h; return rc; }
+    d_tvr = static_cast<const float*>(dv);
   }
   for (int i = 0; i < nr; ++i) {
     float s = 0.f;
@@ -1667,9 +1752,31 @@ int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
   CarryView cv{carry->w_in, carry->m_in, carry->P_in, carry->w_out, carry->m_out, carry->P_out};
   OutViews ov{make_sview(out->weights), make_sview(out->means), make_sview(out->covs),
               make_sview(out->pred_means), make_sview(out->pred_covs), make_sview(out->loglik)};
-  hipLaunchKernelGGL(kf_scan_bf32_kernel, dim3((unsigned)((B + 1) / 2)), dim3(128), 2 * BF32_WAVE_LDS, stream,
-                     static_cast<const Bf32Const*>(dv), yv, cv, ov, B, T, nr, mr);
-  BF_HIP_CHECK(hipGetLastError());
+  const Bf32Const* dc = static_cast<const Bf32Const*>(dv);
+  const dim3 grid((unsigned)((B + 1) / 2)), block(128);
+  const bool tv = d_tvq || d_tvr;
+  if (!multi) {
+    if (tv) hipLaunchKernelGGL((kf_scan_bf32_kernel<false, true>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, B, T, nr, mr, 1, nullptr, nullptr, d_tvq, d_tvr);
+    else hipLaunchKernelGGL((kf_scan_bf32_kernel<false, false>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, B, T, nr, mr, 1, nullptr, nullptr, nullptr, nullptr);
+    BF_HIP_CHECK(hipGetLastError());
+    return BF_OK;
+  }
+  // components in turn: their predicted means / covariances wait in the caller's carry-out buffers when given, else in a
+  // stream-ordered scratch (m_out / P_out may alias m_in / P_in: a component's input is read at t = 0, before its slot is written)
+  float* gm = carry->m_out;
+  float* gP = carry->P_out;
+  float* scratch = nullptr;
+  if (!gm || !gP) {
+    const size_t fl = (size_t)B * K * ((size_t)nr + (size_t)nr * nr);
+    BF_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(float) * fl, stream));
+    if (!gm) gm = scratch;
+    if (!gP) gP = scratch + (size_t)B * K * nr;
+  }
+  if (tv) hipLaunchKernelGGL((kf_scan_bf32_kernel<true, true>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, B, T, nr, mr, K, gm, gP, d_tvq, d_tvr);
+  else hipLaunchKernelGGL((kf_scan_bf32_kernel<true, false>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, B, T, nr, mr, K, gm, gP, nullptr, nullptr);
+  const hipError_t le = hipGetLastError();
+  if (scratch) (void)hipFreeAsync(scratch, stream);
+  BF_HIP_CHECK(le);
   return BF_OK;
 }
 

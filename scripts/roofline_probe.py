@@ -46,8 +46,10 @@ elif which == "gsf_collapsed":   # gsf_scan_kernel<8,4,2,EMIT_NONE,...>: cfg3 in
     y = cm.device_observations(p, (8, 8, 4, 4), B, T, seed=2000)
     g = torch.Generator(device="cuda").manual_seed(20)
     init = 8.0 + torch.randn((B, K, n), device="cuda", generator=g)
-    fn = lambda: bfa.gaussian_sum_filter(p, y, K, 1, initial_means=init, fields=(), return_carry=True, return_collapsed=True)
-    info = {"kernel": "gsf_scan_kernel", "mode": "COLLAPSED", "n": n, "m": m, "K": K, "B": B, "T": T, "units": B * T, "unit": "timesteps"}
+    lanes = int(os.environ.get("PLANES", "0"))
+    fn = lambda: bfa.gaussian_sum_filter(p, y, K, 1, initial_means=init, fields=(), return_carry=True, return_collapsed=True,
+                                         options={"kf_lanes": lanes} if lanes else None)
+    info = {"kernel": "gsf_scan_kernel", "mode": "COLLAPSED", "lanes_per_chain": lanes or 2, "n": n, "m": m, "K": K, "B": B, "T": T, "units": B * T, "unit": "timesteps"}
 else:
     raise SystemExit("unknown probe")
 fn(); torch.cuda.synchronize()

@@ -216,3 +216,73 @@ def test_small_mode_off_routes_to_the_other_kernels(n, m):
     for k in FIELDS:
         assert cm.rel_err(getattr(post, k).cpu().numpy(), ref[k]) < 1e-5, k
     assert cm.rel_err(ll.cpu().numpy(), ref["loglik"]) < 5e-5
+
+
+@pytest.mark.parametrize("n,m,K,tv", [(16, 8, 4, False), (32, 16, 32, False), (24, 12, 5, True), (32, 16, 4, True), (12, 10, 3, True),
+                                       (32, 32, 64, False)])
+def test_gaussian_sum_of_a_linear_model_on_the_matrix_cores(n, m, K, tv):
+    """_predict / _condition_on are vmapped over the components and read per-step covariances (inference.py:21,51-105,337-353):
+    for LINEAR models of 9 <= n <= 32 the K components take turns on the one-wave matrix-core kernel (bf16 three-term
+    products), per-step Q_t / R_t tables included.  Against the oracle at 1e-5 (weights absolutely), against the
+    run-time-dimension kernel, and two chunks through the carry == one shot bit for bit."""
+    import torch
+    import bayesianfiltering_amd as bfa
+    a = cm.random_stable_lgssm(n, m, seed=n + m + K, dq=max(1, n - 2), dr=m, bias=True)
+    B, T = 3, 14
+    ys = cm.simulate_batch(a, B, T, seed=K)
+    rng = np.random.default_rng(K)
+    pp, po = cm.product_params(a), cm.oracle_params(a)
+    if tv:
+        Qt = np.stack([(0.6 + rng.random()) * a["Q"] for _ in range(T)]).astype(F32)
+        Rt = np.stack([(0.6 + rng.random()) * a["R"] for _ in range(T)]).astype(F32)
+        pp = pp._replace(dynamics_noise_covariance=Qt, emission_noise_covariance=Rt)
+        po = po._replace(dynamics_noise_covariance=Qt, emission_noise_covariance=Rt)
+    im = (a["m0"] + 0.5 * rng.normal(size=(B, K, n))).astype(F32)
+    post, ll, carry = bfa.gaussian_sum_filter(pp, ys, K, 1, initial_means=im, return_loglik=True, return_carry=True)
+    with _forced():
+        slow = bfa.gaussian_sum_filter(pp, ys, K, 1, initial_means=im)
+    assert not torch.equal(post.covariances, slow.covariances)          # (another kernel did run: the two round differently)
+    for b in range(B):
+        ref, rll = go.gaussian_sum_filter(po, ys[b], K, initial_means=im[b], return_ll=True)
+        for k in FIELDS:
+            e = cm.both_err(getattr(post, k)[b].cpu().numpy(), getattr(ref, k), k)
+            assert e[0] < 1e-5, (b, k, e)
+            assert cm.rel_err(getattr(post, k)[b].cpu().numpy(), getattr(slow, k)[b].cpu().numpy()) < 1e-5, (b, k)
+        assert np.max(np.abs(post.weights[b].cpu().numpy() - ref.weights)) < 2e-5, b
+        assert cm.rel_err(ll[b].cpu().numpy(), rll) < 2e-5, b
+        assert cm.rel_err(carry.means[b].cpu().numpy(), ref.predicted_means[:, -1]) < 1e-5
+        assert np.max(np.abs(carry.weights[b].cpu().numpy() - ref.weights[:, -1])) < 2e-5
+    # two chunks through the carry (the per-step tables are sliced with the observations)
+    cut = 6
+    p1 = pp if not tv else pp._replace(dynamics_noise_covariance=Qt[:cut], emission_noise_covariance=Rt[:cut])
+    p2 = pp if not tv else pp._replace(dynamics_noise_covariance=Qt[cut:], emission_noise_covariance=Rt[cut:])
+    h1, c1 = bfa.gaussian_sum_filter(p1, ys[:, :cut], K, 1, initial_means=im, return_carry=True)
+    h2, c2 = bfa.gaussian_sum_filter(p2, ys[:, cut:], K, 1, carry=c1, return_carry=True)
+    for k in FIELDS + ("weights",):
+        assert torch.equal(torch.cat([getattr(h1, k), getattr(h2, k)], dim=2), getattr(post, k)), k
+    for x, y_ in zip(c2, carry):
+        assert torch.equal(x, y_)
+
+
+def test_time_varying_kalman_on_the_matrix_cores():
+    """bf_kalman_filter_f32 with (T, d, d) covariances at (32, 16): the one-wave matrix-core kernel reads per-step tables."""
+    import torch
+    import bayesianfiltering_amd as bfa
+    n, m, B, T = 32, 16, 4, 20
+    a = cm.random_stable_lgssm(n, m, seed=77, bias=True)
+    ys = cm.simulate_batch(a, B, T, seed=7)
+    rng = np.random.default_rng(7)
+    Qt = np.stack([(0.6 + rng.random()) * a["Q"] for _ in range(T)]).astype(F32)
+    Rt = np.stack([(0.6 + rng.random()) * a["R"] for _ in range(T)]).astype(F32)
+    init = np.tile(a["m0"], (B, 1))
+    for kw in ({"dynamics_noise_covariance": Qt, "emission_noise_covariance": Rt}, {"dynamics_noise_covariance": Qt}, {"emission_noise_covariance": Rt}):
+        pp, po = cm.product_params(a)._replace(**kw), cm.oracle_params(a)._replace(**kw)
+        post, ll = bfa.kalman_filter(pp, ys, initial_means=init, return_loglik=True)
+        with _forced():
+            slow = bfa.kalman_filter(pp, ys, initial_means=init)
+        assert not torch.equal(post.covariances, slow.covariances)
+        for b in range(B):
+            ref, rll = go.gaussian_sum_filter(po, ys[b], 1, initial_means=init[b].reshape(1, -1), return_ll=True)
+            for k in FIELDS:
+                assert cm.rel_err(getattr(post, k)[b].cpu().numpy(), getattr(ref, k)) < 1e-5, (b, k)
+            assert cm.rel_err(ll[b].cpu().numpy(), rll) < 2e-5
