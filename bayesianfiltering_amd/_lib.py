@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BAYESFILT_HIP_LIB") or os.path.join(_HERE, "libbayesfilt_hip.so")
 
 BF_OK, BF_EINVAL, BF_EUNSUPPORTED, BF_EHIP, BF_ENOGPU = 0, -1, -2, -3, -4
-HEADER_VERSION = 200  # the BF_VERSION of include/bayesfilt.h these bindings were written against
+HEADER_VERSION = 210  # the BF_VERSION of include/bayesfilt.h these bindings were written against
 
 
 class BayesFiltError(RuntimeError):
@@ -64,7 +64,8 @@ class bf_ukf_params(C.Structure):
 
 
 class bf_bpf_model(C.Structure):
-    _fields_ = [("ssm", bf_model), ("m0", _FP), ("P0", _FP), ("lp_cov", _FP), ("r_eval", _FP)]
+    _fields_ = [("ssm", bf_model), ("m0", _FP), ("P0", _FP), ("lp_cov", _FP), ("r_eval", _FP), ("lp_theta", _FP),
+                ("n_lp_theta", C.c_int32)]
 
 
 class bf_bpf_carry(C.Structure):
@@ -109,6 +110,7 @@ SYMBOLS = {
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "bf_resample_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "bf_user_model_create": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "bf_user_model_create_lp": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "bf_user_model_destroy": (None, [C.c_void_p]),
     "bf_allgather_summaries": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "bf_canon_eval_f32": (C.c_int, [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -13,7 +13,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#ifndef BF_JIT
 #include <cmath>
+#endif
 
 namespace bf {
 

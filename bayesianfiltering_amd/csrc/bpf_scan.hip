@@ -47,6 +47,9 @@ BF_DECL(launch_bpf_group_b);
 BF_DECL(launch_bpf_group_c);
 #undef BF_DECL
 
+int launch_bpf_user_impl(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP, float ess,
+                         int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o, hipStream_t stream);
+
 int launch_bpf(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP,
                float ess, int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o,
                hipStream_t stream) {
@@ -54,6 +57,10 @@ int launch_bpf(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u,
               carry ? carry->x_out : nullptr, carry ? carry->w_out : nullptr, carry ? carry->key_out : nullptr};
   BpfOut out{o->weights, o->w_sB, o->w_sN, o->w_sT, o->particles, o->x_sB, o->x_sN, o->x_sT, o->ancestors,
              o->mean, o->ess, o->logz, o->resampled};
+  if (bp->ssm.user)   // functions from the caller's source: the kernel compiled at run time for this model (user_model.hip)
+    return launch_bpf_user_impl(bp, y, u, B, T, NP, ess, resampler, key, carry, o, stream);
+  if (bp->ssm.dyn_id == BF_FN_USER || bp->ssm.emi_id == BF_FN_USER)
+    return set_error(BF_EINVAL, "dyn_id / emi_id = BF_FN_USER needs bf_model.user (bf_user_model_create)");
   bool matched = false;
   int rc = launch_bpf_group_a(bp, y, u, B, T, NP, ess, resampler, key, cr, out, stream, &matched);
   if (matched) return rc;

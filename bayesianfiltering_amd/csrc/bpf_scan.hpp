@@ -24,10 +24,12 @@
 // inference.py:1359-1362,1378) and/or SUMMARY per step (weighted mean, ESS, log-evidence
 // increment, resampled flag) -- the full history of cfg4 is 4.6 TB and does not fit HBM.
 #pragma once
+#ifndef BF_JIT
 #include <cstring>
-#include <type_traits>
 #include <cstdlib>
 #include "bf_common.hpp"
+#endif
+#include <type_traits>
 #include "kf_math.hpp"
 #include "scan_common.hpp"
 #include "bf_rng.hpp"
@@ -248,9 +250,11 @@ struct BpfArgs {
   uint32_t key0, key1;
 };
 
+// The kernel proper, as a device function: every kernel entry that runs it -- bpf_scan_kernel below, the `extern "C"` entries
+// of a build compiled at run time with a caller's functions (user_model.hip) -- has the parameter list
+// (const BpfModel*, BpfArgs by value), which is what the kernarg-segment reads below rely on.
 template <int N, int DQ, int M, int PPT, int NW, class SP = SpecRuntime>
-__global__ void __launch_bounds__(64 * NW)
-bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, const BpfArgs<N, DQ, M> args_by_value) {
+__device__ __forceinline__ void bpf_scan_body(const BpfModel<N, DQ, M>* __restrict__ mdlp) {
   // `ka[fresh()]`: the argument struct as it lies in the kernarg segment (behind the model pointer, which stays a
   // `__restrict__` parameter of its own: that is what lets the compiler read the model with scalar loads), behind an
   // offset the compiler cannot see through (always 0), so that a field read inside the time loop is a fresh scalar load
@@ -263,7 +267,6 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, const BpfArgs<N, DQ
     asm volatile("" : "+s"(z));
     return z;
   };
-  (void)args_by_value;
   const long long T = ka->T;
   const int NP = ka->NP;
   constexpr int NT = 64 * NW;
@@ -571,6 +574,14 @@ bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, const BpfArgs<N, DQ
   }
 }
 
+template <int N, int DQ, int M, int PPT, int NW, class SP = SpecRuntime>
+__global__ void __launch_bounds__(64 * NW)
+bpf_scan_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, const BpfArgs<N, DQ, M> args_by_value) {
+  (void)args_by_value;   // (read from the kernarg segment inside)
+  bpf_scan_body<N, DQ, M, PPT, NW, SP>(mdlp);
+}
+
+#ifndef BF_JIT   // host side: launches
 // ---------------------------------------------------------------------------------------
 template <int N, int DQ, int M, int PPT, int NW, class SP = SpecRuntime>
 static inline int launch_bpf_cfg(const BpfModel<N, DQ, M>* d_mdl, const bf_cstream* y, const bf_cstream* u, long long B,
@@ -653,5 +664,7 @@ static inline int launch_bpf_dims(const bf_bpf_model* bp, const bf_cstream* y, c
   }
   return by_capacity(SpecRuntime{});
 }
+
+#endif  // BF_JIT
 
 }  // namespace bf

@@ -2,9 +2,12 @@
 // the registry functions' VALUES (no Jacobians), the Cholesky factors the Gaussian draws and the
 // emission log-density need, and the host code that fills them from the C-ABI structs.
 #pragma once
+#ifndef BF_JIT
 #include <cstring>
-#include <type_traits>
+#include <vector>
 #include "bf_common.hpp"
+#endif
+#include <type_traits>
 #include "bf_rng.hpp"
 #include "kf_math.hpp"
 #include "models.hpp"
@@ -29,7 +32,11 @@ struct BpfModel {
   float lp_const;     // -0.5 m log(2 pi) - sum log diag(LR)
   float m0[N];
   float L0[N * N];    // chol(P0), lower
+  // functions compiled from the caller's source (user_model.hip): their parameter vectors and the noise value the emission
+  // density's mean is evaluated at (h(x, r_eval, u))
+  float uth_dyn[64], uth_emi[64], uth_lp[64], r_eval[64];
 };
+enum { DYN_USER_SRC = 100, EMI_USER_SRC = 100 };   // BF_FN_USER
 
 // What the sampling code reads from a model's STRUCTURE fields (function ids, "this factor is diagonal" flags): at run time
 // from the struct (SpecRuntime: one binary serves every registry model), or as compile-time constants (SpecFixed: the
@@ -37,10 +44,19 @@ struct BpfModel {
 // switch, none of the other models' code or registers, and only the fields that model reads).
 struct SpecRuntime {
   static constexpr bool fixed = false;
+  static constexpr bool user_dyn = false, user_emi = false, user_lp = false;
+};
+// run-time structure flags plus functions from the caller's source (hiprtc builds only): f(x, q, u), h(x, r, u) and / or the
+// emission log-density itself
+template <bool UD, bool UE, bool ULP>
+struct SpecUser {
+  static constexpr bool fixed = false;
+  static constexpr bool user_dyn = UD, user_emi = UE, user_lp = ULP;
 };
 template <int DYN, int EMI, bool G_ID, bool LQ_DIAG, bool LR_DIAG, bool H_PICK, int IMPL = 0>
 struct SpecFixed {
   static constexpr bool fixed = true;
+  static constexpr bool user_dyn = false, user_emi = false, user_lp = false;
   static constexpr int impl = IMPL;   // 0: Threefry + normals as the hand-scheduled block of bf_rng.hpp; 1: plain C++
   static constexpr int dyn_id = DYN, emi_id = EMI;
   static constexpr bool g_identity = G_ID, lq_diag = LQ_DIAG, lr_diag = LR_DIAG, h_pick = H_PICK;
@@ -117,6 +133,12 @@ __device__ __forceinline__ void dyn_base_t(const MDL& p, const float* x, float u
 template <int N, int DQ, class MDL, class SP = SpecRuntime>
 __device__ __forceinline__ void dyn_value_t(const MDL& p, const float* x, const float* q, float u0, float* out) {
 #pragma clang fp contract(off)
+#ifdef BF_USER_DYN
+  if constexpr (SP::user_dyn) {   // the caller's f(x, q, u): the noise enters however the function says (models.py:82-84)
+    bfu::dynamics<float>(x, q, u0, p.uth_dyn, out);
+    return;
+  }
+#endif
   dyn_base_t<N, DQ, MDL, SP>(p, x, u0, out);
   if (spec_g_identity<SP>(p)) {
     if constexpr (DQ == N) BF_UNROLL for (int i = 0; i < N; ++i) out[i] += q[i];
@@ -229,7 +251,15 @@ __device__ __forceinline__ void draw_dynamics_noise(const BpfModel<N, DQ, M>& md
 template <int N, int DQ, int M, class SP = SpecRuntime>
 __device__ __forceinline__ float emission_loglik(const BpfModel<N, DQ, M>& mdl, const float* xn, float u0, const float* yv) {
 #pragma clang fp contract(off)
+#ifdef BF_USER_LP
+  if constexpr (SP::user_lp) return bfu::log_prob<float>(xn, yv, u0, mdl.uth_lp);   // the caller's emission_distribution_log_prob
+#endif
   float hx[M], zz[M];
+#ifdef BF_USER_EMI
+  if constexpr (SP::user_emi) {
+    bfu::emission<float>(xn, mdl.r_eval, u0, mdl.uth_emi, hx);   // mean of the density: h(x, r_eval, u)
+  } else
+#endif
   if (spec_h_pick<SP>(mdl)) {  // selection emission (e.g. the even states of Lorenz-96): the exact-zero terms of H x are skipped
     BF_UNROLL for (int a = 0; a < M; ++a) hx[a] = xn[(2 * a) % N] + mdl.hb[a];
   } else {
@@ -252,6 +282,7 @@ __device__ __forceinline__ float emission_loglik(const BpfModel<N, DQ, M>& mdl, 
   return __builtin_fmaf(-0.5f, quad, mdl.lp_const) - lsc;
 }
 
+#ifndef BF_JIT   // host side: the C-ABI structs -> BpfModel
 static inline int cholesky_lower(const float* A, int n, float* L) {  // fp32, row-major; returns 0 or -1 (not PD)
 #pragma clang fp contract(off)  // every operation rounded on its own: what the test oracle's NumPy loop does
   for (int i = 0; i < n * n; ++i) L[i] = 0.f;
@@ -270,23 +301,51 @@ static inline int cholesky_lower(const float* A, int n, float* L) {  // fp32, ro
   return 0;
 }
 
-template <int N, int DQ, int M>
-static inline int fill_bpf_model(const bf_bpf_model* bp, BpfModel<N, DQ, M>& e) {
+// The fields of a BpfModel<N, DQ, M> by address, for dimensions known at run time: the struct holds 4-byte members only, in
+// declaration order and without padding, so the model of a kernel compiled at run time (user_model.hip) is the same words laid
+// out one after the other (bpf_model_view_flat) -- and ONE fill routine serves both.
+struct BpfModelView {
+  int N, DQ, M;
+  int *dyn_id, *emi_id, *g_identity, *lq_diag, *lr_diag, *h_pick;
+  float *dth, *eth, *A, *Gm, *Hm, *q0, *LQ, *LQd, *hb, *LR, *rdLR, *lp_const, *m0, *L0, *uth_dyn, *uth_emi, *uth_lp, *r_eval;
+};
+constexpr size_t bpf_model_words(int n, int dq, int m) {
+  return 8 + 16 + (size_t)n * n + (size_t)n * dq + (size_t)m * n + dq + (size_t)dq * dq + dq + m + (size_t)m * m + m + 1 + n + (size_t)n * n + 4 * 64;
+}
+static inline BpfModelView bpf_model_view_flat(uint32_t* w, int n, int dq, int m) {
+  BpfModelView v;
+  v.N = n; v.DQ = dq; v.M = m;
+  int* iw = reinterpret_cast<int*>(w);
+  v.dyn_id = iw; v.emi_id = iw + 1; v.g_identity = iw + 2; v.lq_diag = iw + 3; v.lr_diag = iw + 4; v.h_pick = iw + 5;
+  float* f = reinterpret_cast<float*>(w) + 8;
+  auto take = [&](size_t k) { float* r = f; f += k; return r; };
+  v.dth = take(8); v.eth = take(8); v.A = take((size_t)n * n); v.Gm = take((size_t)n * dq); v.Hm = take((size_t)m * n); v.q0 = take(dq);
+  v.LQ = take((size_t)dq * dq); v.LQd = take(dq); v.hb = take(m); v.LR = take((size_t)m * m); v.rdLR = take(m); v.lp_const = take(1);
+  v.m0 = take(n); v.L0 = take((size_t)n * n); v.uth_dyn = take(64); v.uth_emi = take(64); v.uth_lp = take(64); v.r_eval = take(64);
+  return v;
+}
+
+// user_flags: bit 0 = dynamics, bit 1 = emission, bit 2 = log-density come from the caller's source (their parameter vectors:
+// p->dyn_theta, p->emi_theta, bp->lp_theta; at most 64 entries each)
+static inline int fill_bpf_model_view(const bf_bpf_model* bp, BpfModelView e, int user_flags, const float* lp_theta, int n_lp_theta) {
 #pragma clang fp contract(off)
   const bf_model* p = &bp->ssm;
+  const int N = e.N, DQ = e.DQ, M = e.M;
   if (p->Q_steps > 1 || p->R_steps > 1)
     return set_error(BF_EUNSUPPORTED, "time-varying Q/R are not supported by the sampling kernels (particle filter, data generator)");
-  std::memset(&e, 0, sizeof(e));
-  e.dyn_id = p->dyn_id;
-  e.emi_id = p->emi_id;
-  e.g_identity = 1;
+  *e.dyn_id = p->dyn_id;
+  *e.emi_id = p->emi_id;
+  *e.g_identity = 1;
   const float* th = p->dyn_theta;
-  switch (p->dyn_id) {
+  if (user_flags & 1) {
+    if (p->n_dyn_theta > 64) return set_error(BF_EUNSUPPORTED, "a dynamics function from source takes at most 64 parameters here");
+    for (int i = 0; i < p->n_dyn_theta; ++i) e.uth_dyn[i] = th[i];
+  } else switch (p->dyn_id) {
     case DYN_LINEAR:
       if (p->n_dyn_theta != N * N + N * DQ) return set_error(BF_EINVAL, "linear dynamics: theta must hold A and G");
       for (int i = 0; i < N * N; ++i) e.A[i] = th[i];
       for (int i = 0; i < N * DQ; ++i) e.Gm[i] = th[N * N + i];
-      e.g_identity = 0;
+      *e.g_identity = 0;
       break;
     case DYN_LORENZ96:
       if (p->n_dyn_theta != 5 || DQ != N) return set_error(BF_EINVAL, "lorenz96: theta = (alpha, beta, gamma, dt, mode), dq = n");
@@ -302,7 +361,7 @@ static inline int fill_bpf_model(const bf_bpf_model* bp, BpfModel<N, DQ, M>& e) 
       e.dth[1] = th[1];
       const float Gb[8] = {0.5f, 0, 1, 0, 0, 0.5f, 0, 1};
       for (int i = 0; i < 8 && i < N * DQ; ++i) e.Gm[i] = Gb[i];
-      e.g_identity = 0;
+      *e.g_identity = 0;
     } break;
     case DYN_SINE:
       if (p->n_dyn_theta != 1 || DQ != N) return set_error(BF_EINVAL, "sine: theta = (w0), dq = n");
@@ -315,11 +374,21 @@ static inline int fill_bpf_model(const bf_bpf_model* bp, BpfModel<N, DQ, M>& e) 
   }
   th = p->emi_theta;
   const int dr = p->dr;
-  float D[M * 64] = {0};
   if (dr > 64) return set_error(BF_EUNSUPPORTED, "emission noise dimension > 64");
+  std::vector<float> D((size_t)M * dr, 0.f);
   for (int i = 0; i < M; ++i)
     for (int k = 0; k < dr; ++k) D[i * dr + k] = (i == k) ? 1.f : 0.f;
-  switch (p->emi_id) {
+  for (int k = 0; k < dr; ++k) e.r_eval[k] = bp->r_eval ? bp->r_eval[k] : 0.f;
+  if (user_flags & 4) {
+    if (n_lp_theta > 64) return set_error(BF_EUNSUPPORTED, "a log-density function from source takes at most 64 parameters here");
+    for (int i = 0; i < n_lp_theta; ++i) e.uth_lp[i] = lp_theta[i];
+  }
+  if (user_flags & 2) {
+    if (p->n_emi_theta > 64) return set_error(BF_EUNSUPPORTED, "an emission function from source takes at most 64 parameters here");
+    for (int i = 0; i < p->n_emi_theta; ++i) e.uth_emi[i] = th[i];
+  } else if (user_flags & 4) {
+    // the density is the caller's own function: the emission function plays no part in the particle filter
+  } else switch (p->emi_id) {
     case EMI_LINEAR:
       if (p->n_emi_theta != M * N + M * dr) return set_error(BF_EINVAL, "linear emission: theta must hold H and D");
       for (int i = 0; i < M * N; ++i) e.Hm[i] = th[i];
@@ -350,31 +419,43 @@ static inline int fill_bpf_model(const bf_bpf_model* bp, BpfModel<N, DQ, M>& e) 
   }
   for (int i = 0; i < DQ; ++i) e.q0[i] = p->q0 ? p->q0[i] : 0.f;
   if (cholesky_lower(p->Q, DQ, e.LQ) != 0) return set_error(BF_EINVAL, "dynamics noise covariance is not positive definite");
-  e.lq_diag = 1;
+  *e.lq_diag = 1;
   for (int i = 0; i < DQ; ++i) {
     e.LQd[i] = e.LQ[i * DQ + i];
     for (int k = 0; k < i; ++k)
-      if (e.LQ[i * DQ + k] != 0.f) e.lq_diag = 0;
+      if (e.LQ[i * DQ + k] != 0.f) *e.lq_diag = 0;
   }
-  if (cholesky_lower(bp->lp_cov, M, e.LR) != 0) return set_error(BF_EINVAL, "log-prob covariance is not positive definite");
-  e.lr_diag = 1;
-  for (int i = 0; i < M; ++i)
-    for (int k = 0; k < i; ++k)
-      if (e.LR[i * M + k] != 0.f) e.lr_diag = 0;
-  e.h_pick = (p->emi_id == EMI_LINEAR && 2 * M <= N + 1) ? 1 : 0;
-  if (e.h_pick)
-    for (int a = 0; a < M; ++a)
-      for (int i = 0; i < N; ++i)
-        if (e.Hm[a * N + i] != ((i == 2 * a) ? 1.0f : 0.0f)) e.h_pick = 0;
-  float logdet = 0.f;
-  for (int i = 0; i < M; ++i) {
-    e.rdLR[i] = 1.0f / e.LR[i * M + i];
-    logdet += canon_log(e.LR[i * M + i]);
+  *e.lr_diag = 1;
+  *e.h_pick = 0;
+  if (!(user_flags & 4)) {   // Gaussian density MVN(h(x, r_eval, u), lp_cov): its Cholesky factor and constant
+    if (cholesky_lower(bp->lp_cov, M, e.LR) != 0) return set_error(BF_EINVAL, "log-prob covariance is not positive definite");
+    for (int i = 0; i < M; ++i)
+      for (int k = 0; k < i; ++k)
+        if (e.LR[i * M + k] != 0.f) *e.lr_diag = 0;
+    *e.h_pick = (!(user_flags & 2) && p->emi_id == EMI_LINEAR && 2 * M <= N + 1) ? 1 : 0;
+    if (*e.h_pick)
+      for (int a = 0; a < M; ++a)
+        for (int i = 0; i < N; ++i)
+          if (e.Hm[a * N + i] != ((i == 2 * a) ? 1.0f : 0.0f)) *e.h_pick = 0;
+    float logdet = 0.f;
+    for (int i = 0; i < M; ++i) {
+      e.rdLR[i] = 1.0f / e.LR[i * M + i];
+      logdet += canon_log(e.LR[i * M + i]);
+    }
+    *e.lp_const = -0.5f * (float)M * 1.8378770664093453f - logdet;
   }
-  e.lp_const = -0.5f * (float)M * 1.8378770664093453f - logdet;
   for (int i = 0; i < N; ++i) e.m0[i] = bp->m0[i];
   if (cholesky_lower(bp->P0, N, e.L0) != 0) return set_error(BF_EINVAL, "initial covariance is not positive definite");
   return BF_OK;
 }
+
+template <int N, int DQ, int M>
+static inline int fill_bpf_model(const bf_bpf_model* bp, BpfModel<N, DQ, M>& e) {
+  static_assert(sizeof(BpfModel<N, DQ, M>) == 4 * bpf_model_words(N, DQ, M), "BpfModel: 4-byte members in declaration order, no padding");
+  std::memset(&e, 0, sizeof(e));
+  return fill_bpf_model_view(bp, bpf_model_view_flat(reinterpret_cast<uint32_t*>(&e), N, DQ, M), 0, nullptr, 0);
+}
+
+#endif  // BF_JIT
 
 }  // namespace bf

@@ -21,22 +21,28 @@
 #include <string>
 #include <vector>
 #include "bf_common.hpp"
+#include "bpf_scan.hpp"   // BpfArgs / BpfCarry / BpfOut, the run-time-dimension model fill
 
 #ifndef BF_ARCH_NAME
 #define BF_ARCH_NAME "gfx950"
 #endif
 
 struct bf_user_model {
-  hipModule_t mod = nullptr;
+  hipModule_t mod = nullptr;              // the Gaussian-sum scan with dual-number Jacobians (built when f or h is given)
   hipFunction_t k64 = nullptr, k256 = nullptr;
   int n = 0, dq = 0, m = 0, dr = 0;
   int device = -1;
-  bool has_dyn = false, has_emi = false;
+  bool has_dyn = false, has_emi = false, has_lp = false;
+  std::string dyn_src, emi_src, lp_src;  // kept: the particle-filter kernels are built on first use, per particle capacity
+  std::map<int, hipFunction_t> bpf;       // key = PPT * 100 + NW
+  std::vector<hipModule_t> extra_mods;
 };
 
 namespace bf {
 
-extern const char* const kGenericDeviceSource;  // generic_device.hpp, embedded at build time (jit_sources.cpp)
+extern const char* const kGenericDeviceSource;  // generic_device.hpp, embedded at build time (jit_sources.hip)
+extern const char* const kSamplingSourceA;      // kf_math.hpp + bf_canon_math.hpp
+extern const char* const kSamplingSourceB;      // scan_common / bf_rng / models / ssm_device / bpf_scan
 
 namespace {
 
@@ -157,6 +163,12 @@ __device__ inline Dual atan(Dual x) { return Dual(::atanf(x.v), x.d / (1.f + x.v
 __device__ inline Dual atan2(Dual y, Dual x) { const float r2 = x.v * x.v + y.v * y.v; return Dual(::atan2f(y.v, x.v), (x.v * y.d - y.v * x.d) / r2); }
 __device__ inline Dual pow(Dual x, float p) { const float w = ::powf(x.v, p - 1.f); return Dual(w * x.v, p * w * x.d); }
 __device__ inline Dual abs(Dual x) { return x.v < 0.f ? -x : x; }
+__device__ inline void sincos(float x, float* s, float* c) { *s = ::sinf(x); *c = ::cosf(x); }
+__device__ inline void sincos(Dual x, Dual* s, Dual* c) { const float sv = ::sinf(x.v), cv = ::cosf(x.v); *s = Dual(sv, cv * x.d); *c = Dual(cv, -sv * x.d); }
+__device__ inline float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
+__device__ inline Dual fma(Dual a, Dual b, Dual c) { return a * b + c; }
+__device__ inline Dual fma(float a, Dual b, Dual c) { return a * b + c; }
+__device__ inline Dual fma(Dual a, float b, Dual c) { return a * b + c; }
 )BFSRC";
 
 std::string build_source(const char* dyn_src, const char* emi_src, int n, int dq, int m, int dr) {
@@ -234,6 +246,9 @@ int launch_user_kernel(const bf_user_model* um, int nt, unsigned grid, size_t ld
   return BF_OK;
 }
 
+int launch_bpf_user_impl(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP, float ess,
+                         int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o, hipStream_t stream);
+
 namespace {
 
 bool read_file(const std::string& path, std::vector<char>& code) {
@@ -306,7 +321,154 @@ hipError_t load_module(bf_user_model* um, const std::vector<char>& code) {
   return e;
 }
 
+// source -> code object through the disk cache (a cached file that does not load is deleted and rebuilt) -> one kernel
+int build_function(const std::string& src, const char* kernel_name, hipModule_t* mod, hipFunction_t* fn) {
+  int rtver = 0;
+  (void)hipRuntimeGetVersion(&rtver);
+  char key[32];
+  std::snprintf(key, sizeof(key), "%016llx", (unsigned long long)fnv1a(src + "|" BF_ARCH_NAME "|" + std::to_string(rtver)));
+  const std::string path = cache_dir() + "/user_" + key + "_" BF_ARCH_NAME ".co";
+  std::vector<char> code;
+  hipError_t e = hipErrorUnknown;
+  *mod = nullptr;
+  auto load = [&]() {
+    hipError_t le = hipModuleLoadData(mod, code.data());
+    if (le == hipSuccess) le = hipModuleGetFunction(fn, *mod, kernel_name);
+    if (le != hipSuccess && *mod) {
+      (void)hipModuleUnload(*mod);
+      *mod = nullptr;
+    }
+    return le;
+  };
+  if (read_file(path, code)) {
+    e = load();
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return set_error(BF_ENOGPU, "loading the compiled model failed: %s", hipGetErrorString(e));
+      std::remove(path.c_str());
+      code.clear();
+    }
+  }
+  if (code.empty()) {
+    const int rc = compile_with_hiprtc(src, code);
+    if (rc != BF_OK) return rc;
+    write_file_atomically(path, code);
+    e = load();
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return set_error(e == hipErrorNoDevice ? BF_ENOGPU : BF_EHIP, "loading the compiled model failed: %s", hipGetErrorString(e));
+  }
+  return BF_OK;
+}
+
+// The particle-filter kernel (bpf_scan.hpp) with the caller's functions compiled in: state in registers at the compile-time
+// dimensions of the handle, one entry per particle capacity.  The caller's functions see the CANONICAL arithmetic of the
+// weight path (bf_canon_math.hpp: sin / cos / atan2 / exp / log as defined there, IEEE sqrt, no contraction), so a function
+// written like its registry twin gives the registry twin's bits.
+const char* const kSamplingUserMath = R"BFSRC(
+namespace bfu {
+#pragma clang fp contract(off)
+__device__ inline float sin(float x) { return bf::canon_sin(x); }
+__device__ inline float cos(float x) { float s, c; bf::canon_sincos(x, &s, &c); return c; }
+__device__ inline void sincos(float x, float* s, float* c) { bf::canon_sincos(x, s, c); }
+__device__ inline float exp(float x) { return bf::canon_exp(x); }
+__device__ inline float log(float x) { return bf::canon_log(x); }
+__device__ inline float sqrt(float x) { return __builtin_sqrtf(x); }
+__device__ inline float atan2(float y, float x) { return bf::canon_atan2(y, x); }
+__device__ inline float atan(float x) { return bf::canon_atan(x); }
+__device__ inline float abs(float x) { return __builtin_fabsf(x); }
+__device__ inline float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+)BFSRC";
+
+std::string build_bpf_source(const bf_user_model* um, int ppt, int nw) {
+  std::string s = "#define BF_JIT 1\n#include <cstdint>\n#include <type_traits>\n";
+  if (um->has_dyn) s += "#define BF_USER_DYN 1\n";
+  if (um->has_emi) s += "#define BF_USER_EMI 1\n";
+  if (um->has_lp) s += "#define BF_USER_LP 1\n";
+  s += "#define BF_N " + std::to_string(um->n) + "\n#define BF_DQ " + std::to_string(um->dq) + "\n#define BF_M " + std::to_string(um->m) +
+       "\n#define BF_DR " + std::to_string(um->dr) + "\n";
+  s += "namespace bf { struct CView { const float* p; long long sB, sT, sE; }; }\n";
+  s += kSamplingSourceA;
+  s += kSamplingUserMath;
+  s += "\n// ---- the caller's functions\n";
+  if (um->has_dyn) s += um->dyn_src + "\n";
+  if (um->has_emi) s += um->emi_src + "\n";
+  if (um->has_lp) s += um->lp_src + "\n";
+  s += "}  // namespace bfu\n";
+  s += kSamplingSourceB;
+  const std::string spec = std::string("bf::SpecUser<") + (um->has_dyn ? "true" : "false") + ", " + (um->has_emi ? "true" : "false") + ", " +
+                           (um->has_lp ? "true" : "false") + ">";
+  s += "extern \"C\" __global__ void __launch_bounds__(" + std::to_string(64 * nw) + ") bf_user_bpf(const bf::BpfModel<BF_N, BF_DQ, BF_M>* __restrict__ mdlp, "
+       "const bf::BpfArgs<BF_N, BF_DQ, BF_M> args_by_value) {\n  (void)args_by_value;\n  bf::bpf_scan_body<BF_N, BF_DQ, BF_M, " +
+       std::to_string(ppt) + ", " + std::to_string(nw) + ", " + spec + ">(mdlp);\n}\n";
+  return s;
+}
+
 }  // namespace
+
+
+int launch_bpf_user_impl(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP, float ess,
+                         int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o, hipStream_t stream) {
+  const bf_model* p = &bp->ssm;
+  bf_user_model* um = const_cast<bf_user_model*>(p->user);
+  if (um->n != p->n || um->dq != p->dq || um->m != p->m || um->dr != p->dr)
+    return set_error(BF_EINVAL, "bf_model.user was compiled for (n, dq, m, dr) = (%d, %d, %d, %d) but the model says (%d, %d, %d, %d)",
+                     um->n, um->dq, um->m, um->dr, p->n, p->dq, p->m, p->dr);
+  if ((p->dyn_id == BF_FN_USER) != um->has_dyn) return set_error(BF_EINVAL, "dyn_id = BF_FN_USER exactly when bf_model.user holds dynamics source");
+  if ((p->emi_id == BF_FN_USER) != um->has_emi) return set_error(BF_EINVAL, "emi_id = BF_FN_USER exactly when bf_model.user holds emission source");
+  int dev = -1;
+  (void)hipGetDevice(&dev);
+  if (dev != um->device) return set_error(BF_EINVAL, "bf_model.user was loaded on device %d, the current device is %d", um->device, dev);
+  const int N = p->n, M = p->m;
+  // smallest particle capacity that holds NP (the geometries of bpf_scan.hpp: particles in registers)
+  int ppt, nw;
+  if (NP <= 64) { ppt = 1; nw = 1; }
+  else if (NP <= 256) { ppt = 1; nw = 4; }
+  else if (NP <= 1024) { ppt = 1; nw = 16; }
+  else if (NP <= 4096 && N <= 16) { ppt = 4; nw = 16; }
+  else return set_error(BF_EUNSUPPORTED, "particle filter with functions from source: at most 4096 particles for state_dim <= 16, 1024 beyond");
+  hipFunction_t fn = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = um->bpf.find(ppt * 100 + nw);
+    if (it != um->bpf.end()) {
+      fn = it->second;
+    } else {
+      hipModule_t mod = nullptr;
+      const int rc = build_function(build_bpf_source(um, ppt, nw), "bf_user_bpf", &mod, &fn);
+      if (rc != BF_OK) return rc;
+      um->extra_mods.push_back(mod);
+      um->bpf[ppt * 100 + nw] = fn;
+    }
+  }
+  // the model, word for word the BpfModel<N, DQ, M> of the kernel
+  std::vector<uint32_t> words(bpf_model_words(N, p->dq, M), 0u);
+  const int flags = (um->has_dyn ? 1 : 0) | (um->has_emi ? 2 : 0) | (um->has_lp ? 4 : 0);
+  int rc = fill_bpf_model_view(bp, bpf_model_view_flat(words.data(), N, p->dq, M), flags, bp->lp_theta, bp->n_lp_theta);
+  if (rc != BF_OK) return rc;
+  const void* dv = nullptr;
+  rc = device_constants(words.data(), sizeof(uint32_t) * words.size(), stream, &dv);
+  if (rc != BF_OK) return rc;
+  BpfArgs<1, 1, 1> a;   // (the argument struct does not depend on the dimensions)
+  std::memset(&a, 0, sizeof(a));
+  a.y = CView{y->ptr, y->sB, y->sT, y->sE};
+  a.uptr = (u && u->ptr) ? u->ptr : nullptr;
+  a.u_sB = u ? u->sB : 0;
+  a.u_sT = u ? u->sT : 0;
+  a.carry = BpfCarry{carry ? carry->x_in : nullptr, carry ? carry->w_in : nullptr, carry ? carry->key_in : nullptr,
+                     carry ? carry->x_out : nullptr, carry ? carry->w_out : nullptr, carry ? carry->key_out : nullptr};
+  a.out = BpfOut{o->weights, o->w_sB, o->w_sN, o->w_sT, o->particles, o->x_sB, o->x_sN, o->x_sT, o->ancestors, o->mean, o->ess, o->logz, o->resampled};
+  a.B = B; a.T = T; a.NP = NP; a.ess_threshold = ess; a.resampler = resampler; a.key0 = key[0]; a.key1 = key[1];
+  const int cap = 64 * nw * ppt, dch = (ppt >= 16) ? 1 : ((N >= 8) ? 8 : N);
+  const size_t lds_bytes = sizeof(float) * (size_t)(((cdf_words(cap) + 3) & ~3) + 64 + ((nw * N + 3) & ~3) + cap * dch);
+  if (lds_bytes > 160 * 1024) return set_error(BF_EUNSUPPORTED, "particle tile exceeds the 160 KiB LDS");
+  struct { const void* mdl; BpfArgs<1, 1, 1> a; } packed{dv, a};   // the kernarg segment: the model pointer, then the struct
+  size_t psz = sizeof(packed);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &packed, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psz, HIP_LAUNCH_PARAM_END};
+  BF_HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)B, 1, 1, (unsigned)(64 * nw), 1, 1, (unsigned)lds_bytes, stream, nullptr, config));
+  return BF_OK;
+}
 
 }  // namespace bf
 
@@ -314,11 +476,17 @@ extern "C" {
 
 int bf_user_model_create(const char* dynamics_src, const char* emission_src, int32_t n, int32_t dq, int32_t m, int32_t dr,
                          bf_user_model** model) {
+  return bf_user_model_create_lp(dynamics_src, emission_src, nullptr, n, dq, m, dr, model);
+}
+
+int bf_user_model_create_lp(const char* dynamics_src, const char* emission_src, const char* log_prob_src, int32_t n, int32_t dq,
+                            int32_t m, int32_t dr, bf_user_model** model) {
   using namespace bf;
-  if (!model || (!dynamics_src && !emission_src)) return set_error(BF_EINVAL, "bf_user_model_create: no source given");
+  if (!model || (!dynamics_src && !emission_src && !log_prob_src)) return set_error(BF_EINVAL, "bf_user_model_create: no source given");
   if (n <= 0 || dq <= 0 || m <= 0 || dr <= 0 || n > 64 || dq > 64 || m > 64 || dr > 64)
     return set_error(BF_EINVAL, "bf_user_model_create: dimensions must be in 1..64");
-  const std::string src = build_source(dynamics_src, emission_src, n, dq, m, dr);
+  const bool gsf = dynamics_src || emission_src;   // the Gaussian-sum scan is built now; the particle-filter kernels on first use
+  const std::string src = build_source(dynamics_src, emission_src, n, dq, m, dr) + (log_prob_src ? std::string("// lp: ") + log_prob_src : std::string());
   // the code object depends on the source, the target and the compiler: all three are in the key (the HIP runtime's version
   // stands for hiprtc's, which ships with it -- known without loading hiprtc on a cache hit)
   int rtver = 0;
@@ -341,6 +509,15 @@ int bf_user_model_create(const char* dynamics_src, const char* emission_src, int
   um->n = n; um->dq = dq; um->m = m; um->dr = dr; um->device = dev;
   um->has_dyn = dynamics_src != nullptr;
   um->has_emi = emission_src != nullptr;
+  um->has_lp = log_prob_src != nullptr;
+  if (dynamics_src) um->dyn_src = dynamics_src;
+  if (emission_src) um->emi_src = emission_src;
+  if (log_prob_src) um->lp_src = log_prob_src;
+  if (!gsf) {   // a log-density alone: nothing to build before the first particle-filter call
+    g_models[mem_key] = um;
+    *model = um;
+    return BF_OK;
+  }
   // ---- code object: disk cache (a file that does not load -- truncated, stale, foreign -- is deleted and rebuilt), else hiprtc
   std::vector<char> code;
   const std::string path = cache_dir() + "/user_" + key + "_" BF_ARCH_NAME ".co";

@@ -238,7 +238,7 @@ def kalman_filter(params, emissions, *, initial_means=None, initial_covariances=
 class _Model:
     """Host-side build of bf_model from a ParamsNLSSM / ParamsBPF holding registry functions."""
 
-    def __init__(self, params):
+    def __init__(self, params, log_prob_source=None):
         f = require_device_function(params.dynamics_function, "dynamics", "params.dynamics_function")
         h = require_device_function(params.emission_function, "emission", "params.emission_function")
         self.n, self.dq, self.m, self.dr = f.out_dim, f.noise_dim, h.out_dim, h.noise_dim
@@ -260,23 +260,23 @@ class _Model:
         # functions given as source text (nonlinearities.user_dynamics / user_emission): compiled once per source by hiprtc
         dsrc = getattr(f, "source", None)
         esrc = getattr(h, "source", None)
-        if dsrc is not None or esrc is not None:
-            c.user = _compile_user_model(dsrc, esrc, self.n, self.dq, self.m, self.dr)
+        if dsrc is not None or esrc is not None or log_prob_source is not None:
+            c.user = _compile_user_model(dsrc, esrc, self.n, self.dq, self.m, self.dr, log_prob_source)
         self.c = c
 
 
 _USER_MODELS = {}
 
 
-def _compile_user_model(dyn_src, emi_src, n, dq, m, dr):
-    """bf_user_model_create, memoised per (sources, dimensions); returns the opaque handle."""
-    key = (dyn_src, emi_src, n, dq, m, dr)
+def _compile_user_model(dyn_src, emi_src, n, dq, m, dr, lp_src=None):
+    """bf_user_model_create(_lp), memoised per (sources, dimensions); returns the opaque handle."""
+    key = (dyn_src, emi_src, lp_src, n, dq, m, dr)
     h = _USER_MODELS.get(key)
     if h is None:
         lib = _lib.require_gpu()
         out = C.c_void_p()
-        _lib.check(lib.bf_user_model_create(dyn_src.encode() if dyn_src is not None else None,
-                                            emi_src.encode() if emi_src is not None else None, n, dq, m, dr, C.byref(out)))
+        enc = lambda t: t.encode() if t is not None else None
+        _lib.check(lib.bf_user_model_create_lp(enc(dyn_src), enc(emi_src), enc(lp_src), n, dq, m, dr, C.byref(out)))
         h = _USER_MODELS[key] = out.value
     return h
 
@@ -632,7 +632,7 @@ def bootstrap_particle_filter(params, emissions, num_particles: int, key=None, i
     'multinomial' (the reference's ``jr.choice``, utils.py:207-214) or 'systematic'.
     ``params.emission_distribution_log_prob`` must be a :class:`~.nonlinearities.GaussianLogProb`.
     """
-    from .nonlinearities import GaussianLogProb
+    from .nonlinearities import GaussianLogProb, UserLogProb
     torch = _torch()
     lib = _lib.require_gpu()
     NP = int(num_particles)
@@ -643,21 +643,30 @@ def bootstrap_particle_filter(params, emissions, num_particles: int, key=None, i
     if output not in ("full", "summary", "both"):
         raise ValueError("output must be 'full', 'summary' or 'both'")
     lp = params.emission_distribution_log_prob
-    if not isinstance(lp, GaussianLogProb):
-        raise TypeError("params.emission_distribution_log_prob must be a nonlinearities.GaussianLogProb: Python "
-                        "callables cannot run inside the HIP kernels, and there is no CPU fallback.")
-    if lp.emission_function is not params.emission_function and \
+    if not isinstance(lp, (GaussianLogProb, UserLogProb)):
+        raise TypeError("params.emission_distribution_log_prob must be a nonlinearities.GaussianLogProb (around a registry or "
+                        "source emission function) or a nonlinearities.user_log_prob(source, ...): Python callables cannot run "
+                        "inside the HIP kernels, and there is no CPU fallback.")
+    user_lp = isinstance(lp, UserLogProb)
+    if not user_lp and lp.emission_function is not params.emission_function and \
             (lp.emission_function.fn_id != params.emission_function.fn_id or
-             not np.array_equal(lp.emission_function.theta, params.emission_function.theta)):
+             not np.array_equal(lp.emission_function.theta, params.emission_function.theta) or
+             getattr(lp.emission_function, "source", None) != getattr(params.emission_function, "source", None)):
         raise ValueError("the log-prob's emission function must be params.emission_function")
-    mdl = _Model(params)
+    mdl = _Model(params, lp.source if user_lp else None)
     n, m = mdl.n, mdl.m
     bm = _lib.bf_bpf_model()
     bm.ssm = mdl.c
     m0 = _host_f32(params.initial_mean).reshape(n)
     P0 = _host_f32(params.initial_covariance).reshape(n, n)
-    lpc = np.ascontiguousarray(lp.covariance.reshape(m, m))
-    rev = np.ascontiguousarray(lp.r_eval.reshape(mdl.dr))
+    if user_lp:      # the density is the caller's function: no covariance, its own parameters
+        lpc = np.ascontiguousarray(np.eye(m, dtype=F32))
+        rev = np.zeros(mdl.dr, F32)
+        lpth = np.ascontiguousarray(lp.theta if lp.theta.size else np.zeros(1, F32))
+        bm.lp_theta, bm.n_lp_theta = _fp(lpth), int(lp.theta.size)
+    else:
+        lpc = np.ascontiguousarray(lp.covariance.reshape(m, m))
+        rev = np.ascontiguousarray(lp.r_eval.reshape(mdl.dr))
     bm.m0, bm.P0, bm.lp_cov, bm.r_eval = _fp(m0), _fp(P0), _fp(lpc), _fp(rev)
 
     y = _dev_f32(emissions, device)

@@ -250,6 +250,30 @@ def user_emission(source, state_dim, emission_dim, noise_dim=None, theta=(), hos
                         host_fn, name)
 
 
+class UserLogProb:
+    """``emission_distribution_log_prob(x, y, u)`` (gaussfiltax/models.py:73-84, inference.py:1348-1349) OUTSIDE the Gaussian
+    family, given as HIP C++ source text and compiled at run time into the particle-filter kernel::
+
+        template <class T> __device__ T log_prob(const T* x, const float* y, T u, const float* theta)
+
+    (``BF_N`` / ``BF_M`` are compile-time constants; sin cos sincos atan atan2 exp log sqrt abs fma are the canonical fp32
+    arithmetic of the weight path).  ``host_fn(x, y, u)`` (optional) is a NumPy twin for the host."""
+
+    def __init__(self, source, theta=(), host_fn=None):
+        self.source = str(source)
+        self.theta = np.asarray(theta, dtype=F32).reshape(-1)
+        self._host_fn = host_fn
+
+    def __call__(self, x, y, u=None):
+        if self._host_fn is None:
+            raise NotImplementedError("this log-density exists as device source only (pass host_fn= for a NumPy twin)")
+        return self._host_fn(x, y, u)
+
+
+def user_log_prob(source, theta=(), host_fn=None):
+    return UserLogProb(source, theta, host_fn)
+
+
 def require_device_function(fn, kind, what):
     if not isinstance(fn, DeviceFunction) or fn.kind != kind:
         raise TypeError(

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BF_VERSION 200 /* 0.2.0: major = ABI revision (struct layouts), see bf_abi_check */
+#define BF_VERSION 210 /* 0.2.0: major = ABI revision (struct layouts), see bf_abi_check */
 
 #define BF_OK 0
 #define BF_EINVAL (-1)       /* bad argument (NULL pointer, non-positive size, misaligned) */
@@ -198,6 +198,19 @@ typedef struct bf_model {
 typedef struct bf_user_model bf_user_model;
 int bf_user_model_create(const char* dynamics_src, const char* emission_src, int32_t n, int32_t dq, int32_t m, int32_t dr,
                          bf_user_model** model);
+/* ... and for the bootstrap particle filter (bf_bpf_f32), whose model is f, the emission log-density and nothing else
+ * (gaussfiltax/inference.py:1344-1349: x' = f(x, q, u), lls = emission_distribution_log_prob(x', y, u), any callables):
+ * the same handle also compiles the particle-filter kernel with the caller's functions, on first use and per particle
+ * capacity (<= 4096 particles for state_dim <= 16, <= 1024 beyond).  The density is either Gaussian around the (registry or
+ * source) emission function, MVN(h(x, r_eval, u), lp_cov) as for registry models, or -- log_prob_src -- the caller's own
+ *
+ *     template <class T> __device__ T log_prob(const T* x, const float* y, T u, const float* theta);   // theta = bf_bpf_model.lp_theta
+ *
+ * In these kernels sin cos sincos atan atan2 exp log sqrt abs fma are the CANONICAL fp32 arithmetic of the weight path
+ * (bf_canon_eval_f32), so a function written like a registry function gives that function's bits.  Any of the three
+ * sources may be NULL (at least one is given). */
+int bf_user_model_create_lp(const char* dynamics_src, const char* emission_src, const char* log_prob_src, int32_t n, int32_t dq,
+                            int32_t m, int32_t dr, bf_user_model** model);
 void bf_user_model_destroy(bf_user_model* model);
 
 /* Hyper-parameters of the unscented transform -- ParamsUKF (inference.py:41-49): lambda =
@@ -279,6 +292,8 @@ typedef struct bf_bpf_model {
   const float* lp_cov; /* [m,m] covariance R of the emission log-density (the stochastic-volatility
                         * emission uses M(x,u) R M(x,u)^T, adaptive_experiment.py:55-57)          */
   const float* r_eval; /* [dr] noise value h is evaluated at (NULL = zeros)     */
+  const float* lp_theta; /* parameters of a log-density given as source (bf_user_model_create_lp), else NULL */
+  int32_t n_lp_theta;
 } bf_bpf_model;
 
 /* Scan carry (weights, particles, key) of inference.py:1364 for chunked runs; DEVICE pointers,

@@ -32,7 +32,7 @@ def test_header_compiles_and_links_from_c(tmp_path):
         pytest.skip("a GPU is present: the gpu-marked test runs the program")
     out = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    assert "version 200" in out.stdout and "no-gpu" in out.stdout
+    assert "version 210" in out.stdout and "no-gpu" in out.stdout
 
 
 def test_abi_guard_names_the_mismatching_struct():

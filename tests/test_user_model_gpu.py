@@ -208,7 +208,7 @@ def test_user_model_errors_and_cache():
     for _ in range(20):                                               # compiled once: later calls find the module
         bfa.gaussian_sum_filter(base._replace(dynamics_function=nl.user_dynamics(GROWTH_SRC, 1)), ys, 1, initial_means=np.zeros((1, 1), F32))
     assert time.perf_counter() - t0 < 2.0
-    # the particle / unscented / augmented kernels take registry functions only
+    # the unscented / augmented kernels take registry functions only
     with pytest.raises(_lib.BayesFiltError):
         bfa.unscented_gaussian_sum_filter(base._replace(dynamics_function=f), bfa.ParamsUKF(1, 0, 0), ys, 1, initial_means=np.zeros((1, 1), F32))
 
@@ -259,17 +259,17 @@ def test_user_model_handle_must_match_the_model(monkeypatch):
     bfa.gaussian_sum_filter(usr, ys, 1, initial_means=im)                      # the matching handle runs
     real = inference._compile_user_model
     # (a) a handle compiled for other dimensions
-    monkeypatch.setattr(inference, "_compile_user_model", lambda d, e, n, dq, m, dr: real(d, e, n + 1, dq + 1, m, dr))
+    monkeypatch.setattr(inference, "_compile_user_model", lambda d, e, n, dq, m, dr, lp=None: real(d, e, n + 1, dq + 1, m, dr))
     with pytest.raises(_lib.BayesFiltError) as e:
         bfa.gaussian_sum_filter(usr, ys, 1, initial_means=im)
     assert e.value.code == _lib.BF_EINVAL and "compiled for" in str(e.value)
     # (b) dyn_id = BF_FN_USER on a handle that holds an emission only
-    monkeypatch.setattr(inference, "_compile_user_model", lambda d, e, n, dq, m, dr: real(None, QUAD_SRC, n, dq, m, dr))
+    monkeypatch.setattr(inference, "_compile_user_model", lambda d, e, n, dq, m, dr, lp=None: real(None, QUAD_SRC, n, dq, m, dr))
     with pytest.raises(_lib.BayesFiltError) as e:
         bfa.gaussian_sum_filter(usr, ys, 1, initial_means=im)
     assert e.value.code == _lib.BF_EINVAL and "without dynamics source" in str(e.value)
     # (c) a handle that holds a function the model does not ask for
-    monkeypatch.setattr(inference, "_compile_user_model", lambda d, e, n, dq, m, dr: real(L63_SRC, QUAD_SRC, n, dq, m, dr))
+    monkeypatch.setattr(inference, "_compile_user_model", lambda d, e, n, dq, m, dr, lp=None: real(L63_SRC, QUAD_SRC, n, dq, m, dr))
     with pytest.raises(_lib.BayesFiltError) as e:
         bfa.gaussian_sum_filter(usr, ys, 1, initial_means=im)
     assert e.value.code == _lib.BF_EINVAL and "emi_id must be BF_FN_USER" in str(e.value)
@@ -304,3 +304,131 @@ print("created")
     r = run()
     assert r.returncode == 0 and "created" in r.stdout, (r.stdout, r.stderr)
     assert (tmp_path / files[0]).read_bytes() == good
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The bootstrap particle filter with functions from source (bf_user_model_create_lp): x' = f(x, q, u) and
+# emission_distribution_log_prob(x', y, u) are arbitrary callables in the reference (gaussfiltax/models.py:73-84,
+# inference.py:1344-1349).
+
+# fBOT / gBOT of docs/experiments/BOT_Experiment_script.py:31-44, operation for operation as the registry functions evaluate
+# them (csrc/ssm_device.hpp: DYN_MANEUVER_BOT, EMI_BEARING_RANGE) -- in the particle-filter kernels sin / cos / atan2 / sqrt
+# of a source function ARE the canonical arithmetic, so the twin reproduces the registry function's bits
+BOT_DYN_SRC = """
+template <class T> __device__ void dynamics(const T* x, const T* q, T u0, const float* th, T* out) {
+  const float dt = th[0], acc = th[1];
+  const T c0 = 0.5f * (u0 - 1.f) * (u0 - 2.f), c1 = -u0 * (u0 - 2.f), c2 = 0.5f * u0 * (u0 - 1.f);
+  T Mx[16] = {c0, c0 * dt, 0, 0, 0, c0, 0, 0, 0, 0, c0, c0 * dt, 0, 0, 0, c0};
+  const T nrm = sqrt(x[1] * x[1] + x[3] * x[3]);
+  T sn0, cs0;
+  sincos(dt * (0.1f * acc / nrm), &sn0, &cs0);
+  for (int sgn = 0; sgn < 2; ++sgn) {
+    const T cc = sgn == 0 ? c1 : c2;
+    const T om = 0.1f * (sgn == 0 ? acc : -acc) / nrm;
+    const T sn = sgn == 0 ? sn0 : -sn0, cs = cs0;
+    const T so = sn / om, co = (1.f - cs) / om;
+    const T Fm[16] = {1, so, 0, -co, 0, cs, 0, -sn, 0, co, 1, so, 0, sn, 0, cs};
+    for (int i = 0; i < 16; ++i) Mx[i] += cc * Fm[i];
+  }
+  const float G[8] = {0.5f, 0, 1, 0, 0, 0.5f, 0, 1};
+  for (int i = 0; i < 4; ++i) {
+    T s = Mx[i * 4] * x[0];
+    for (int k = 1; k < 4; ++k) s = fma(Mx[i * 4 + k], x[k], s);
+    T g = 0.f;
+    for (int k = 0; k < 2; ++k) g = fma(G[i * 2 + k], q[k], g);
+    out[i] = s + g;
+  }
+}
+"""
+BOT_EMI_SRC = """
+template <class T> __device__ void emission(const T* x, const T* r, T u, const float* th, T* out) {
+  out[0] = atan2(x[2], x[0]) + r[0];
+  out[1] = sqrt(x[0] * x[0] + x[2] * x[2]) + r[1];
+}
+"""
+L63_LP_SRC = """
+template <class T> __device__ T log_prob(const T* x, const float* y, T u, const float* th) {   // Laplace density around c |x|^2
+  T s = x[0] * x[0];
+  for (int i = 1; i < BF_N; ++i) s = fma(x[i], x[i], s);
+  const T d = abs(y[0] - th[0] * s);
+  return -d / th[1] - log(2.0f * th[1]);
+}
+"""
+
+
+def _bits_eq(a, b):
+    return np.array_equal(np.ascontiguousarray(a.cpu().numpy(), F32).view(np.uint32), np.ascontiguousarray(b.cpu().numpy(), F32).view(np.uint32))
+
+
+@pytest.mark.parametrize("N", [100, 1000, 4096])
+def test_particle_filter_bot_source_twins_match_the_registry_bit_for_bit(N):
+    import bayesianfiltering_amd as bfa
+    nl = bfa.nonlinearities
+    T, B = 24, 2
+    mu0 = np.array([2.0, 0.3, 3.0, -0.2], F32)
+    S0 = np.diag([0.1, 0.005, 0.1, 0.01]).astype(F32)
+    Q, R = 1e-3 * np.eye(2, dtype=F32), np.diag([1e-3, 1e-2]).astype(F32)
+    r0 = np.array([0.01, -0.02], F32)
+    inputs = np.array([1] * 8 + [0] * 8 + [2] * 8, F32)
+    po = go.ParamsNLSSM(mu0, S0, om.ManeuverBOT(), np.zeros(2, F32), Q, om.BearingRange(), r0, R)
+    ys = np.stack([go.sample_ssm(po, otf.PRNGKey(10 + b), T, inputs.reshape(T, 1))[1] for b in range(B)])
+    g_reg = nl.bearing_range()
+    reg = bfa.ParamsBPF(mu0, S0, nl.maneuver_bot(), np.zeros(2, F32), Q, g_reg, r0, R, nl.gaussian_log_prob(g_reg, R, r0))
+    f_usr = nl.user_dynamics(BOT_DYN_SRC, 4, noise_dim=2, theta=nl.maneuver_bot().theta)
+    g_usr = nl.user_emission(BOT_EMI_SRC, 4, 2)
+    key = np.array([0, 5], np.uint32)
+    # (bpf_hbm_mode = 1: the registry run on the one-workgroup-per-trajectory kernel too -- for few trajectories with thousands
+    # of particles it would otherwise spread the particles over the chip, where the unpinned mean summary sums in another order)
+    a = bfa.bootstrap_particle_filter(reg, ys, N, key, inputs, output="both", return_ancestors=True, options={"bpf_hbm_mode": 1})
+    assert float(a["resampled"].mean()) > 0
+    for usr in (reg._replace(dynamics_function=f_usr),                                                               # f from source
+                reg._replace(emission_function=g_usr, emission_distribution_log_prob=nl.gaussian_log_prob(g_usr, R, r0)),   # h from source
+                reg._replace(dynamics_function=f_usr, emission_function=g_usr,
+                             emission_distribution_log_prob=nl.gaussian_log_prob(g_usr, R, r0))):                  # both
+        b_ = bfa.bootstrap_particle_filter(usr, ys, N, key, inputs, output="both", return_ancestors=True)
+        for k in ("weights", "particles", "mean", "ess", "logz", "resampled"):
+            assert _bits_eq(a[k], b_[k]), k
+        assert np.array_equal(a["ancestors"].cpu().numpy(), b_["ancestors"].cpu().numpy())
+
+
+def test_particle_filter_with_a_log_density_from_source():
+    """A non-Gaussian emission density (Laplace around c |x|^2) on Lorenz-63 dynamics written as source: against a NumPy
+    restatement of the recursion run on the engine's own particles (weights one step at a time), and chunked == one shot."""
+    import torch
+    import bayesianfiltering_amd as bfa
+    nl = bfa.nonlinearities
+    N, T, B = 512, 12, 2
+    Q = 0.1 * np.eye(3, dtype=F32)
+    m0, P0 = np.array([0.0, 1.0, 1.05], F32), np.eye(3, dtype=F32)
+    th = [10.0, 28.0, 2.667, 0.01]
+    c, scale = 0.05, 0.7
+    f_usr = nl.user_dynamics(L63_SRC, 3, theta=th)
+    lp = nl.user_log_prob(L63_LP_SRC, theta=[c, scale])
+    pp = bfa.ParamsBPF(m0, P0, f_usr, np.zeros(3, F32), Q, nl.quadratic(3, c), np.zeros(1, F32), np.eye(1, dtype=F32), lp)
+    po = go.ParamsNLSSM(m0, P0, om.Lorenz63(), np.zeros(3, F32), Q, om.Quadratic(3, c), np.zeros(1, F32), np.eye(1, dtype=F32))
+    ys = np.stack([go.sample_ssm(po, otf.PRNGKey(b), T)[1] for b in range(B)])
+    key = np.array([0, 9], np.uint32)
+    out, carry = bfa.bootstrap_particle_filter(pp, ys, N, key, output="both", ess_threshold=0.0, return_carry=True)   # no resampling: weights compound
+    x = out["particles"].cpu().numpy().astype(np.float64)       # (B, N, T, 3)
+    w = out["weights"].cpu().numpy().astype(np.float64)         # (B, N, T)
+    for b in range(B):
+        wprev = np.full(N, 1.0 / N)
+        for t in range(T):
+            s = np.sum(x[b, :, t] ** 2, axis=1)
+            ll = -np.abs(ys[b, t, 0] - c * s) / scale - np.log(2 * scale)
+            wn = np.exp(ll - ll.max()) * wprev
+            wn /= wn.sum()
+            assert np.max(np.abs(wn - w[b, :, t])) < 2e-5 * max(1.0, w[b, :, t].max() * N) / N + 1e-7, (b, t)
+            wprev = w[b, :, t]
+    # the registry Lorenz-63 with the same density gives the same bits (the source twin of f)
+    reg = pp._replace(dynamics_function=nl.lorenz63(*th))
+    out2 = bfa.bootstrap_particle_filter(reg, ys, N, key, output="both", ess_threshold=0.0)
+    assert _bits_eq(out["particles"], out2["particles"]) and _bits_eq(out["weights"], out2["weights"])
+    # with resampling, in two chunks through the carry
+    one, c1 = bfa.bootstrap_particle_filter(pp, ys, N, key, output="both", return_carry=True)
+    h1, cc = bfa.bootstrap_particle_filter(pp, ys[:, :5], N, key, output="both", return_carry=True)
+    h2, c2 = bfa.bootstrap_particle_filter(pp, ys[:, 5:], N, None, output="both", carry=cc, return_carry=True)
+    assert float(one["resampled"].mean()) > 0
+    assert torch.equal(torch.cat([h1["weights"], h2["weights"]], dim=2), one["weights"])
+    assert torch.equal(torch.cat([h1["particles"], h2["particles"]], dim=2), one["particles"])
+    assert torch.equal(c2.particles, c1.particles)
