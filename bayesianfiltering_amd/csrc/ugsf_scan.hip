@@ -4,8 +4,15 @@
 
 namespace bf {
 
+int launch_ugsf_user_impl(const bf_model* p, const bf_ukf_params* up, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
+                          int K, const bf_carry* carry, const bf_out_desc* out, hipStream_t stream);
+
 int launch_ugsf_ukf(const bf_model* p, const bf_ukf_params* up, const bf_cstream* y, const bf_cstream* u, long long B,
                     long long T, int K, const bf_carry* carry, const bf_out_desc* out, hipStream_t stream) {
+  if (p->user)   // functions from the caller's source: the kernel compiled at run time for this model (user_model.hip)
+    return launch_ugsf_user_impl(p, up, y, u, B, T, K, carry, out, stream);
+  if (p->dyn_id == BF_FN_USER || p->emi_id == BF_FN_USER)
+    return set_error(BF_EINVAL, "dyn_id / emi_id = BF_FN_USER needs bf_model.user (bf_user_model_create)");
 #define BF_CASE(N_, DQ_, M_, DR_)                                                      \
   if (p->n == N_ && p->dq == DQ_ && p->m == M_ && p->dr == DR_)                        \
     return launch_ugsf<N_, DQ_, M_, DR_>(p, up, y, u, B, T, K, carry, out, stream);

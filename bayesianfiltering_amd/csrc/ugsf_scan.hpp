@@ -21,10 +21,12 @@
 // same segmented xor-butterfly (adjacent-pair tree) as in gsf_scan.hpp.  Outputs go out as strided
 // dword stores: a step is ~10^4 VALU operations, the stores are not what bounds it.
 #pragma once
+#ifndef BF_JIT
 #include <cstring>
 #include <cmath>
 #include <vector>
 #include "bf_common.hpp"
+#endif
 #include "kf_math.hpp"
 #include "scan_common.hpp"
 #include "models.hpp"
@@ -46,6 +48,7 @@ struct UkfModel {
   // unscented-transform constants for the update (L = n + dr) and the prediction (L = n + dq)
   float c_u, ws_u, w0_u, wc_u;  // sqrt(L + lambda), 1 / (2 (L + lambda)), lambda / (L + lambda), w0 + 1 - alpha^2 + beta
   float c_p, ws_p, w0_p, wc_p;
+  float uth_dyn[64], uth_emi[64];   // parameters of functions compiled from the caller's source (user_model.hip)
 };
 
 // Symmetric square root of a symmetric positive semi-definite matrix, in place (row-major N x N).
@@ -53,6 +56,7 @@ struct UkfModel {
 // off-diagonal mass is below fp32 resolution; then V diag(sqrt(max(d, 0))) V^T.
 template <int N>
 __device__ __forceinline__ void sym_sqrt(float* a) {
+#pragma clang fp contract(fast)   // (stated, not inherited: a build compiled at run time sets contraction off for the caller's functions)
   if constexpr (N == 1) {
     a[0] = sqrtf(fmaxf(a[0], 0.f));
     return;
@@ -105,15 +109,22 @@ __device__ __forceinline__ void sym_sqrt(float* a) {
 }
 
 // f(x, q, u) of the registry dynamics (noise through the constant F_q)
-template <int N, int DQ, int M, int DR>
+template <class SP = SpecRuntime, int N, int DQ, int M, int DR>
 __device__ __forceinline__ void ukf_dyn(const UkfModel<N, DQ, M, DR>& p, const float* x, const float* q, float u0, float* out) {
-  dyn_value_t<N, DQ>(p, x, q, u0, out);
+  dyn_value_t<N, DQ, UkfModel<N, DQ, M, DR>, SP>(p, x, q, u0, out);   // (SP::user_dyn: the caller's f(x, q, u) from source)
 }
 
 // h(x, r, u) of the registry emissions: g(x, u) + H_r r, or the stochastic-volatility form
 // u beta exp(x / sigma) r + (1 - u)(c x + r)  (docs/experiments/adaptive_experiment.py:51-54)
-template <int N, int DQ, int M, int DR>
+template <class SP = SpecRuntime, int N, int DQ, int M, int DR>
 __device__ __forceinline__ void ukf_emi(const UkfModel<N, DQ, M, DR>& p, const float* x, const float* r, float u0, float* out) {
+#pragma clang fp contract(fast)
+#ifdef BF_USER_EMI
+  if constexpr (SP::user_emi) {   // the caller's h(x, r, u) from source
+    bfu::emission<float>(x, r, u0, p.uth_emi, out);
+    return;
+  }
+#endif
   if (p.emi_id == EMI_STOCH_VOL) {
     if constexpr (M == N && DR == N) {
       const float sigma = p.eth[0], beta = p.eth[1], c = p.eth[2];
@@ -136,9 +147,10 @@ __device__ __forceinline__ void ukf_emi(const UkfModel<N, DQ, M, DR>& p, const f
 // _ukf_condition_on_nonadditive (inference.py:198-224): m, P <- posterior; returns the log-likelihood.
 // sR: sqrtm of this step's emission noise covariance (mdl.sR, or row t of the per-step table when R is (T, dr, dr):
 // inference.py:416 picks R_t before the step, :206-209 take the square root of blockdiag(P, R_t))
-template <int N, int DQ, int M, int DR>
+template <class SP = SpecRuntime, int N, int DQ, int M, int DR>
 __device__ __forceinline__ float ukf_condition_on(const UkfModel<N, DQ, M, DR>& mdl, float* m, float* P, const float* yv, float u0,
                                                   const float* sR) {
+#pragma clang fp contract(fast)
   constexpr int EP = N * N;
   float ll;
 
@@ -146,7 +158,7 @@ __device__ __forceinline__ float ukf_condition_on(const UkfModel<N, DQ, M, DR>& 
   BF_UNROLL for (int i = 0; i < EP; ++i) sP[i] = P[i];
   sym_sqrt<N>(sP);
   float h0[M], mu[M];
-  ukf_emi(mdl, m, mdl.r0, u0, h0);
+  ukf_emi<SP>(mdl, m, mdl.r0, u0, h0);
   // visits the 2 L sigma points in the order of utils.py:251-253: the plus rows, then the minus rows.  The points are
   // needed twice (mean, then covariances about the mean): small problems keep the 2 L images h(x) in registers, large
   // ones push the points through h again (2 L M floats would not fit)
@@ -165,7 +177,7 @@ __device__ __forceinline__ float ukf_condition_on(const UkfModel<N, DQ, M, DR>& 
           x[i] = m[i] + dx[i];
         }
         if constexpr (eval) {
-          ukf_emi(mdl, x, mdl.r0, u0, yy);
+          ukf_emi<SP>(mdl, x, mdl.r0, u0, yy);
           if constexpr (STORE) BF_UNROLL for (int a = 0; a < M; ++a) img[pt * M + a] = yy[a];
         } else {
           BF_UNROLL for (int a = 0; a < M; ++a) yy[a] = img[pt * M + a];
@@ -178,7 +190,7 @@ __device__ __forceinline__ float ukf_condition_on(const UkfModel<N, DQ, M, DR>& 
         BF_UNROLL for (int i = 0; i < DR; ++i) r[i] = mdl.r0[i] + cs * sR[j * DR + i];
         BF_UNROLL for (int i = 0; i < N; ++i) dx[i] = 0.f;
         if constexpr (eval) {
-          ukf_emi(mdl, m, r, u0, yy);
+          ukf_emi<SP>(mdl, m, r, u0, yy);
           if constexpr (STORE) BF_UNROLL for (int a = 0; a < M; ++a) img[pt * M + a] = yy[a];
         } else {
           BF_UNROLL for (int a = 0; a < M; ++a) yy[a] = img[pt * M + a];
@@ -230,15 +242,16 @@ __device__ __forceinline__ float ukf_condition_on(const UkfModel<N, DQ, M, DR>& 
 }
 
 // _ukf_predict_nonadditive (inference.py:146-174): m, P <- predicted mean and covariance.  sQ: sqrtm(Q_t), as sR above
-template <int N, int DQ, int M, int DR>
+template <class SP = SpecRuntime, int N, int DQ, int M, int DR>
 __device__ __forceinline__ void ukf_predict(const UkfModel<N, DQ, M, DR>& mdl, float* m, float* P, float u0, const float* sQ) {
+#pragma clang fp contract(fast)
   constexpr int EP = N * N;
 
   float sP[EP];
   BF_UNROLL for (int i = 0; i < EP; ++i) sP[i] = P[i];
   sym_sqrt<N>(sP);
   float f0[N], mu[N];
-  ukf_dyn(mdl, m, mdl.q0, u0, f0);
+  ukf_dyn<SP>(mdl, m, mdl.q0, u0, f0);
   constexpr int NPTS = 2 * (N + DQ);
   constexpr bool STORE = NPTS * N <= 96;  // keep the 2 L images f(x) in registers instead of evaluating f twice
   float img[STORE ? NPTS * N : 1];
@@ -251,7 +264,7 @@ __device__ __forceinline__ void ukf_predict(const UkfModel<N, DQ, M, DR>& mdl, f
         float x[N], xx[N];
         if constexpr (eval) {
           BF_UNROLL for (int i = 0; i < N; ++i) x[i] = m[i] + cs * sP[j * N + i];
-          ukf_dyn(mdl, x, mdl.q0, u0, xx);
+          ukf_dyn<SP>(mdl, x, mdl.q0, u0, xx);
           if constexpr (STORE) BF_UNROLL for (int i = 0; i < N; ++i) img[pt * N + i] = xx[i];
         } else {
           BF_UNROLL for (int i = 0; i < N; ++i) xx[i] = img[pt * N + i];
@@ -263,7 +276,7 @@ __device__ __forceinline__ void ukf_predict(const UkfModel<N, DQ, M, DR>& mdl, f
         float q[DQ], xx[N];
         if constexpr (eval) {
           BF_UNROLL for (int i = 0; i < DQ; ++i) q[i] = mdl.q0[i] + cs * sQ[j * DQ + i];
-          ukf_dyn(mdl, m, q, u0, xx);
+          ukf_dyn<SP>(mdl, m, q, u0, xx);
           if constexpr (STORE) BF_UNROLL for (int i = 0; i < N; ++i) img[pt * N + i] = xx[i];
         } else {
           BF_UNROLL for (int i = 0; i < N; ++i) xx[i] = img[pt * N + i];
@@ -289,11 +302,11 @@ __device__ __forceinline__ void ukf_predict(const UkfModel<N, DQ, M, DR>& mdl, f
   BF_UNROLL for (int i = 0; i < N; ++i) m[i] = mu[i];
 }
 
-template <int N, int DQ, int M, int DR>
-__global__ void __launch_bounds__(256)
-ugsf_scan_kernel(const UkfModel<N, DQ, M, DR>* __restrict__ mdlp, CView y, const float* __restrict__ uptr, long long u_sB,
+template <int N, int DQ, int M, int DR, class SP = SpecRuntime>
+__device__ __forceinline__ void ugsf_scan_body(const UkfModel<N, DQ, M, DR>* __restrict__ mdlp, CView y, const float* __restrict__ uptr, long long u_sB,
                  long long u_sT, CarryView carry, OutViews out, long long B, long long T, int K, int KP,
                  const float* __restrict__ tvsq, const float* __restrict__ tvsr) {
+#pragma clang fp contract(fast)
   const UkfModel<N, DQ, M, DR>& mdl = *mdlp;
   constexpr int EP = N * N;
   const int tid = threadIdx.x;
@@ -336,7 +349,7 @@ ugsf_scan_kernel(const UkfModel<N, DQ, M, DR>* __restrict__ mdlp, CView y, const
     float ll;
 
     // ================= _ukf_condition_on_nonadditive (inference.py:198-224)
-    ll = ukf_condition_on(mdl, m, P, yv, u0, tvsr ? tvsr + t * (DR * DR) : mdl.sR);
+    ll = ukf_condition_on<SP>(mdl, m, P, yv, u0, tvsr ? tvsr + t * (DR * DR) : mdl.sR);
 
     // ================= reweight (inference.py:424-427)
     {
@@ -354,7 +367,7 @@ ugsf_scan_kernel(const UkfModel<N, DQ, M, DR>* __restrict__ mdlp, CView y, const
     }
 
     // ================= _ukf_predict_nonadditive (inference.py:146-174)
-    ukf_predict(mdl, m, P, u0, tvsq ? tvsq + t * (DQ * DQ) : mdl.sQ);
+    ukf_predict<SP>(mdl, m, P, u0, tvsq ? tvsq + t * (DQ * DQ) : mdl.sQ);
     if (chain_ok) {
       if (out.pm.p) BF_UNROLL for (int i = 0; i < N; ++i) out.pm.p[b * out.pm.sB + k * out.pm.sK + t * out.pm.sT + i * out.pm.sE] = m[i];
       if (out.pP.p) BF_UNROLL for (int i = 0; i < EP; ++i) out.pP.p[b * out.pP.sB + k * out.pP.sK + t * out.pP.sT + i * out.pP.sE] = P[i];
@@ -368,6 +381,15 @@ ugsf_scan_kernel(const UkfModel<N, DQ, M, DR>* __restrict__ mdlp, CView y, const
   }
 }
 
+template <int N, int DQ, int M, int DR>
+__global__ void __launch_bounds__(256)
+ugsf_scan_kernel(const UkfModel<N, DQ, M, DR>* __restrict__ mdlp, CView y, const float* __restrict__ uptr, long long u_sB,
+                 long long u_sT, CarryView carry, OutViews out, long long B, long long T, int K, int KP,
+                 const float* __restrict__ tvsq, const float* __restrict__ tvsr) {
+  ugsf_scan_body<N, DQ, M, DR, SpecRuntime>(mdlp, y, uptr, u_sB, u_sT, carry, out, B, T, K, KP, tvsq, tvsr);
+}
+
+#ifndef BF_JIT   // host side
 // ---------------------------------------------------------------------------------------
 // host: symmetric square root in double precision (cyclic Jacobi), rounded to fp32
 static inline void host_sym_sqrt(const float* A, int n, float* out) {
@@ -427,24 +449,49 @@ static inline int upload_table(const std::vector<float>& v, hipStream_t stream, 
 
 // tvsq / tvsr: filled with sqrtm(Q_t) / sqrtm(R_t), one matrix per step, when p->Q_steps / p->R_steps > 1
 // (inference.py:414-417: the step's covariances are picked by _get_params before the unscented transforms)
-template <int N, int DQ, int M, int DR>
-static inline int fill_ukf_model(const bf_model* p, const bf_ukf_params* up, UkfModel<N, DQ, M, DR>& e,
-                                 std::vector<float>* tvsq = nullptr, std::vector<float>* tvsr = nullptr) {
-  std::memset(&e, 0, sizeof(e));
+// The fields of a UkfModel<N, DQ, M, DR> by address for dimensions known at run time (4-byte members, declaration order, no
+// padding: see BpfModelView in ssm_device.hpp).  user_flags: bit 0 = dynamics, bit 1 = emission from the caller's source.
+struct UkfModelView {
+  int N, DQ, M, DR;
+  int *dyn_id, *emi_id, *g_identity, *d_identity;
+  float *dth, *eth, *A, *Gm, *Hm, *Dm, *q0, *r0, *sQ, *sR, *cu, *cp, *uth_dyn, *uth_emi;
+};
+constexpr size_t ukf_model_words(int n, int dq, int m, int dr) {
+  return 4 + 16 + (size_t)n * n + (size_t)n * dq + (size_t)m * n + (size_t)m * dr + dq + dr + (size_t)dq * dq + (size_t)dr * dr + 8 + 128;
+}
+static inline UkfModelView ukf_model_view_flat(uint32_t* w, int n, int dq, int m, int dr) {
+  UkfModelView v;
+  v.N = n; v.DQ = dq; v.M = m; v.DR = dr;
+  int* iw = reinterpret_cast<int*>(w);
+  v.dyn_id = iw; v.emi_id = iw + 1; v.g_identity = iw + 2; v.d_identity = iw + 3;
+  float* f = reinterpret_cast<float*>(w) + 4;
+  auto take = [&](size_t k) { float* r = f; f += k; return r; };
+  v.dth = take(8); v.eth = take(8); v.A = take((size_t)n * n); v.Gm = take((size_t)n * dq); v.Hm = take((size_t)m * n); v.Dm = take((size_t)m * dr);
+  v.q0 = take(dq); v.r0 = take(dr); v.sQ = take((size_t)dq * dq); v.sR = take((size_t)dr * dr); v.cu = take(4); v.cp = take(4);
+  v.uth_dyn = take(64); v.uth_emi = take(64);
+  return v;
+}
+
+static inline int fill_ukf_model_view(const bf_model* p, const bf_ukf_params* up, UkfModelView e, int user_flags,
+                                      std::vector<float>* tvsq = nullptr, std::vector<float>* tvsr = nullptr) {
+  const int N = e.N, DQ = e.DQ, M = e.M, DR = e.DR;
   if ((p->Q_steps > 1 && !tvsq) || (p->R_steps > 1 && !tvsr))
     return set_error(BF_EUNSUPPORTED, "time-varying Q/R are not supported on this path");
   if (p->flags != 0) return set_error(BF_EUNSUPPORTED, "legacy-class flags do not apply to the unscented filter");
-  e.dyn_id = p->dyn_id;
-  e.emi_id = p->emi_id;
-  e.g_identity = 1;
-  e.d_identity = 1;
+  *e.dyn_id = p->dyn_id;
+  *e.emi_id = p->emi_id;
+  *e.g_identity = 1;
+  *e.d_identity = 1;
   const float* th = p->dyn_theta;
-  switch (p->dyn_id) {
+  if (user_flags & 1) {
+    if (p->n_dyn_theta > 64) return set_error(BF_EUNSUPPORTED, "a dynamics function from source takes at most 64 parameters here");
+    for (int i = 0; i < p->n_dyn_theta; ++i) e.uth_dyn[i] = th[i];
+  } else switch (p->dyn_id) {
     case DYN_LINEAR:
       if (p->n_dyn_theta != N * N + N * DQ) return set_error(BF_EINVAL, "linear dynamics: theta must hold A and G");
       for (int i = 0; i < N * N; ++i) e.A[i] = th[i];
       for (int i = 0; i < N * DQ; ++i) e.Gm[i] = th[N * N + i];
-      e.g_identity = 0;
+      *e.g_identity = 0;
       break;
     case DYN_LORENZ96:
       if (p->n_dyn_theta != 5 || DQ != N) return set_error(BF_EINVAL, "lorenz96: theta = (alpha, beta, gamma, dt, mode), dq = n");
@@ -460,7 +507,7 @@ static inline int fill_ukf_model(const bf_model* p, const bf_ukf_params* up, Ukf
       e.dth[1] = th[1];
       const float Gb[8] = {0.5f, 0, 1, 0, 0, 0.5f, 0, 1};
       for (int i = 0; i < 8 && i < N * DQ; ++i) e.Gm[i] = Gb[i];
-      e.g_identity = 0;
+      *e.g_identity = 0;
     } break;
     case DYN_SINE:
       if (p->n_dyn_theta != 1 || DQ != N) return set_error(BF_EINVAL, "sine: theta = (w0), dq = n");
@@ -472,12 +519,15 @@ static inline int fill_ukf_model(const bf_model* p, const bf_ukf_params* up, Ukf
     default: return set_error(BF_EUNSUPPORTED, "unknown dynamics function id %d", p->dyn_id);
   }
   th = p->emi_theta;
-  switch (p->emi_id) {
+  if (user_flags & 2) {
+    if (p->n_emi_theta > 64) return set_error(BF_EUNSUPPORTED, "an emission function from source takes at most 64 parameters here");
+    for (int i = 0; i < p->n_emi_theta; ++i) e.uth_emi[i] = th[i];
+  } else switch (p->emi_id) {
     case EMI_LINEAR:
       if (p->n_emi_theta != M * N + M * DR) return set_error(BF_EINVAL, "linear emission: theta must hold H and D");
       for (int i = 0; i < M * N; ++i) e.Hm[i] = th[i];
       for (int i = 0; i < M * DR; ++i) e.Dm[i] = th[M * N + i];
-      e.d_identity = 0;
+      *e.d_identity = 0;
       break;
     case EMI_BEARING_RANGE:
       if (N != 4 || M != 2 || DR != 2) return set_error(BF_EINVAL, "bearing_range: n = 4, m = dr = 2");
@@ -515,9 +565,17 @@ static inline int fill_ukf_model(const bf_model* p, const bf_ukf_params* up, Ukf
     w0 = lam / (lam + (float)L);
     wc = w0 + 1.0f - a2 + up->beta;
   };
-  consts(N + DR, e.c_u, e.ws_u, e.w0_u, e.wc_u);
-  consts(N + DQ, e.c_p, e.ws_p, e.w0_p, e.wc_p);
+  consts(N + DR, e.cu[0], e.cu[1], e.cu[2], e.cu[3]);
+  consts(N + DQ, e.cp[0], e.cp[1], e.cp[2], e.cp[3]);
   return BF_OK;
+}
+
+template <int N, int DQ, int M, int DR>
+static inline int fill_ukf_model(const bf_model* p, const bf_ukf_params* up, UkfModel<N, DQ, M, DR>& e,
+                                 std::vector<float>* tvsq = nullptr, std::vector<float>* tvsr = nullptr) {
+  static_assert(sizeof(UkfModel<N, DQ, M, DR>) == 4 * ukf_model_words(N, DQ, M, DR), "UkfModel: 4-byte members in declaration order, no padding");
+  std::memset(&e, 0, sizeof(e));
+  return fill_ukf_model_view(p, up, ukf_model_view_flat(reinterpret_cast<uint32_t*>(&e), N, DQ, M, DR), 0, tvsq, tvsr);
 }
 
 template <int N, int DQ, int M, int DR>
@@ -551,5 +609,7 @@ static inline int launch_ugsf(const bf_model* p, const bf_ukf_params* up, const 
   BF_HIP_CHECK(hipGetLastError());
   return BF_OK;
 }
+
+#endif  // BF_JIT
 
 }  // namespace bf

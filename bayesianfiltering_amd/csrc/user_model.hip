@@ -22,6 +22,7 @@
 #include <vector>
 #include "bf_common.hpp"
 #include "bpf_scan.hpp"   // BpfArgs / BpfCarry / BpfOut, the run-time-dimension model fill
+#include "ugsf_scan.hpp"  // UkfModelView, fill_ukf_model_view
 
 #ifndef BF_ARCH_NAME
 #define BF_ARCH_NAME "gfx950"
@@ -35,6 +36,7 @@ struct bf_user_model {
   bool has_dyn = false, has_emi = false, has_lp = false;
   std::string dyn_src, emi_src, lp_src;  // kept: the particle-filter kernels are built on first use, per particle capacity
   std::map<int, hipFunction_t> bpf;       // key = PPT * 100 + NW
+  hipFunction_t ugsf = nullptr;           // the unscented Gaussian-sum scan, built on first use
   std::vector<hipModule_t> extra_mods;
 };
 
@@ -42,7 +44,8 @@ namespace bf {
 
 extern const char* const kGenericDeviceSource;  // generic_device.hpp, embedded at build time (jit_sources.hip)
 extern const char* const kSamplingSourceA;      // kf_math.hpp + bf_canon_math.hpp
-extern const char* const kSamplingSourceB;      // scan_common / bf_rng / models / ssm_device / bpf_scan
+extern const char* const kSamplingSourceB;
+extern const char* const kUgsfSource;           // ugsf_scan.hpp      // scan_common / bf_rng / models / ssm_device / bpf_scan
 
 namespace {
 
@@ -279,14 +282,16 @@ void write_file_atomically(const std::string& path, const std::vector<char>& cod
   }
 }
 
-int compile_with_hiprtc(const std::string& src, std::vector<char>& code) {
+int compile_with_hiprtc(const std::string& src, std::vector<char>& code, bool contract_off = true) {
   std::string why;
   if (!load_rtc(why)) return set_error(BF_EUNSUPPORTED, "hiprtc is not available: %.400s", why.c_str());
   hiprtcProgram prog = nullptr;
   int rc = g_rtc.CreateProgram(&prog, src.c_str(), "bf_user_model.hip", 0, nullptr, nullptr);
   if (rc != 0) return set_error(BF_EHIP, "hiprtcCreateProgram failed (%d)", rc);
+  // (contract_off = false: the translation unit keeps hipcc's default contraction -- what the ahead-of-time build of the same
+  // kernel was compiled with -- and the source itself switches contraction off around the caller's functions)
   const char* opts[] = {"--offload-arch=" BF_ARCH_NAME, "-O3", "-std=c++17", "-ffp-contract=off"};
-  rc = g_rtc.CompileProgram(prog, 4, opts);
+  rc = g_rtc.CompileProgram(prog, contract_off ? 4 : 3, opts);
   if (rc != 0) {
     size_t ls = 0;
     std::string log;
@@ -322,7 +327,7 @@ hipError_t load_module(bf_user_model* um, const std::vector<char>& code) {
 }
 
 // source -> code object through the disk cache (a cached file that does not load is deleted and rebuilt) -> one kernel
-int build_function(const std::string& src, const char* kernel_name, hipModule_t* mod, hipFunction_t* fn) {
+int build_function(const std::string& src, const char* kernel_name, hipModule_t* mod, hipFunction_t* fn, bool contract_off = true) {
   int rtver = 0;
   (void)hipRuntimeGetVersion(&rtver);
   char key[32];
@@ -350,7 +355,7 @@ int build_function(const std::string& src, const char* kernel_name, hipModule_t*
     }
   }
   if (code.empty()) {
-    const int rc = compile_with_hiprtc(src, code);
+    const int rc = compile_with_hiprtc(src, code, contract_off);
     if (rc != BF_OK) return rc;
     write_file_atomically(path, code);
     e = load();
@@ -367,8 +372,8 @@ int build_function(const std::string& src, const char* kernel_name, hipModule_t*
 // weight path (bf_canon_math.hpp: sin / cos / atan2 / exp / log as defined there, IEEE sqrt, no contraction), so a function
 // written like its registry twin gives the registry twin's bits.
 const char* const kSamplingUserMath = R"BFSRC(
+#pragma clang fp contract(off)   // no contraction in the caller's functions, as in the registry's
 namespace bfu {
-#pragma clang fp contract(off)
 __device__ inline float sin(float x) { return bf::canon_sin(x); }
 __device__ inline float cos(float x) { float s, c; bf::canon_sincos(x, &s, &c); return c; }
 __device__ inline void sincos(float x, float* s, float* c) { bf::canon_sincos(x, s, c); }
@@ -381,14 +386,17 @@ __device__ inline float abs(float x) { return __builtin_fabsf(x); }
 __device__ inline float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 )BFSRC";
 
-std::string build_bpf_source(const bf_user_model* um, int ppt, int nw) {
+std::string build_bpf_source(const bf_user_model* um, int ppt, int nw, bool ugsf = false) {
   std::string s = "#define BF_JIT 1\n#include <cstdint>\n#include <type_traits>\n";
   if (um->has_dyn) s += "#define BF_USER_DYN 1\n";
   if (um->has_emi) s += "#define BF_USER_EMI 1\n";
   if (um->has_lp) s += "#define BF_USER_LP 1\n";
   s += "#define BF_N " + std::to_string(um->n) + "\n#define BF_DQ " + std::to_string(um->dq) + "\n#define BF_M " + std::to_string(um->m) +
        "\n#define BF_DR " + std::to_string(um->dr) + "\n";
-  s += "namespace bf { struct CView { const float* p; long long sB, sT, sE; }; }\n";
+  s += "namespace bf { struct CView { const float* p; long long sB, sT, sE; };\n"
+       "struct SView { float* p; long long sB, sK, sT, sE; };\n"
+       "struct OutViews { SView w, m, P, pm, pP, ll; SView cm, cP; };\n"
+       "struct CarryView { const float* w_in; const float* m_in; const float* P_in; float* w_out; float* m_out; float* P_out; }; }\n";
   s += kSamplingSourceA;
   s += kSamplingUserMath;
   s += "\n// ---- the caller's functions\n";
@@ -399,6 +407,14 @@ std::string build_bpf_source(const bf_user_model* um, int ppt, int nw) {
   s += kSamplingSourceB;
   const std::string spec = std::string("bf::SpecUser<") + (um->has_dyn ? "true" : "false") + ", " + (um->has_emi ? "true" : "false") + ", " +
                            (um->has_lp ? "true" : "false") + ">";
+  if (ugsf) {
+    s += kUgsfSource;
+    s += "extern \"C\" __global__ void __launch_bounds__(256) bf_user_ugsf(const bf::UkfModel<BF_N, BF_DQ, BF_M, BF_DR>* __restrict__ mdlp, bf::CView y, "
+         "const float* __restrict__ uptr, long long u_sB, long long u_sT, bf::CarryView carry, bf::OutViews out, long long B, long long T, int K, int KP, "
+         "const float* __restrict__ tvsq, const float* __restrict__ tvsr) {\n  bf::ugsf_scan_body<BF_N, BF_DQ, BF_M, BF_DR, " + spec +
+         ">(mdlp, y, uptr, u_sB, u_sT, carry, out, B, T, K, KP, tvsq, tvsr);\n}\n";
+    return s;
+  }
   s += "extern \"C\" __global__ void __launch_bounds__(" + std::to_string(64 * nw) + ") bf_user_bpf(const bf::BpfModel<BF_N, BF_DQ, BF_M>* __restrict__ mdlp, "
        "const bf::BpfArgs<BF_N, BF_DQ, BF_M> args_by_value) {\n  (void)args_by_value;\n  bf::bpf_scan_body<BF_N, BF_DQ, BF_M, " +
        std::to_string(ppt) + ", " + std::to_string(nw) + ", " + spec + ">(mdlp);\n}\n";
@@ -467,6 +483,56 @@ int launch_bpf_user_impl(const bf_bpf_model* bp, const bf_cstream* y, const bf_c
   size_t psz = sizeof(packed);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &packed, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psz, HIP_LAUNCH_PARAM_END};
   BF_HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)B, 1, 1, (unsigned)(64 * nw), 1, 1, (unsigned)lds_bytes, stream, nullptr, config));
+  return BF_OK;
+}
+
+
+// The unscented Gaussian-sum scan (ugsf_scan.hpp: a lane per (trajectory, component), sigma points through f and h) with the
+// caller's functions: state in registers, so the state dimension is bounded like the compiled instances' (n <= 8)
+int launch_ugsf_user_impl(const bf_model* p, const bf_ukf_params* up, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
+                          int K, const bf_carry* carry, const bf_out_desc* out, hipStream_t stream) {
+  bf_user_model* um = const_cast<bf_user_model*>(p->user);
+  int rc = check_user_model(um, p);
+  if (rc != BF_OK) return rc;
+  if (um->has_lp) return set_error(BF_EINVAL, "a log-density from source belongs to the particle filter, not to the unscented filter");
+  if (p->n > 8 || p->dq > 8 || p->m > 8 || p->dr > 8)
+    return set_error(BF_EUNSUPPORTED, "unscented filter with functions from source: dimensions up to 8 (the sigma points live in registers)");
+  int dev = -1;
+  (void)hipGetDevice(&dev);
+  if (dev != um->device) return set_error(BF_EINVAL, "bf_model.user was loaded on device %d, the current device is %d", um->device, dev);
+  if ((p->Q_steps > 1 && p->Q_steps != T) || (p->R_steps > 1 && p->R_steps != T))
+    return set_error(BF_EINVAL, "time-varying covariances need one matrix per step (Q_steps / R_steps = T = %lld)", T);
+  int KP = 1;
+  while (KP < K) KP <<= 1;
+  if (KP > 256) return set_error(BF_EUNSUPPORTED, "unscented Gaussian-sum filter: %d components exceed one workgroup (256 lanes)", K);
+  if (out->coll_mean.ptr || out->coll_cov.ptr) return set_error(BF_EUNSUPPORTED, "collapsed streams are produced by bf_gsf_ekf_f32 only");
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!um->ugsf) {
+      hipModule_t mod = nullptr;
+      rc = build_function(build_bpf_source(um, 0, 0, true), "bf_user_ugsf", &mod, &um->ugsf);
+      if (rc != BF_OK) return rc;
+      um->extra_mods.push_back(mod);
+    }
+  }
+  std::vector<uint32_t> words(ukf_model_words(p->n, p->dq, p->m, p->dr), 0u);
+  std::vector<float> tvsq, tvsr;
+  rc = fill_ukf_model_view(p, up, ukf_model_view_flat(words.data(), p->n, p->dq, p->m, p->dr), (um->has_dyn ? 1 : 0) | (um->has_emi ? 2 : 0), &tvsq, &tvsr);
+  if (rc != BF_OK) return rc;
+  const void* dv = nullptr;
+  rc = device_constants(words.data(), sizeof(uint32_t) * words.size(), stream, &dv);
+  if (rc != BF_OK) return rc;
+  const float *d_tvsq = nullptr, *d_tvsr = nullptr;
+  if ((rc = upload_table(tvsq, stream, &d_tvsq)) != BF_OK || (rc = upload_table(tvsr, stream, &d_tvsr)) != BF_OK) return rc;
+  CView yv{y->ptr, y->sB, y->sT, y->sE};
+  CarryView cv{carry->w_in, carry->m_in, carry->P_in, carry->w_out, carry->m_out, carry->P_out};
+  OutViews ov{make_sview(out->weights), make_sview(out->means), make_sview(out->covs),
+              make_sview(out->pred_means), make_sview(out->pred_covs), make_sview(out->loglik)};
+  const float* uptr = (u && u->ptr) ? u->ptr : nullptr;
+  long long u_sB = u ? u->sB : 0, u_sT = u ? u->sT : 0;
+  void* args[] = {&dv, &yv, &uptr, &u_sB, &u_sT, &cv, &ov, &B, &T, &K, &KP, &d_tvsq, &d_tvsr};
+  const int tpb = 256 / KP;
+  BF_HIP_CHECK(hipModuleLaunchKernel(um->ugsf, (unsigned)((B + tpb - 1) / tpb), 1, 1, 256, 1, 1, 0, stream, args, nullptr));
   return BF_OK;
 }
 
