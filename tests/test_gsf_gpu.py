@@ -20,7 +20,7 @@ def _nl():
     return bfa, bfa.nonlinearities
 
 
-def _check(post, ref, ll=None, ref_ll=None, tol=TOL, wtol=2e-5, etol=1e-4):
+def _check(post, ref, ll=None, ref_ll=None, tol=TOL, wtol=2e-5, etol=3e-5):
     for k in FIELDS:
         got = getattr(post, k).cpu().numpy()
         exp = getattr(ref, k) if hasattr(ref, "_fields") else ref[k]
