@@ -23,7 +23,7 @@ int launch_kf_group(const bf_lgssm* p, const bf_cstream* y, long long B, long lo
                     const bf_out_desc* out, hipStream_t stream, int force_mode, int lanes);
 
 int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
-                   const bf_out_desc* out, hipStream_t stream);
+                   const bf_out_desc* out, hipStream_t stream, int K, bool multi);
 int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry, const bf_out_desc* out,
                    hipStream_t stream, int K, bool multi);
 int launch_kf_generic(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
@@ -234,7 +234,7 @@ int bf_kalman_filter_f32(const bf_lgssm* model, const bf_cstream* y, int64_t B, 
   if (model->n >= 9 && model->n <= 32 && model->m <= 32 && (model->n >= 16 || model->m > 8) && bf::g_kf_small_mode.load() != 0)
     return bf::with_generic_fallback(bf::launch_kf_bf32(model, y, B, T, carry, out, hs, 1, false), generic);
   if (model->n >= 24 && model->n <= 64 && model->m <= 32)
-    return bf::with_generic_fallback(bf::launch_kf_mfma(model, y, B, T, carry, out, hs), generic);
+    return bf::with_generic_fallback(bf::launch_kf_mfma(model, y, B, T, carry, out, hs, 1, false), generic);
   return bf::with_generic_fallback(
       bf::launch_kf_group(model, y, B, T, carry, out, hs, bf::g_kf_emit_mode.load(), bf::g_kf_lanes.load()), generic);
 }
@@ -253,11 +253,14 @@ int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream*
   auto generic = [&]() { return bf::launch_gsf_generic(model, y, u, B, T, K, carry, out, hs); };
   if (model->user || model->dyn_id == BF_FN_USER || model->emi_id == BF_FN_USER) return generic();  // compiled from source
   if (bf::g_force_generic.load()) return generic();
-  // a LINEAR model beyond the register kernels (n >= 9): the Gaussian-sum filter's K components take turns on the one-wave
-  // matrix-core kernel (single 32 x 32 tiles, bf16 three-term products), per-step Q_t / R_t tables included
-  if (model->dyn_id == 0 && model->emi_id == 0 && model->flags == 0 && model->n >= 9 && model->n <= 32 && model->m <= 32 &&
-      (model->n >= 16 || model->m > 8) && K <= 64 && !out->coll_mean.ptr && !out->coll_cov.ptr && bf::g_kf_small_mode.load() != 0 &&
-      model->n_dyn_theta == model->n * model->n + model->n * model->dq && model->n_emi_theta == model->m * model->n + model->m * model->dr) {
+  // a LINEAR model beyond the register kernels (n >= 9): the Gaussian-sum filter's K components take turns on the matrix-core
+  // kernels (bf16 three-term products: one wave per trajectory on single 32 x 32 tiles up to n = 32, four waves on 64 x 64 up
+  // to n = 64), per-step Q_t / R_t tables included
+  const bool small_tiles = model->n >= 9 && model->n <= 32 && model->m <= 32 && (model->n >= 16 || model->m > 8) && bf::g_kf_small_mode.load() != 0;
+  const bool big_tiles = !small_tiles && model->n >= 24 && model->n <= 64 && model->m <= 32;
+  if (model->dyn_id == 0 && model->emi_id == 0 && model->flags == 0 && (small_tiles || big_tiles) && K <= 64 && !out->coll_mean.ptr &&
+      !out->coll_cov.ptr && model->n_dyn_theta == model->n * model->n + model->n * model->dq &&
+      model->n_emi_theta == model->m * model->n + model->m * model->dr) {
     bf_lgssm lg;
     std::memset(&lg, 0, sizeof(lg));
     lg.n = model->n; lg.dq = model->dq; lg.m = model->m; lg.dr = model->dr;
@@ -265,7 +268,8 @@ int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream*
     lg.H = model->emi_theta; lg.D = model->emi_theta + model->m * model->n;
     lg.q0 = model->q0; lg.r0 = model->r0; lg.Q = model->Q; lg.R = model->R;
     lg.Q_steps = model->Q_steps > 0 ? model->Q_steps : 1; lg.R_steps = model->R_steps > 0 ? model->R_steps : 1;
-    return bf::with_generic_fallback(bf::launch_kf_bf32(&lg, y, B, T, carry, out, hs, K, K > 1), generic);
+    if (small_tiles) return bf::with_generic_fallback(bf::launch_kf_bf32(&lg, y, B, T, carry, out, hs, K, K > 1), generic);
+    return bf::with_generic_fallback(bf::launch_kf_mfma(&lg, y, B, T, carry, out, hs, K, K > 1), generic);   // 33 <= n <= 64: four waves per trajectory
   }
   return bf::with_generic_fallback(
       bf::launch_gsf_ekf(model, y, u, B, T, K, carry, out, hs, bf::g_kf_emit_mode.load(), bf::g_kf_lanes.load()), generic);

@@ -906,10 +906,10 @@ __device__ __forceinline__ gl_f* per_step(float* p) { return (gl_f*)p + opaque_s
 __device__ __forceinline__ gl_cf* per_step(const float* p) { return (gl_cf*)p + opaque_szero(); }
 // one 32x32 accumulator tile (pi, pj) of a [N][N] stream entry at (b, t)
 template <int N>
-__device__ __forceinline__ void store_tile(const SView& sv, long long b, long long t, int pi, int pj, int lane, const f32x16& acc) {
+__device__ __forceinline__ void store_tile(const SView& sv, long long b, long long t, int pi, int pj, int lane, const f32x16& acc, int k = 0) {
   if (!sv.p) return;
   const int lr = lane & 31, lk = lane >> 5;
-  gl_f* base = per_step(sv.p + b * sv.sB + t * sv.sT);
+  gl_f* base = per_step(sv.p + b * sv.sB + k * sv.sK + t * sv.sT);
   const unsigned e0 = (unsigned)((32 * pi + 4 * lk) * N + 32 * pj + lr);
   if (sv.sE == 1) {
     BF_UNROLL for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(acc[r], base + (e0 + ((r & 3) + 8 * (r >> 2)) * N));
@@ -1107,11 +1107,11 @@ kf_scan_mfma2_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
 // store_tile for a model of nr <= N states riding zero-padded in the N x N tiles: entries (row, col) with both < nr, at the
 // model's own row length
 template <int N>
-__device__ __forceinline__ void store_tile_n(const SView& sv, long long b, long long t, int pi, int pj, int lane, const f32x16& acc, int nr) {
-  if (nr == N) return store_tile<N>(sv, b, t, pi, pj, lane, acc);
+__device__ __forceinline__ void store_tile_n(const SView& sv, long long b, long long t, int pi, int pj, int lane, const f32x16& acc, int nr, int k = 0) {
+  if (nr == N) return store_tile<N>(sv, b, t, pi, pj, lane, acc, k);
   if (!sv.p) return;
   const int lr = lane & 31, lk = lane >> 5;
-  gl_f* base = per_step(sv.p + b * sv.sB + t * sv.sT);
+  gl_f* base = per_step(sv.p + b * sv.sB + k * sv.sK + t * sv.sT);
   const int col = 32 * pj + lr;
   const long long sE = sv.sE + (long long)opaque_szero();
   BF_UNROLL for (int r = 0; r < 16; ++r) {
@@ -1192,10 +1192,15 @@ __device__ __forceinline__ float dot_terms_half(const u32x4 (*x)[4], const float
   return s;
 }
 
-template <int N, int M>
+// MULTI: K >= 2 Gaussian-sum components of a LINEAR model per trajectory take turns in the workgroup's tiles (their predicted
+// means / covariances parked in HBM between turns: gm / gP), the weight update runs over the lanes of wave 2 (the wave that
+// holds the log-likelihoods; K <= 64) in the adjacent-pair tree order.  TV: per-step G Q_t G^T / D R_t D^T tables (64 x 64 and
+// 32 x 32 floats per step) instead of the constants -- inference.py:21,337-353.
+template <int N, int M, bool MULTI = false, bool TV = false>
 __global__ void __launch_bounds__(256, 2)
 kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView carry, OutViews out, long long B, long long T,
-                     int rot_mode, int nr, int mr) {
+                     int rot_mode, int nr, int mr, int K, float* __restrict__ gm, float* __restrict__ gP,
+                     const float* __restrict__ tvq, const float* __restrict__ tvr) {
   // nr <= 64, mr <= 32: the model's own dimensions (streams and carry are laid out for them); inside, everything is (64, 32)
   static_assert(N == 64 && M == 32, "tile assignment is written for n = 64, m = 32");
   constexpr int PS = M + 1, HPP = N + 1;
@@ -1240,13 +1245,19 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
   }
   f32x16 Pacc;  // the wave's tile of P-: carried in registers from phase J to phase H
   const bool col_ok = 32 * tj + lr < nr;
-  BF_UNROLL for (int r = 0; r < 16; ++r) {
-    const int row = 32 * ti + c_row(r, lane);
-    Pacc[r] = (col_ok && row < nr) ? carry.P_in[b * nr * nr + row * nr + 32 * tj + lr] : 0.f;
+  const long long bk0 = b * (long long)(MULTI ? K : 1);
+  float w, llk = 0.f;
+  if constexpr (!MULTI) {
+    BF_UNROLL for (int r = 0; r < 16; ++r) {
+      const int row = 32 * ti + c_row(r, lane);
+      Pacc[r] = (col_ok && row < nr) ? carry.P_in[b * nr * nr + row * nr + 32 * tj + lr] : 0.f;
+    }
+    store_terms_transposed(Pn, PN_TERM, PITCH, ti, tj, lane, Pacc);
+    if (tid < N) sm[tid] = tid < nr ? carry.m_in[b * nr + tid] : 0.f;
+    w = carry.w_in ? carry.w_in[b] : 1.0f;
+  } else {
+    w = lane < K ? (carry.w_in ? carry.w_in[bk0 + lane] : 1.0f / (float)K) : 0.f;   // (wave 2's lanes: component `lane`'s weight)
   }
-  store_terms_transposed(Pn, PN_TERM, PITCH, ti, tj, lane, Pacc);
-  if (tid < N) sm[tid] = tid < nr ? carry.m_in[b * nr + tid] : 0.f;
-  float w = carry.w_in ? carry.w_in[b] : 1.0f;
   float ynext = (wave >= 2 && lane < mr) ? y.p[b * y.sB + lane * y.sE] : 0.f;
   const float ll_pad = 0.5f * 1.8378770664093453f * (float)(M - mr);   // the padded observations' log N(0; 0, 1), taken off
   const float dr0 = cst->Dr0[lr], gq0 = cst->Gq0[lane];
@@ -1262,6 +1273,25 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
   float* mcur = sm;
   float* mnxt = sm2;
   for (long long t = 0; t < T; ++t) {
+    float yv_t = ynext;                      // this step's observation (waves 2, 3), the same for every component
+    if (wave >= 2) {
+      const long long tn = t + 1 < T ? t + 1 : t;
+      if (lane < mr) ynext = y.p[b * y.sB + tn * y.sT + lane * y.sE];  // prefetch
+    }
+    gl_cf* const drd_t = TV && tvr ? per_step(tvr + t * (M * M)) : per_step(cst->DRD);
+    gl_cf* const gqg_t = TV && tvq ? per_step(tvq + t * (N * N)) : per_step(cst->GQG);
+   for (int k = 0; k < (MULTI ? K : 1); ++k) {
+    if constexpr (MULTI) {   // this component's carried prior: the caller's at t = 0, the workgroup's own store of the previous step after
+      const float* pin = t == 0 ? carry.P_in : gP;
+      const float* min_ = t == 0 ? carry.m_in : gm;
+      BF_UNROLL for (int r = 0; r < 16; ++r) {
+        const int row = 32 * ti + c_row(r, lane);
+        Pacc[r] = (col_ok && row < nr) ? pin[(bk0 + k) * nr * nr + row * nr + 32 * tj + lr] : 0.f;
+      }
+      store_terms_transposed(Pn, PN_TERM, PITCH, ti, tj, lane, Pacc);
+      if (wave == 2) mcur[lane] = lane < nr ? min_[(bk0 + k) * nr + lane] : 0.f;   // (wave 2 parked it: same lanes read it back)
+      lds_barrier();
+    }
     // ================= phase A: Z = P-^T H^T (waves 0, 1: row tile = wave); innovation (wave 2)
     if (wave < 2) {
       f32x16 z = {0};
@@ -1286,14 +1316,10 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
     float ll = 0.f;
     if (wave >= 2 + BF_V5_LL_LEMMA) {
       {  // innovation v = y - (H m- + D r0): both factorizing waves form it (same bits) for their own use
-        const float yv = ynext;
-        const long long tn = t + 1 < T ? t + 1 : t;
-        if (lane < mr) ynext = y.p[b * y.sB + tn * y.sT + lane * y.sE];  // prefetch
-        if (lane < M) (wave == 2 ? sv : sv3)[lane] = yv - ((part[lane] + part[N + lane]) + dr0);
+        if (lane < M) (wave == 2 ? sv : sv3)[lane] = yv_t - ((part[lane] + part[N + lane]) + dr0);
       }
       f32x16 acc;
-      gl_cf* drd = per_step(cst->DRD);
-      BF_UNROLL for (int r = 0; r < 16; ++r) acc[r] = drd[lr * M + c_row(r, lane)];
+      BF_UNROLL for (int r = 0; r < 16; ++r) acc[r] = drd_t[lr * M + c_row(r, lane)];
       BF_UNROLL for (int c = 0; c < 4; ++c) {
         u32x4 bz[3];
         load_terms(bz, Zn, ZN_TERM, PITCH, lr, c, lk);
@@ -1328,11 +1354,17 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
         acc = mfma_bf6(a, bw, acc);
       }
       acc = mfma2(lk == 0 ? scv[32 * ti + lr] : 0.f, lk == 0 ? scv[32 * tj + lr] : 0.f, acc);
-      store_tile_n<N>(out.P, b, t, ti, tj, lane, acc, nr);
+      store_tile_n<N>(out.P, b, t, ti, tj, lane, acc, nr, MULTI ? k : 0);
       store_terms_transposed(Pn, PN_TERM, PITCH, ti, tj, lane, acc);
     }
-    if (wave == 1 && out.m.p && lane < nr) out.m.p[b * out.m.sB + t * out.m.sT + lane * out.m.sE] = mnxt[lane];
-    if (wave == 2 + BF_V5_LL_LEMMA && lane == 0) {
+    if (wave == 1 && out.m.p && lane < nr) out.m.p[b * out.m.sB + (MULTI ? k : 0) * out.m.sK + t * out.m.sT + lane * out.m.sE] = mnxt[lane];
+    if constexpr (MULTI) {
+      if (wave == 2 + BF_V5_LL_LEMMA) {
+        const float ll0 = rdlane(ll, 0);
+        if (lane == k) llk = ll0;
+        if (lane == 0 && out.ll.p) out.ll.p[b * out.ll.sB + k * out.ll.sK + t * out.ll.sT] = ll0;
+      }
+    } else if (wave == 2 + BF_V5_LL_LEMMA && lane == 0) {
       w = reweight_single(ll, w);
       if (out.w.p) out.w.p[b * out.w.sB + t * out.w.sT] = w;
       if (out.ll.p) out.ll.p[b * out.ll.sB + t * out.ll.sT] = ll;
@@ -1351,8 +1383,7 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
       BF_UNROLL for (int q = 0; q < 3; ++q) BF_UNROLL for (int c = 0; c < 4; ++c)
           hop[q][c] = *reinterpret_cast<const u32x4*>(&cst->H3[q][lr * N + 16 * c + 8 * lk + oz]);
 #endif
-      gl_cf* gqg = per_step(cst->GQG);
-      BF_UNROLL for (int r = 0; r < 16; ++r) gq[r] = gqg[(32 * ti + c_row(r, lane)) * N + 32 * tj + lr];
+      BF_UNROLL for (int r = 0; r < 16; ++r) gq[r] = gqg_t[(32 * ti + c_row(r, lane)) * N + 32 * tj + lr];
     }
     {
       f32x16 acc = {0};
@@ -1385,15 +1416,42 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
         Pacc = mfma_bf6(a, ba, Pacc);
       }
       BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] += gq[r];
-      store_tile_n<N>(out.pP, b, t, ti, tj, lane, Pacc, nr);
-      store_terms_transposed(Pn, PN_TERM, PITCH, ti, tj, lane, Pacc);
+      store_tile_n<N>(out.pP, b, t, ti, tj, lane, Pacc, nr, MULTI ? k : 0);
+      if constexpr (!MULTI) store_terms_transposed(Pn, PN_TERM, PITCH, ti, tj, lane, Pacc);   // (MULTI: the next turn brings its own P-)
+      if constexpr (MULTI) {   // park the component's predicted covariance / mean until its next turn (also the carry out)
+        BF_UNROLL for (int r = 0; r < 16; ++r) {
+          const int row = 32 * ti + c_row(r, lane);
+          if (col_ok && row < nr) gP[(bk0 + k) * nr * nr + row * nr + 32 * tj + lr] = Pacc[r];
+        }
+        if (wave == 2 && lane < nr) gm[(bk0 + k) * nr + lane] = (part[lane] + part[N + lane]) + gq0;
+      }
     }
-    if (wave == 2 && out.pm.p && lane < nr) out.pm.p[b * out.pm.sB + t * out.pm.sT + lane * out.pm.sE] = (part[lane] + part[N + lane]) + gq0;
+    if (wave == 2 && out.pm.p && lane < nr) out.pm.p[b * out.pm.sB + (MULTI ? k : 0) * out.pm.sK + t * out.pm.sT + lane * out.pm.sE] = (part[lane] + part[N + lane]) + gq0;
     BF_TICK5(8)
     lds_barrier();
     BF_TICK5(9)
+   }
+    if constexpr (MULTI) {
+      // ---- weight update (inference.py:347-350) over wave 2's lanes, adjacent-pair trees; lanes beyond K carry -inf / 0
+      if (wave == 2 + BF_V5_LL_LEMMA) {
+        float mx = lane < K ? llk : -__builtin_inff();
+        BF_UNROLL for (int off = 1; off < 64; off <<= 1) {
+          const float o = __shfl_xor(mx, off, 64);
+          mx = (mx != mx || o != o) ? __builtin_nanf("") : fmaxf(mx, o);   // jnp.max propagates NaN
+        }
+        const float e = lane < K ? expf(llk - mx) * w : 0.f;
+        float tot = e;
+        BF_UNROLL for (int off = 1; off < 64; off <<= 1) tot += __shfl_xor(tot, off, 64);
+        w = e / tot;
+        if (lane < K && out.w.p) out.w.p[b * out.w.sB + lane * out.w.sK + t * out.w.sT] = w;
+      }
+    }
   }
 
+  if constexpr (MULTI) {   // (gm / gP ARE the carry-out buffers when the caller asked for them)
+    if (carry.w_out && wave == 2 + BF_V5_LL_LEMMA && lane < K) carry.w_out[bk0 + lane] = w;
+    return;
+  }
   if (carry.P_out && col_ok) BF_UNROLL for (int r = 0; r < 16; ++r) {
       const int row = 32 * ti + c_row(r, lane);
       if (row < nr) carry.P_out[b * nr * nr + row * nr + 32 * tj + lr] = Pacc[r];
@@ -1648,6 +1706,50 @@ kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry,
   if (carry.w_out && lane == 0) carry.w_out[b] = w;
 }
 
+
+// Per-step covariance products for the matrix-core kernels, formed ON THE DEVICE: out[t] = W C_t W^T zero-padded into an
+// NP x NP block (W = G, C = Q: n x dq; or W = D, C = R: m x dr), with diag_from .. NP - 1 set to 1 (the unit noise of padded
+// observations).  Same association and the same k-ascending fma chains as the host code for constant covariances
+// (inference.py:69,:100: (W C) W^T), so a constant table equals the constant block bit for bit.  One workgroup per step.
+__global__ void __launch_bounds__(256)
+tv_table_kernel(const float* __restrict__ W, const float* __restrict__ C, int rows, int d, int NP, int diag_from, float* __restrict__ out) {
+  extern __shared__ float wc[];   // [rows][d]  W C_t
+  const float* Ct = C + (size_t)blockIdx.x * d * d;
+  float* o = out + (size_t)blockIdx.x * NP * NP;
+  for (int e = threadIdx.x; e < rows * d; e += blockDim.x) {
+    const int i = e / d, l = e % d;
+    float s = 0.f;
+    for (int k = 0; k < d; ++k) s = fmaf(W ? W[i * d + k] : (i == k ? 1.f : 0.f), Ct[k * d + l], s);
+    wc[e] = s;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < NP * NP; e += blockDim.x) {
+    const int i = e / NP, j = e % NP;
+    float s = 0.f;
+    if (i < rows && j < rows) {
+      for (int l = 0; l < d; ++l) s = fmaf(wc[i * d + l], W ? W[j * d + l] : (j == l ? 1.f : 0.f), s);
+    } else if (i == j && i >= diag_from) {
+      s = 1.0f;
+    }
+    o[e] = s;
+  }
+}
+
+// d_out: a stream-ordered allocation the caller frees with hipFreeAsync after its launch
+static int tv_table_on_device(const float* W_host, const float* C_host, long long T, int rows, int d, int NP, int diag_from,
+                              hipStream_t stream, float** d_out) {
+  const void* dW = nullptr;
+  const void* dC = nullptr;
+  int rc = BF_OK;
+  if (W_host && (rc = device_constants(W_host, sizeof(float) * (size_t)rows * d, stream, &dW)) != BF_OK) return rc;
+  if ((rc = device_constants(C_host, sizeof(float) * (size_t)T * d * d, stream, &dC)) != BF_OK) return rc;
+  BF_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(d_out), sizeof(float) * (size_t)T * NP * NP, stream));
+  hipLaunchKernelGGL(tv_table_kernel, dim3((unsigned)T), dim3(256), sizeof(float) * (size_t)rows * d, stream,
+                     static_cast<const float*>(dW), static_cast<const float*>(dC), rows, d, NP, diag_from, *d_out);
+  BF_HIP_CHECK(hipGetLastError());
+  return BF_OK;
+}
+
 // K = 1: bf_kalman_filter_f32; K >= 1: the Gaussian-sum filter of a linear model (bf_gsf_ekf_f32), components in turn.
 int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry, const bf_out_desc* out,
                    hipStream_t stream, int K, bool multi) {
@@ -1716,23 +1818,15 @@ int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
   };
   gqg_of(p->Q, h->GQG);
   drd_of(p->R, h->DRD);
-  // per-step tables (_get_params(x, 2, t), inference.py:21): T blocks of 32 x 32, through the constant cache like the model
-  const float *d_tvq = nullptr, *d_tvr = nullptr;
+  // per-step tables (_get_params(x, 2, t), inference.py:21): T blocks of 32 x 32, formed on the device
+  float *d_tvq = nullptr, *d_tvr = nullptr;
   if (p->Q_steps > 1) {
-    std::vector<float> tab((size_t)T * N * N, 0.f);
-    for (long long t = 0; t < T; ++t) gqg_of(p->Q + (size_t)t * dq * dq, tab.data() + (size_t)t * N * N);
-    const void* dv = nullptr;
-    const int rc = device_constants(tab.data(), sizeof(float) * tab.size(), stream, &dv);
+    const int rc = tv_table_on_device(p->G, p->Q, T, nr, dq, N, N, stream, &d_tvq);
     if (rc != BF_OK) { delete h; return rc; }
-    d_tvq = static_cast<const float*>(dv);
   }
   if (p->R_steps > 1) {
-    std::vector<float> tab((size_t)T * N * N, 0.f);
-    for (long long t = 0; t < T; ++t) drd_of(p->R + (size_t)t * dr * dr, tab.data() + (size_t)t * N * N);
-    const void* dv = nullptr;
-    const int rc = device_constants(tab.data(), sizeof(float) * tab.size(), stream, &dv);
-    if (rc != BF_OK) { delete h; return rc; }
-    d_tvr = static_cast<const float*>(dv);
+    const int rc = tv_table_on_device(p->D, p->R, T, mr, dr, N, mr, stream, &d_tvr);
+    if (rc != BF_OK) { delete h; if (d_tvq) (void)hipFreeAsync(d_tvq, stream); return rc; }
   }
   for (int i = 0; i < nr; ++i) {
     float s = 0.f;
@@ -1747,7 +1841,11 @@ int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
   const void* dv = nullptr;
   const int crc = device_constants(h, sizeof(*h), stream, &dv);
   delete h;
-  if (crc != BF_OK) return crc;
+  if (crc != BF_OK) {
+    if (d_tvq) (void)hipFreeAsync(d_tvq, stream);
+    if (d_tvr) (void)hipFreeAsync(d_tvr, stream);
+    return crc;
+  }
   CView yv{y->ptr, y->sB, y->sT, y->sE};
   CarryView cv{carry->w_in, carry->m_in, carry->P_in, carry->w_out, carry->m_out, carry->P_out};
   OutViews ov{make_sview(out->weights), make_sview(out->means), make_sview(out->covs),
@@ -1755,10 +1853,16 @@ int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
   const Bf32Const* dc = static_cast<const Bf32Const*>(dv);
   const dim3 grid((unsigned)((B + 1) / 2)), block(128);
   const bool tv = d_tvq || d_tvr;
+  auto free_tables = [&]() {
+    if (d_tvq) (void)hipFreeAsync(d_tvq, stream);
+    if (d_tvr) (void)hipFreeAsync(d_tvr, stream);
+  };
   if (!multi) {
     if (tv) hipLaunchKernelGGL((kf_scan_bf32_kernel<false, true>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, B, T, nr, mr, 1, nullptr, nullptr, d_tvq, d_tvr);
     else hipLaunchKernelGGL((kf_scan_bf32_kernel<false, false>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, B, T, nr, mr, 1, nullptr, nullptr, nullptr, nullptr);
-    BF_HIP_CHECK(hipGetLastError());
+    const hipError_t le0 = hipGetLastError();
+    free_tables();
+    BF_HIP_CHECK(le0);
     return BF_OK;
   }
   // components in turn: their predicted means / covariances wait in the caller's carry-out buffers when given, else in a
@@ -1776,13 +1880,15 @@ int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
   else hipLaunchKernelGGL((kf_scan_bf32_kernel<true, false>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, B, T, nr, mr, K, gm, gP, nullptr, nullptr);
   const hipError_t le = hipGetLastError();
   if (scratch) (void)hipFreeAsync(scratch, stream);
+  free_tables();
   BF_HIP_CHECK(le);
   return BF_OK;
 }
 
 // ---------------------------------------------------------------------------------------
+// K = 1, multi = false: bf_kalman_filter_f32; multi: the Gaussian-sum filter of a linear model (bf_gsf_ekf_f32), components in turn.
 int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
-                   const bf_out_desc* out, hipStream_t stream) {
+                   const bf_out_desc* out, hipStream_t stream, int K, bool multi) {
   constexpr int N = 64, M = 32;
   // Smaller models ride in the (64, 32) tiles zero-padded (variant 5): A, H, G Q G^T padded with zeros keep the padded
   // block of P at exactly zero; the padded observations are y = 0 with unit noise and H rows of zero, independent of the
@@ -1792,8 +1898,12 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
   const bool padded = nr != N || mr != M;
   if (nr > N || mr > M || (padded && g_kf_mfma_variant.load() != 5))
     return set_error(BF_EUNSUPPORTED, "MFMA Kalman kernel: n <= 64 and m <= 32 (smaller than (64, 32) on variant 5 only)");
-  if (p->Q_steps > 1 || p->R_steps > 1)
-    return set_error(BF_EUNSUPPORTED, "time-varying Q/R are not supported on the MFMA Kalman kernel");
+  const bool tv = p->Q_steps > 1 || p->R_steps > 1;
+  if ((tv || multi) && g_kf_mfma_variant.load() != 5)
+    return set_error(BF_EUNSUPPORTED, "MFMA Kalman kernel: per-step covariances and Gaussian-sum components need variant 5");
+  if (K > 64) return set_error(BF_EUNSUPPORTED, "MFMA Kalman kernel: at most 64 components (one per lane in the weight update)");
+  if ((p->Q_steps > 1 && p->Q_steps != T) || (p->R_steps > 1 && p->R_steps != T))
+    return set_error(BF_EINVAL, "time-varying covariances need one matrix per step (Q_steps / R_steps = T = %lld)", T);
   const int dq = p->dq, dr = p->dr;
   MfmaConst<N, M>* h = new MfmaConst<N, M>();  // zero-filled: the constant cache compares contents
   auto Gat = [&](int i, int k) { return p->G ? p->G[i * dq + k] : (i == k ? 1.f : 0.f); };
@@ -1826,36 +1936,48 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
     split3(h->A, N * N, h->A3, nullptr);
     split3(h->H, M * N, nullptr, h->H3);
   }
-  {  // (G Q) G^T and (D R) D^T, association of inference.py:69,:100
-    float* GQ = new float[(size_t)N * dq];
+  // (G Q) G^T and (D R) D^T, association of inference.py:69,:100, zero-padded into N x N / M x M blocks
+  std::vector<float> GQv((size_t)N * dq), DRv((size_t)M * dr);
+  auto gqg_of = [&](const float* Q, float* dst) {
     for (int i = 0; i < nr; ++i)
       for (int l = 0; l < dq; ++l) {
         float s = 0.f;
-        for (int k = 0; k < dq; ++k) s = fmaf(Gat(i, k), p->Q[k * dq + l], s);
-        GQ[i * dq + l] = s;
+        for (int k = 0; k < dq; ++k) s = fmaf(Gat(i, k), Q[k * dq + l], s);
+        GQv[i * dq + l] = s;
       }
     for (int i = 0; i < nr; ++i)
       for (int j = 0; j < nr; ++j) {
         float s = 0.f;
-        for (int l = 0; l < dq; ++l) s = fmaf(GQ[i * dq + l], Gat(j, l), s);
-        h->GQG[i * N + j] = s;
+        for (int l = 0; l < dq; ++l) s = fmaf(GQv[i * dq + l], Gat(j, l), s);
+        dst[i * N + j] = s;
       }
-    delete[] GQ;
-    float* DRm = new float[(size_t)M * dr];
+  };
+  auto drd_of = [&](const float* R, float* dst) {
     for (int i = 0; i < mr; ++i)
       for (int l = 0; l < dr; ++l) {
         float s = 0.f;
-        for (int k = 0; k < dr; ++k) s = fmaf(Dat(i, k), p->R[k * dr + l], s);
-        DRm[i * dr + l] = s;
+        for (int k = 0; k < dr; ++k) s = fmaf(Dat(i, k), R[k * dr + l], s);
+        DRv[i * dr + l] = s;
       }
     for (int i = 0; i < mr; ++i)
       for (int j = 0; j < mr; ++j) {
         float s = 0.f;
-        for (int l = 0; l < dr; ++l) s = fmaf(DRm[i * dr + l], Dat(j, l), s);
-        h->DRD[i * M + j] = s;
+        for (int l = 0; l < dr; ++l) s = fmaf(DRv[i * dr + l], Dat(j, l), s);
+        dst[i * M + j] = s;
       }
-    for (int i = mr; i < M; ++i) h->DRD[i * M + i] = 1.0f;   // padded observations: unit noise
-    delete[] DRm;
+    for (int i = mr; i < M; ++i) dst[i * M + i] = 1.0f;   // padded observations: unit noise
+  };
+  gqg_of(p->Q, h->GQG);
+  drd_of(p->R, h->DRD);
+  // per-step tables (_get_params(x, 2, t), inference.py:21), formed on the device
+  float *d_tvq = nullptr, *d_tvr = nullptr;
+  if (p->Q_steps > 1) {
+    const int rc = tv_table_on_device(p->G, p->Q, T, nr, dq, N, N, stream, &d_tvq);
+    if (rc != BF_OK) { delete h; return rc; }
+  }
+  if (p->R_steps > 1) {
+    const int rc = tv_table_on_device(p->D, p->R, T, mr, dr, M, mr, stream, &d_tvr);
+    if (rc != BF_OK) { delete h; if (d_tvq) (void)hipFreeAsync(d_tvq, stream); return rc; }
   }
   for (int i = 0; i < nr; ++i) {
     float s = 0.f;
@@ -1870,7 +1992,11 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
   const void* dv = nullptr;
   const int crc = device_constants(h, sizeof(*h), stream, &dv);
   delete h;
-  if (crc != BF_OK) return crc;
+  if (crc != BF_OK) {
+    if (d_tvq) (void)hipFreeAsync(d_tvq, stream);
+    if (d_tvr) (void)hipFreeAsync(d_tvr, stream);
+    return crc;
+  }
   const MfmaConst<N, M>* d = static_cast<const MfmaConst<N, M>*>(dv);
 
   CView yv{y->ptr, y->sB, y->sT, y->sE};
@@ -1888,10 +2014,28 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
     static const int rot_mode = [] { const char* e = std::getenv("BAYESFILT_MFMA_ROT"); return e ? std::atoi(e) : 1; }();
     if (var == 5) {
       const size_t lds5 = 3 * 64 * 144 + 3 * 32 * 144 + 3 * 64 * 80 + sizeof(float) * (size_t)(M * (N + 1) + 2 * M * (M + 1) + 5 * N + 2 * M);
-      auto kern5 = kf_scan_mfma5_kernel<N, M>;
-      BF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern5), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5));
-      hipLaunchKernelGGL(kern5, dim3((unsigned)B), dim3(256), lds5, stream, d, yv, cv, ov, B, T, rot_mode, nr, mr);
-      BF_HIP_CHECK(hipGetLastError());
+      float* gm = carry->m_out;
+      float* gP = carry->P_out;
+      float* scratch = nullptr;
+      if (multi && (!gm || !gP)) {   // components in turn: parked in the carry-out buffers when given, else a stream-ordered scratch
+        const size_t fl = (size_t)B * K * ((size_t)nr + (size_t)nr * nr);
+        BF_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(float) * fl, stream));
+        if (!gm) gm = scratch;
+        if (!gP) gP = scratch + (size_t)B * K * nr;
+      }
+      auto go = [&](auto kern5) {
+        const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kern5), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
+        if (ae != hipSuccess) return ae;
+        hipLaunchKernelGGL(kern5, dim3((unsigned)B), dim3(256), lds5, stream, d, yv, cv, ov, B, T, rot_mode, nr, mr, K, gm, gP, d_tvq, d_tvr);
+        return hipGetLastError();
+      };
+      hipError_t le;
+      if (multi) le = tv ? go(kf_scan_mfma5_kernel<N, M, true, true>) : go(kf_scan_mfma5_kernel<N, M, true, false>);
+      else le = tv ? go(kf_scan_mfma5_kernel<N, M, false, true>) : go(kf_scan_mfma5_kernel<N, M, false, false>);
+      if (scratch) (void)hipFreeAsync(scratch, stream);
+      if (d_tvq) (void)hipFreeAsync(d_tvq, stream);
+      if (d_tvr) (void)hipFreeAsync(d_tvr, stream);
+      BF_HIP_CHECK(le);
       return BF_OK;
     }
     const size_t lds_bytes = var == 4 ? sizeof(float) * (size_t)(2 * N * (N + 1) + M * (N + 1) + 2 * M * (M + 1) + 3 * N + M)

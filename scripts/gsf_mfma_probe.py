@@ -6,7 +6,7 @@ import bayesianfiltering_amd as bfa
 from tests import common as cm
 F32 = np.float32
 for n, m, K, B, T, tv in ((32, 16, 32, 2048, 50, False), (32, 16, 4, 8192, 50, False), (32, 16, 4, 8192, 50, True), (16, 8, 32, 2048, 50, False),
-                          (32, 16, 1, 16384, 50, True)):
+                          (32, 16, 1, 16384, 50, True), (64, 32, 4, 2048, 40, False), (64, 32, 32, 512, 20, False), (64, 32, 1, 8192, 40, True)):
     a = cm.random_stable_lgssm(n, m, seed=n)
     p = cm.product_params(a)
     if tv:

@@ -219,11 +219,11 @@ def test_small_mode_off_routes_to_the_other_kernels(n, m):
 
 
 @pytest.mark.parametrize("n,m,K,tv", [(16, 8, 4, False), (32, 16, 32, False), (24, 12, 5, True), (32, 16, 4, True), (12, 10, 3, True),
-                                       (32, 32, 64, False)])
+                                       (32, 32, 64, False), (64, 32, 4, False), (64, 32, 32, True), (48, 24, 5, True), (33, 7, 2, False)])
 def test_gaussian_sum_of_a_linear_model_on_the_matrix_cores(n, m, K, tv):
     """_predict / _condition_on are vmapped over the components and read per-step covariances (inference.py:21,51-105,337-353):
-    for LINEAR models of 9 <= n <= 32 the K components take turns on the one-wave matrix-core kernel (bf16 three-term
-    products), per-step Q_t / R_t tables included.  Against the oracle at 1e-5 (weights absolutely), against the
+    for LINEAR models of 9 <= n <= 64 the K components take turns on the matrix-core kernels (bf16 three-term products: one
+    wave per trajectory up to n = 32, four waves up to (64, 32)), per-step Q_t / R_t tables included.  Against the oracle at 1e-5 (weights absolutely), against the
     run-time-dimension kernel, and two chunks through the carry == one shot bit for bit."""
     import torch
     import bayesianfiltering_amd as bfa
