@@ -1192,15 +1192,14 @@ __device__ __forceinline__ float dot_terms_half(const u32x4 (*x)[4], const float
   return s;
 }
 
-// MULTI: K >= 2 Gaussian-sum components of a LINEAR model per trajectory take turns in the workgroup's tiles (their predicted
-// means / covariances parked in HBM between turns: gm / gP), the weight update runs over the lanes of wave 2 (the wave that
-// holds the log-likelihoods; K <= 64) in the adjacent-pair tree order.  TV: per-step G Q_t G^T / D R_t D^T tables (64 x 64 and
-// 32 x 32 floats per step) instead of the constants -- inference.py:21,337-353.
+// MULTI: the K Gaussian-sum components of a LINEAR model as independent chains (see kf_scan_bf32_kernel): workgroup c =
+// trajectory * K + component reads trajectory c / K's observations and writes component c % K's streams and per-step
+// log-likelihood; the weights follow in gsf_reweight_kernel.  TV: per-step G Q_t G^T / D R_t D^T tables (64 x 64 and 32 x 32
+// floats per step) instead of the constants -- inference.py:21,337-353.
 template <int N, int M, bool MULTI = false, bool TV = false>
 __global__ void __launch_bounds__(256, 2)
 kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView carry, OutViews out, long long B, long long T,
-                     int rot_mode, int nr, int mr, int K, float* __restrict__ gm, float* __restrict__ gP,
-                     const float* __restrict__ tvq, const float* __restrict__ tvr) {
+                     int rot_mode, int nr, int mr, int K, const float* __restrict__ tvq, const float* __restrict__ tvr) {
   // nr <= 64, mr <= 32: the model's own dimensions (streams and carry are laid out for them); inside, everything is (64, 32)
   static_assert(N == 64 && M == 32, "tile assignment is written for n = 64, m = 32");
   constexpr int PS = M + 1, HPP = N + 1;
@@ -1219,7 +1218,9 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(((tid >> 6) + s_rot) & 3);
   const int ti = wave >> 1, tj = wave & 1;
-  const long long b = blockIdx.x;
+  const long long b = blockIdx.x;                  // chain: carry index
+  const long long bt = MULTI ? b / K : b;          // trajectory: observations, stream batch index
+  const int kc = MULTI ? (int)(b % K) : 0;         // component: stream component index
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   lds_c* L = (lds_c*)reinterpret_cast<char*>(lds);
@@ -1245,20 +1246,14 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
   }
   f32x16 Pacc;  // the wave's tile of P-: carried in registers from phase J to phase H
   const bool col_ok = 32 * tj + lr < nr;
-  const long long bk0 = b * (long long)(MULTI ? K : 1);
-  float w, llk = 0.f;
-  if constexpr (!MULTI) {
-    BF_UNROLL for (int r = 0; r < 16; ++r) {
-      const int row = 32 * ti + c_row(r, lane);
-      Pacc[r] = (col_ok && row < nr) ? carry.P_in[b * nr * nr + row * nr + 32 * tj + lr] : 0.f;
-    }
-    store_terms_transposed(Pn, PN_TERM, PITCH, ti, tj, lane, Pacc);
-    if (tid < N) sm[tid] = tid < nr ? carry.m_in[b * nr + tid] : 0.f;
-    w = carry.w_in ? carry.w_in[b] : 1.0f;
-  } else {
-    w = lane < K ? (carry.w_in ? carry.w_in[bk0 + lane] : 1.0f / (float)K) : 0.f;   // (wave 2's lanes: component `lane`'s weight)
+  BF_UNROLL for (int r = 0; r < 16; ++r) {
+    const int row = 32 * ti + c_row(r, lane);
+    Pacc[r] = (col_ok && row < nr) ? carry.P_in[b * nr * nr + row * nr + 32 * tj + lr] : 0.f;
   }
-  float ynext = (wave >= 2 && lane < mr) ? y.p[b * y.sB + lane * y.sE] : 0.f;
+  store_terms_transposed(Pn, PN_TERM, PITCH, ti, tj, lane, Pacc);
+  if (tid < N) sm[tid] = tid < nr ? carry.m_in[b * nr + tid] : 0.f;
+  float w = (!MULTI && carry.w_in) ? carry.w_in[b] : 1.0f;
+  float ynext = (wave >= 2 && lane < mr) ? y.p[bt * y.sB + lane * y.sE] : 0.f;
   const float ll_pad = 0.5f * 1.8378770664093453f * (float)(M - mr);   // the padded observations' log N(0; 0, 1), taken off
   const float dr0 = cst->Dr0[lr], gq0 = cst->Gq0[lane];
   __syncthreads();
@@ -1276,22 +1271,10 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
     float yv_t = ynext;                      // this step's observation (waves 2, 3), the same for every component
     if (wave >= 2) {
       const long long tn = t + 1 < T ? t + 1 : t;
-      if (lane < mr) ynext = y.p[b * y.sB + tn * y.sT + lane * y.sE];  // prefetch
+      if (lane < mr) ynext = y.p[bt * y.sB + tn * y.sT + lane * y.sE];  // prefetch
     }
     gl_cf* const drd_t = TV && tvr ? per_step(tvr + t * (M * M)) : per_step(cst->DRD);
     gl_cf* const gqg_t = TV && tvq ? per_step(tvq + t * (N * N)) : per_step(cst->GQG);
-   for (int k = 0; k < (MULTI ? K : 1); ++k) {
-    if constexpr (MULTI) {   // this component's carried prior: the caller's at t = 0, the workgroup's own store of the previous step after
-      const float* pin = t == 0 ? carry.P_in : gP;
-      const float* min_ = t == 0 ? carry.m_in : gm;
-      BF_UNROLL for (int r = 0; r < 16; ++r) {
-        const int row = 32 * ti + c_row(r, lane);
-        Pacc[r] = (col_ok && row < nr) ? pin[(bk0 + k) * nr * nr + row * nr + 32 * tj + lr] : 0.f;
-      }
-      store_terms_transposed(Pn, PN_TERM, PITCH, ti, tj, lane, Pacc);
-      if (wave == 2) mcur[lane] = lane < nr ? min_[(bk0 + k) * nr + lane] : 0.f;   // (wave 2 parked it: same lanes read it back)
-      lds_barrier();
-    }
     // ================= phase A: Z = P-^T H^T (waves 0, 1: row tile = wave); innovation (wave 2)
     if (wave < 2) {
       f32x16 z = {0};
@@ -1354,20 +1337,16 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
         acc = mfma_bf6(a, bw, acc);
       }
       acc = mfma2(lk == 0 ? scv[32 * ti + lr] : 0.f, lk == 0 ? scv[32 * tj + lr] : 0.f, acc);
-      store_tile_n<N>(out.P, b, t, ti, tj, lane, acc, nr, MULTI ? k : 0);
+      store_tile_n<N>(out.P, bt, t, ti, tj, lane, acc, nr, kc);
       store_terms_transposed(Pn, PN_TERM, PITCH, ti, tj, lane, acc);
     }
-    if (wave == 1 && out.m.p && lane < nr) out.m.p[b * out.m.sB + (MULTI ? k : 0) * out.m.sK + t * out.m.sT + lane * out.m.sE] = mnxt[lane];
-    if constexpr (MULTI) {
-      if (wave == 2 + BF_V5_LL_LEMMA) {
-        const float ll0 = rdlane(ll, 0);
-        if (lane == k) llk = ll0;
-        if (lane == 0 && out.ll.p) out.ll.p[b * out.ll.sB + k * out.ll.sK + t * out.ll.sT] = ll0;
+    if (wave == 1 && out.m.p && lane < nr) out.m.p[bt * out.m.sB + kc * out.m.sK + t * out.m.sT + lane * out.m.sE] = mnxt[lane];
+    if (wave == 2 + BF_V5_LL_LEMMA && lane == 0) {
+      if constexpr (!MULTI) {
+        w = reweight_single(ll, w);
+        if (out.w.p) out.w.p[b * out.w.sB + t * out.w.sT] = w;
       }
-    } else if (wave == 2 + BF_V5_LL_LEMMA && lane == 0) {
-      w = reweight_single(ll, w);
-      if (out.w.p) out.w.p[b * out.w.sB + t * out.w.sT] = w;
-      if (out.ll.p) out.ll.p[b * out.ll.sB + t * out.ll.sT] = ll;
+      if (out.ll.p) out.ll.p[bt * out.ll.sB + kc * out.ll.sK + t * out.ll.sT] = ll;   // (MULTI: the launcher always provides it)
     }
     BF_TICK5(4)
     lds_barrier();
@@ -1416,48 +1395,21 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
         Pacc = mfma_bf6(a, ba, Pacc);
       }
       BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] += gq[r];
-      store_tile_n<N>(out.pP, b, t, ti, tj, lane, Pacc, nr, MULTI ? k : 0);
-      if constexpr (!MULTI) store_terms_transposed(Pn, PN_TERM, PITCH, ti, tj, lane, Pacc);   // (MULTI: the next turn brings its own P-)
-      if constexpr (MULTI) {   // park the component's predicted covariance / mean until its next turn (also the carry out)
-        BF_UNROLL for (int r = 0; r < 16; ++r) {
-          const int row = 32 * ti + c_row(r, lane);
-          if (col_ok && row < nr) gP[(bk0 + k) * nr * nr + row * nr + 32 * tj + lr] = Pacc[r];
-        }
-        if (wave == 2 && lane < nr) gm[(bk0 + k) * nr + lane] = (part[lane] + part[N + lane]) + gq0;
-      }
+      store_tile_n<N>(out.pP, bt, t, ti, tj, lane, Pacc, nr, kc);
+      store_terms_transposed(Pn, PN_TERM, PITCH, ti, tj, lane, Pacc);
     }
-    if (wave == 2 && out.pm.p && lane < nr) out.pm.p[b * out.pm.sB + (MULTI ? k : 0) * out.pm.sK + t * out.pm.sT + lane * out.pm.sE] = (part[lane] + part[N + lane]) + gq0;
+    if (wave == 2 && out.pm.p && lane < nr) out.pm.p[bt * out.pm.sB + kc * out.pm.sK + t * out.pm.sT + lane * out.pm.sE] = (part[lane] + part[N + lane]) + gq0;
     BF_TICK5(8)
     lds_barrier();
     BF_TICK5(9)
-   }
-    if constexpr (MULTI) {
-      // ---- weight update (inference.py:347-350) over wave 2's lanes, adjacent-pair trees; lanes beyond K carry -inf / 0
-      if (wave == 2 + BF_V5_LL_LEMMA) {
-        float mx = lane < K ? llk : -__builtin_inff();
-        BF_UNROLL for (int off = 1; off < 64; off <<= 1) {
-          const float o = __shfl_xor(mx, off, 64);
-          mx = (mx != mx || o != o) ? __builtin_nanf("") : fmaxf(mx, o);   // jnp.max propagates NaN
-        }
-        const float e = lane < K ? expf(llk - mx) * w : 0.f;
-        float tot = e;
-        BF_UNROLL for (int off = 1; off < 64; off <<= 1) tot += __shfl_xor(tot, off, 64);
-        w = e / tot;
-        if (lane < K && out.w.p) out.w.p[b * out.w.sB + lane * out.w.sK + t * out.w.sT] = w;
-      }
-    }
   }
 
-  if constexpr (MULTI) {   // (gm / gP ARE the carry-out buffers when the caller asked for them)
-    if (carry.w_out && wave == 2 + BF_V5_LL_LEMMA && lane < K) carry.w_out[bk0 + lane] = w;
-    return;
-  }
   if (carry.P_out && col_ok) BF_UNROLL for (int r = 0; r < 16; ++r) {
       const int row = 32 * ti + c_row(r, lane);
       if (row < nr) carry.P_out[b * nr * nr + row * nr + 32 * tj + lr] = Pacc[r];
     }
   if (carry.m_out && tid < nr) carry.m_out[b * nr + tid] = mcur[tid];
-  if (carry.w_out && wave == 2 + BF_V5_LL_LEMMA && lane == 0) carry.w_out[b] = w;
+  if (!MULTI && carry.w_out && wave == 2 + BF_V5_LL_LEMMA && lane == 0) carry.w_out[b] = w;
 #ifdef BF_MFMA_PHASE_TIMERS
   __syncthreads();
   if (b == 0 && lane == 0 && carry.P_out) for (int i = 0; i < 12; ++i) carry.P_out[wave * 16 + i] = (float)tacc[i];
@@ -1502,22 +1454,25 @@ __device__ __forceinline__ void store_tile32(const SView& sv, long long b, long 
 constexpr int BF32_PN_BYTES = 2 * 32 * 33 * 4;   // 8 448 >= 3 * 32 * 80
 constexpr int BF32_WAVE_LDS = BF32_PN_BYTES + 3 * 32 * 80 + 4 * 32 * 4;
 
-// MULTI: K >= 1 Gaussian-sum components of a LINEAR model per trajectory (inference.py:345-353 vmaps _condition_on / _predict
-// over the components): they take turns in the wave's tiles -- a component's predicted mean and covariance wait in HBM
-// (gm / gP: the caller's carry-out buffers or a scratch, L2-resident between turns) -- and the weight update runs over the
-// lanes (component k in lane k, K <= 64) in the oracle's adjacent-pair tree order.  TV: per-step G Q_t G^T / D R_t D^T tables
-// (_get_params(x, 2, t), inference.py:21,337-340) instead of the constants of Bf32Const.
+// MULTI: the K Gaussian-sum components of a LINEAR model (inference.py:345-353 vmaps _condition_on / _predict over them).  Their
+// mean / covariance recursions do not depend on the weights, so every (trajectory, component) pair is a chain of its own:
+// chain c = trajectory * K + component reads trajectory c / K's observations, writes component c % K's streams and its
+// per-step log-likelihood; the weight recursion (the only coupling) runs afterwards over the stored log-likelihoods
+// (gsf_reweight_kernel).  B counts chains.  TV: per-step G Q_t G^T / D R_t D^T tables (_get_params(x, 2, t),
+// inference.py:21,337-340) instead of the constants of Bf32Const.
 template <bool MULTI, bool TV>
 __global__ void __launch_bounds__(128, 2)
 kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry, OutViews out, long long B, long long T, int nr, int mr,
-                    int K, float* __restrict__ gm, float* __restrict__ gP, const float* __restrict__ tvq, const float* __restrict__ tvr) {
+                    int K, const float* __restrict__ tvq, const float* __restrict__ tvr) {
   constexpr int PITCH = 80, TERM = 32 * PITCH, PS = 33;
   const int lane = threadIdx.x & 63;
   const int lr = lane & 31, lk = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long b_raw = (long long)blockIdx.x * 2 + wv;
   if (b_raw >= B) return;   // (no workgroup barrier anywhere below)
-  const long long b = b_raw;
+  const long long b = b_raw;                       // chain: carry index
+  const long long bt = MULTI ? b / K : b;          // trajectory: observations, stream batch index
+  const int kc = MULTI ? (int)(b % K) : 0;         // component: stream component index
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   lds_c* L = (lds_c*)reinterpret_cast<char*>(lds) + wv * BF32_WAVE_LDS;
@@ -1539,21 +1494,14 @@ kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry,
   }
   const float dr0 = cst->Dr0[lr], gq0 = cst->Gq0[lr];
   f32x16 Pacc;
-  float w;
-  if constexpr (!MULTI) {
-    BF_UNROLL for (int r = 0; r < 16; ++r) {
-      const int row = c_row(r, lane);
-      Pacc[r] = (lr < nr && row < nr) ? carry.P_in[b * nr * nr + row * nr + lr] : 0.f;
-    }
-    store_terms_transposed(Pn, TERM, PITCH, 0, 0, lane, Pacc);
-    sm[lr] = lr < nr ? carry.m_in[b * nr + lr] : 0.f;
-    w = carry.w_in ? carry.w_in[b] : 1.0f;
-  } else {
-    w = lane < K ? (carry.w_in ? carry.w_in[b * K + lane] : 1.0f / (float)K) : 0.f;   // component `lane`'s weight
+  BF_UNROLL for (int r = 0; r < 16; ++r) {
+    const int row = c_row(r, lane);
+    Pacc[r] = (lr < nr && row < nr) ? carry.P_in[b * nr * nr + row * nr + lr] : 0.f;
   }
-  float llk = 0.f;                       // MULTI: component `lane`'s log-likelihood of this step
-  const long long bk0 = b * (long long)K;
-  float ynext = lr < mr ? y.p[b * y.sB + lr * y.sE] : 0.f;
+  store_terms_transposed(Pn, TERM, PITCH, 0, 0, lane, Pacc);
+  sm[lr] = lr < nr ? carry.m_in[b * nr + lr] : 0.f;
+  float w = (!MULTI && carry.w_in) ? carry.w_in[b] : 1.0f;
+  float ynext = lr < mr ? y.p[bt * y.sB + lr * y.sE] : 0.f;
   const float ll_pad = 0.5f * 1.8378770664093453f * (float)(32 - mr);
   wave_lds_order();
 
@@ -1561,24 +1509,10 @@ kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry,
     const float yv = ynext;
     {
       const long long tn = t + 1 < T ? t + 1 : t;
-      if (lr < mr) ynext = y.p[b * y.sB + tn * y.sT + lr * y.sE];
+      if (lr < mr) ynext = y.p[bt * y.sB + tn * y.sT + lr * y.sE];
     }
     gl_cf* const drd_t = TV && tvr ? per_step(tvr + t * 1024) : per_step(cst->DRD);
     gl_cf* const gqg_t = TV && tvq ? per_step(tvq + t * 1024) : per_step(cst->GQG);
-   for (int k = 0; k < (MULTI ? K : 1); ++k) {
-    if constexpr (MULTI) {   // this component's carried prior: the caller's at t = 0, the wave's own store of the previous step after
-      // (every lane reads back exactly the addresses it wrote: program order makes the values visible.  Fetching one turn
-      // ahead into 17 more registers was measured 28 % SLOWER: the wave already holds 48 operand registers of A and H)
-      const float* pin = t == 0 ? carry.P_in : gP;
-      const float* min_ = t == 0 ? carry.m_in : gm;
-      BF_UNROLL for (int r = 0; r < 16; ++r) {
-        const int row = c_row(r, lane);
-        Pacc[r] = (lr < nr && row < nr) ? pin[(bk0 + k) * nr * nr + row * nr + lr] : 0.f;
-      }
-      store_terms_transposed(Pn, TERM, PITCH, 0, 0, lane, Pacc);
-      if (lk == 0) sm[lr] = lr < nr ? min_[(bk0 + k) * nr + lr] : 0.f;   // (the lane that parked entry lr reads it back)
-      wave_lds_order();
-    }
     // ---- Z = P-^T H^T; H P- in fp32 for the forward substitution; innovation
     {
       f32x16 z = {0};
@@ -1623,18 +1557,16 @@ kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry,
       }
       const float cv = lk == 0 ? scv[lr] : 0.f;
       acc = mfma2(cv, cv, acc);
-      store_tile32(out.P, b, t, lane, acc, nr, MULTI ? k : 0);
+      store_tile32(out.P, bt, t, lane, acc, nr, kc);
       wave_lds_order();   // (W^T's terms are read before Y^T overwrites them below; P-'s before P+'s here)
       store_terms_transposed(Pn, TERM, PITCH, 0, 0, lane, acc);
-      if (out.m.p && lane < nr) out.m.p[b * out.m.sB + (MULTI ? k : 0) * out.m.sK + t * out.m.sT + lane * out.m.sE] = sm2[lane];
-      if constexpr (MULTI) {
-        const float ll0 = rdlane(ll, 0);
-        if (lane == k) llk = ll0;
-        if (lane == 0 && out.ll.p) out.ll.p[b * out.ll.sB + k * out.ll.sK + t * out.ll.sT] = ll;
-      } else if (lane == 0) {
-        w = reweight_single(ll, w);
-        if (out.w.p) out.w.p[b * out.w.sB + t * out.w.sT] = w;
-        if (out.ll.p) out.ll.p[b * out.ll.sB + t * out.ll.sT] = ll;
+      if (out.m.p && lane < nr) out.m.p[bt * out.m.sB + kc * out.m.sK + t * out.m.sT + lane * out.m.sE] = sm2[lane];
+      if (lane == 0) {
+        if constexpr (!MULTI) {
+          w = reweight_single(ll, w);
+          if (out.w.p) out.w.p[b * out.w.sB + t * out.w.sT] = w;
+        }
+        if (out.ll.p) out.ll.p[bt * out.ll.sB + kc * out.ll.sK + t * out.ll.sT] = ll;   // (MULTI: the launcher always provides it)
       }
     }
     wave_lds_order();
@@ -1665,47 +1597,64 @@ kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry,
         Pacc = mfma_bf6(a, ba, Pacc);
       }
       BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[r] += gq[r];
-      store_tile32(out.pP, b, t, lane, Pacc, nr, MULTI ? k : 0);
-      if constexpr (!MULTI) store_terms_transposed(Pn, TERM, PITCH, 0, 0, lane, Pacc);   // (MULTI: the next turn brings its own P-)
-      if (out.pm.p && lane < nr) out.pm.p[b * out.pm.sB + (MULTI ? k : 0) * out.pm.sK + t * out.pm.sT + lane * out.pm.sE] = sm[lane];
-      if constexpr (MULTI) {   // park the component's predicted mean / covariance until its next turn (also the carry out)
-        BF_UNROLL for (int r = 0; r < 16; ++r) {
-          const int row = c_row(r, lane);
-          if (lr < nr && row < nr) gP[(bk0 + k) * nr * nr + row * nr + lr] = Pacc[r];
-        }
-        if (lane < nr) gm[(bk0 + k) * nr + lane] = sm[lane];
-      }
+      store_tile32(out.pP, bt, t, lane, Pacc, nr, kc);
+      store_terms_transposed(Pn, TERM, PITCH, 0, 0, lane, Pacc);
+      if (out.pm.p && lane < nr) out.pm.p[bt * out.pm.sB + kc * out.pm.sK + t * out.pm.sT + lane * out.pm.sE] = sm[lane];
     }
     wave_lds_order();
-   }
-    if constexpr (MULTI) {
-      // ---- weight update (inference.py:347-350): lls -= max; w = exp(lls) * w; w /= sum(w) over the lanes, adjacent-pair trees
-      // (lanes beyond K carry -inf / 0: the identities of the two trees)
-      float mx = lane < K ? llk : -__builtin_inff();
-      BF_UNROLL for (int off = 1; off < 64; off <<= 1) {
-        const float o = __shfl_xor(mx, off, 64);
-        mx = (mx != mx || o != o) ? __builtin_nanf("") : fmaxf(mx, o);   // jnp.max propagates NaN
-      }
-      const float e = lane < K ? expf(llk - mx) * w : 0.f;
-      float tot = e;
-      BF_UNROLL for (int off = 1; off < 64; off <<= 1) tot += __shfl_xor(tot, off, 64);
-      w = e / tot;
-      if (lane < K && out.w.p) out.w.p[b * out.w.sB + lane * out.w.sK + t * out.w.sT] = w;
-    }
   }
 
-  if constexpr (MULTI) {   // (gm / gP ARE the carry-out buffers when the caller asked for them)
-    if (carry.w_out && lane < K) carry.w_out[bk0 + lane] = w;
-    return;
-  }
   if (carry.P_out && lr < nr) BF_UNROLL for (int r = 0; r < 16; ++r) {
       const int row = c_row(r, lane);
       if (row < nr) carry.P_out[b * nr * nr + row * nr + lr] = Pacc[r];
     }
   if (carry.m_out && lane < nr) carry.m_out[b * nr + lane] = sm[lane];
-  if (carry.w_out && lane == 0) carry.w_out[b] = w;
+  if (!MULTI && carry.w_out && lane == 0) carry.w_out[b] = w;
 }
 
+
+// The weight recursion of the Gaussian-sum filter (inference.py:347-350) on stored per-step log-likelihoods: one wave per
+// trajectory, component k in lane k (K <= 64), w_t = exp(ll_t - max ll_t) w_{t-1} / sum, the max and the sum as xor-butterflies
+// over the lanes = the oracle's adjacent-pair trees (lanes beyond K carry -inf / 0, the trees' identities).
+__global__ void __launch_bounds__(64)
+gsf_reweight_kernel(SView ll, SView wout, const float* __restrict__ w_in, float* __restrict__ w_out, long long T, int K) {
+  const long long b = blockIdx.x;
+  const int lane = threadIdx.x;
+  float w = lane < K ? (w_in ? w_in[b * K + lane] : 1.0f / (float)K) : 0.f;
+  for (long long t = 0; t < T; ++t) {
+    const float l = lane < K ? ll.p[b * ll.sB + lane * ll.sK + t * ll.sT] : -__builtin_inff();
+    float mx = l;
+    BF_UNROLL for (int off = 1; off < 64; off <<= 1) {
+      const float o = __shfl_xor(mx, off, 64);
+      mx = (mx != mx || o != o) ? __builtin_nanf("") : fmaxf(mx, o);   // jnp.max propagates NaN
+    }
+    const float e = lane < K ? expf(l - mx) * w : 0.f;
+    float tot = e;
+    BF_UNROLL for (int off = 1; off < 64; off <<= 1) tot += __shfl_xor(tot, off, 64);
+    w = e / tot;
+    if (lane < K && wout.p) wout.p[b * wout.sB + lane * wout.sK + t * wout.sT] = w;
+  }
+  if (w_out && lane < K) w_out[b * K + lane] = w;
+}
+
+// MULTI launches: the per-step log-likelihoods go to the caller's stream when there is one, else to a stream-ordered scratch
+// [B][K][T] (freed by finish_multi after the weight pass)
+static int begin_multi(const bf_out_desc* out, long long B, long long T, int K, hipStream_t stream, OutViews& ov, float** scratch) {
+  *scratch = nullptr;
+  if (!ov.ll.p) {
+    BF_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(scratch), sizeof(float) * (size_t)B * K * T, stream));
+    ov.ll = SView{*scratch, (long long)K * T, T, 1, 1};
+  }
+  (void)out;
+  return BF_OK;
+}
+static int finish_multi(const OutViews& ov, const bf_carry* carry, long long B, long long T, int K, hipStream_t stream, float* scratch) {
+  hipLaunchKernelGGL(gsf_reweight_kernel, dim3((unsigned)B), dim3(64), 0, stream, ov.ll, ov.w, carry->w_in, carry->w_out, T, K);
+  const hipError_t le = hipGetLastError();
+  if (scratch) (void)hipFreeAsync(scratch, stream);
+  BF_HIP_CHECK(le);
+  return BF_OK;
+}
 
 // Per-step covariance products for the matrix-core kernels, formed ON THE DEVICE: out[t] = W C_t W^T zero-padded into an
 // NP x NP block (W = G, C = Q: n x dq; or W = D, C = R: m x dr), with diag_from .. NP - 1 set to 1 (the unit noise of padded
@@ -1851,37 +1800,30 @@ int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
   OutViews ov{make_sview(out->weights), make_sview(out->means), make_sview(out->covs),
               make_sview(out->pred_means), make_sview(out->pred_covs), make_sview(out->loglik)};
   const Bf32Const* dc = static_cast<const Bf32Const*>(dv);
-  const dim3 grid((unsigned)((B + 1) / 2)), block(128);
+  const long long chains = multi ? B * K : B;
+  const dim3 grid((unsigned)((chains + 1) / 2)), block(128);
   const bool tv = d_tvq || d_tvr;
   auto free_tables = [&]() {
     if (d_tvq) (void)hipFreeAsync(d_tvq, stream);
     if (d_tvr) (void)hipFreeAsync(d_tvr, stream);
   };
-  if (!multi) {
-    if (tv) hipLaunchKernelGGL((kf_scan_bf32_kernel<false, true>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, B, T, nr, mr, 1, nullptr, nullptr, d_tvq, d_tvr);
-    else hipLaunchKernelGGL((kf_scan_bf32_kernel<false, false>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, B, T, nr, mr, 1, nullptr, nullptr, nullptr, nullptr);
-    const hipError_t le0 = hipGetLastError();
-    free_tables();
-    BF_HIP_CHECK(le0);
-    return BF_OK;
+  float* llscratch = nullptr;
+  if (multi) {
+    const int rc = begin_multi(out, B, T, K, stream, ov, &llscratch);
+    if (rc != BF_OK) { free_tables(); return rc; }
   }
-  // components in turn: their predicted means / covariances wait in the caller's carry-out buffers when given, else in a
-  // stream-ordered scratch (m_out / P_out may alias m_in / P_in: a component's input is read at t = 0, before its slot is written)
-  float* gm = carry->m_out;
-  float* gP = carry->P_out;
-  float* scratch = nullptr;
-  if (!gm || !gP) {
-    const size_t fl = (size_t)B * K * ((size_t)nr + (size_t)nr * nr);
-    BF_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(float) * fl, stream));
-    if (!gm) gm = scratch;
-    if (!gP) gP = scratch + (size_t)B * K * nr;
+  if (multi) {
+    if (tv) hipLaunchKernelGGL((kf_scan_bf32_kernel<true, true>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, chains, T, nr, mr, K, d_tvq, d_tvr);
+    else hipLaunchKernelGGL((kf_scan_bf32_kernel<true, false>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, chains, T, nr, mr, K, nullptr, nullptr);
+  } else {
+    if (tv) hipLaunchKernelGGL((kf_scan_bf32_kernel<false, true>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, chains, T, nr, mr, 1, d_tvq, d_tvr);
+    else hipLaunchKernelGGL((kf_scan_bf32_kernel<false, false>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, chains, T, nr, mr, 1, nullptr, nullptr);
   }
-  if (tv) hipLaunchKernelGGL((kf_scan_bf32_kernel<true, true>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, B, T, nr, mr, K, gm, gP, d_tvq, d_tvr);
-  else hipLaunchKernelGGL((kf_scan_bf32_kernel<true, false>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, B, T, nr, mr, K, gm, gP, nullptr, nullptr);
-  const hipError_t le = hipGetLastError();
-  if (scratch) (void)hipFreeAsync(scratch, stream);
+  const hipError_t le0 = hipGetLastError();
   free_tables();
-  BF_HIP_CHECK(le);
+  if (le0 != hipSuccess && llscratch) (void)hipFreeAsync(llscratch, stream);
+  BF_HIP_CHECK(le0);
+  if (multi) return finish_multi(ov, carry, B, T, K, stream, llscratch);
   return BF_OK;
 }
 
@@ -2014,28 +1956,29 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
     static const int rot_mode = [] { const char* e = std::getenv("BAYESFILT_MFMA_ROT"); return e ? std::atoi(e) : 1; }();
     if (var == 5) {
       const size_t lds5 = 3 * 64 * 144 + 3 * 32 * 144 + 3 * 64 * 80 + sizeof(float) * (size_t)(M * (N + 1) + 2 * M * (M + 1) + 5 * N + 2 * M);
-      float* gm = carry->m_out;
-      float* gP = carry->P_out;
-      float* scratch = nullptr;
-      if (multi && (!gm || !gP)) {   // components in turn: parked in the carry-out buffers when given, else a stream-ordered scratch
-        const size_t fl = (size_t)B * K * ((size_t)nr + (size_t)nr * nr);
-        BF_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(float) * fl, stream));
-        if (!gm) gm = scratch;
-        if (!gP) gP = scratch + (size_t)B * K * nr;
+      const long long chains = multi ? B * K : B;
+      float* llscratch = nullptr;
+      auto free_tables = [&]() {
+        if (d_tvq) (void)hipFreeAsync(d_tvq, stream);
+        if (d_tvr) (void)hipFreeAsync(d_tvr, stream);
+      };
+      if (multi) {
+        const int rc = begin_multi(out, B, T, K, stream, ov, &llscratch);
+        if (rc != BF_OK) { free_tables(); return rc; }
       }
       auto go = [&](auto kern5) {
         const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kern5), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
         if (ae != hipSuccess) return ae;
-        hipLaunchKernelGGL(kern5, dim3((unsigned)B), dim3(256), lds5, stream, d, yv, cv, ov, B, T, rot_mode, nr, mr, K, gm, gP, d_tvq, d_tvr);
+        hipLaunchKernelGGL(kern5, dim3((unsigned)chains), dim3(256), lds5, stream, d, yv, cv, ov, chains, T, rot_mode, nr, mr, K, d_tvq, d_tvr);
         return hipGetLastError();
       };
       hipError_t le;
       if (multi) le = tv ? go(kf_scan_mfma5_kernel<N, M, true, true>) : go(kf_scan_mfma5_kernel<N, M, true, false>);
       else le = tv ? go(kf_scan_mfma5_kernel<N, M, false, true>) : go(kf_scan_mfma5_kernel<N, M, false, false>);
-      if (scratch) (void)hipFreeAsync(scratch, stream);
-      if (d_tvq) (void)hipFreeAsync(d_tvq, stream);
-      if (d_tvr) (void)hipFreeAsync(d_tvr, stream);
+      free_tables();
+      if (le != hipSuccess && llscratch) (void)hipFreeAsync(llscratch, stream);
       BF_HIP_CHECK(le);
+      if (multi) return finish_multi(ov, carry, B, T, K, stream, llscratch);
       return BF_OK;
     }
     const size_t lds_bytes = var == 4 ? sizeof(float) * (size_t)(2 * N * (N + 1) + M * (N + 1) + 2 * M * (M + 1) + 3 * N + M)
