@@ -25,7 +25,7 @@ int launch_kf_group(const bf_lgssm* p, const bf_cstream* y, long long B, long lo
 int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
                    const bf_out_desc* out, hipStream_t stream, int K, bool multi);
 int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry, const bf_out_desc* out,
-                   hipStream_t stream, int K, bool multi);
+                   hipStream_t stream, int K, bool multi, int dyn_kind, const float* dth);
 int launch_kf_generic(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
                       const bf_out_desc* out, hipStream_t stream);
 int launch_gsf_generic(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int K,
@@ -232,7 +232,7 @@ int bf_kalman_filter_f32(const bf_lgssm* model, const bf_cstream* y, int64_t B, 
   // 9 <= n <= 32: one wave per trajectory on single 32 x 32 tiles, 1.8e8 steps/s whatever the size; the run-time-dimension
   // kernel is faster only for the smallest of them (n = 12, m = 4: 1.7e8; n = 16, m = 8: 1.0e8; (32, 32): 3.5e6)
   if (model->n >= 9 && model->n <= 32 && model->m <= 32 && (model->n >= 16 || model->m > 8) && bf::g_kf_small_mode.load() != 0)
-    return bf::with_generic_fallback(bf::launch_kf_bf32(model, y, B, T, carry, out, hs, 1, false), generic);
+    return bf::with_generic_fallback(bf::launch_kf_bf32(model, y, B, T, carry, out, hs, 1, false, 0, nullptr), generic);
   if (model->n >= 24 && model->n <= 64 && model->m <= 32)
     return bf::with_generic_fallback(bf::launch_kf_mfma(model, y, B, T, carry, out, hs, 1, false), generic);
   return bf::with_generic_fallback(
@@ -258,17 +258,26 @@ int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream*
   // to n = 64), per-step Q_t / R_t tables included
   const bool small_tiles = model->n >= 9 && model->n <= 32 && model->m <= 32 && (model->n >= 16 || model->m > 8) && bf::g_kf_small_mode.load() != 0;
   const bool big_tiles = !small_tiles && model->n >= 24 && model->n <= 64 && model->m <= 32;
-  if (model->dyn_id == 0 && model->emi_id == 0 && model->flags == 0 && (small_tiles || big_tiles) && K <= 64 && !out->coll_mean.ptr &&
-      !out->coll_cov.ptr && model->n_dyn_theta == model->n * model->n + model->n * model->dq &&
-      model->n_emi_theta == model->m * model->n + model->m * model->dr) {
+  const bool lin_emi = model->emi_id == 0 && model->n_emi_theta == model->m * model->n + model->m * model->dr;
+  const bool lin_dyn = model->dyn_id == 0 && model->n_dyn_theta == model->n * model->n + model->n * model->dq;
+  // registry dynamics with an analytic, sparse Jacobian and identity noise input: extended Kalman chains on the one-wave kernel
+  const int dyn_kind = (model->dyn_id == 1 && model->n_dyn_theta == 5 && model->dq == model->n) ? 1
+                     : (model->dyn_id == 4 && model->n_dyn_theta == 1 && model->dq == model->n) ? 2 : 0;
+  if (lin_emi && model->flags == 0 && K <= 64 && !out->coll_mean.ptr && !out->coll_cov.ptr &&
+      ((lin_dyn && (small_tiles || big_tiles)) || (dyn_kind != 0 && small_tiles))) {
     bf_lgssm lg;
     std::memset(&lg, 0, sizeof(lg));
     lg.n = model->n; lg.dq = model->dq; lg.m = model->m; lg.dr = model->dr;
-    lg.A = model->dyn_theta; lg.G = model->dyn_theta + model->n * model->n;
+    if (lin_dyn) { lg.A = model->dyn_theta; lg.G = model->dyn_theta + model->n * model->n; }
     lg.H = model->emi_theta; lg.D = model->emi_theta + model->m * model->n;
     lg.q0 = model->q0; lg.r0 = model->r0; lg.Q = model->Q; lg.R = model->R;
     lg.Q_steps = model->Q_steps > 0 ? model->Q_steps : 1; lg.R_steps = model->R_steps > 0 ? model->R_steps : 1;
-    if (small_tiles) return bf::with_generic_fallback(bf::launch_kf_bf32(&lg, y, B, T, carry, out, hs, K, K > 1), generic);
+    if (!lin_dyn) {
+      float dth[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < model->n_dyn_theta && i < 8; ++i) dth[i] = model->dyn_theta[i];
+      return bf::with_generic_fallback(bf::launch_kf_bf32(&lg, y, B, T, carry, out, hs, K, true, dyn_kind, dth), generic);
+    }
+    if (small_tiles) return bf::with_generic_fallback(bf::launch_kf_bf32(&lg, y, B, T, carry, out, hs, K, K > 1, 0, nullptr), generic);
     return bf::with_generic_fallback(bf::launch_kf_mfma(&lg, y, B, T, carry, out, hs, K, K > 1), generic);   // 33 <= n <= 64: four waves per trajectory
   }
   return bf::with_generic_fallback(

@@ -1426,6 +1426,7 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
 struct Bf32Const {
   unsigned short A3[3][32 * 32], H3[3][32 * 32];
   float GQG[32 * 32], DRD[32 * 32], Gq0[32], Dr0[32];
+  float dth[8];   // DYN != 0: the registry dynamics' scalars (Lorenz-96: alpha, beta, gamma, dt, mode; sine: w0)
 };
 __device__ __forceinline__ float dot_terms32(const u32x4 (*x)[2], const float* v, int lk) {  // sum over the lane's 16 k
   float s = 0.f;
@@ -1460,7 +1461,11 @@ constexpr int BF32_WAVE_LDS = BF32_PN_BYTES + 3 * 32 * 80 + 4 * 32 * 4;
 // per-step log-likelihood; the weight recursion (the only coupling) runs afterwards over the stored log-likelihoods
 // (gsf_reweight_kernel).  B counts chains.  TV: per-step G Q_t G^T / D R_t D^T tables (_get_params(x, 2, t),
 // inference.py:21,337-340) instead of the constants of Bf32Const.
-template <bool MULTI, bool TV>
+// DYN: 0 = linear dynamics (A as constant operand registers); 1 = Lorenz-96, 2 = sine (models.hpp: DYN_LORENZ96 / DYN_SINE):
+// an extended Kalman filter chain -- row lr of F = df/dx at the filtered mean is evaluated analytically every step
+// (inference.py:328, :61-62 take it with jacfwd), split into its three bf16 terms in the SAME operand registers, and the
+// predicted mean is f(m+) + F_q q0 instead of A m+ + G q0 (identity noise input).
+template <bool MULTI, bool TV, int DYN = 0>
 __global__ void __launch_bounds__(128, 2)
 kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry, OutViews out, long long B, long long T, int nr, int mr,
                     int K, const float* __restrict__ tvq, const float* __restrict__ tvr) {
@@ -1490,7 +1495,7 @@ kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry,
   u32x4 hop[3][2], aop[3][2];          // row lr of H and of A as bf16 terms
   BF_UNROLL for (int q = 0; q < 3; ++q) BF_UNROLL for (int c = 0; c < 2; ++c) {
     hop[q][c] = *reinterpret_cast<const u32x4*>(&cst->H3[q][lr * 32 + 16 * c + 8 * lk]);
-    aop[q][c] = *reinterpret_cast<const u32x4*>(&cst->A3[q][lr * 32 + 16 * c + 8 * lk]);
+    if constexpr (DYN == 0) aop[q][c] = *reinterpret_cast<const u32x4*>(&cst->A3[q][lr * 32 + 16 * c + 8 * lk]);
   }
   const float dr0 = cst->Dr0[lr], gq0 = cst->Gq0[lr];
   f32x16 Pacc;
@@ -1570,7 +1575,43 @@ kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry,
       }
     }
     wave_lds_order();
-    // ---- Y^T = P+^T A^T; m- = A m+ + G q0
+    float fval = 0.f;
+    if constexpr (DYN != 0) {   // F's row lr at the filtered mean (sm2), columns 16 c + 8 lk + e, and f_lr(m+)
+      gl_cf* th = per_step(cst->dth);
+      float fr[2][8];
+      BF_UNROLL for (int c = 0; c < 2; ++c) BF_UNROLL for (int e = 0; e < 8; ++e) fr[c][e] = 0.f;
+      if (lr < nr) {
+        if constexpr (DYN == 1) {   // models.hpp: DYN_LORENZ96 (gaussfiltax/nonlinearities.py:37-50)
+          const float alpha = th[0], beta = th[1], gamma = th[2], dt = th[3];
+          const bool mp = th[4] != 0.f;
+          const int im1 = (lr + nr - 1) % nr, ip1 = (lr + 1) % nr, im2 = (lr + 2 * nr - 2) % nr;
+          const float xi = sm2[lr], ax = sm2[im1];
+          const float bx = mp ? (sm2[ip1] - sm2[im2]) : 0.f;
+          fval = xi + dt * (alpha * (ax * bx) - beta * xi + gamma);
+          BF_UNROLL for (int c = 0; c < 2; ++c) BF_UNROLL for (int e = 0; e < 8; ++e) {
+            const int j = 16 * c + 8 * lk + e;
+            float v = 0.f;
+            if (j == lr) v += 1.0f - dt * beta;
+            if (mp) {
+              if (j == im1) v += dt * alpha * bx;
+              if (j == ip1) v += dt * alpha * ax;
+              if (j == im2) v -= dt * alpha * ax;
+            }
+            fr[c][e] = v;
+          }
+        } else {                    // models.hpp: DYN_SINE
+          const float w0 = th[0], xi = sm2[lr];
+          fval = sinf(w0 * xi);
+          const float d = w0 * cosf(w0 * xi);
+          BF_UNROLL for (int c = 0; c < 2; ++c) BF_UNROLL for (int e = 0; e < 8; ++e) fr[c][e] = (16 * c + 8 * lk + e == lr) ? d : 0.f;
+        }
+      }
+      BF_UNROLL for (int c = 0; c < 2; ++c) BF_UNROLL for (int d = 0; d < 4; ++d) {
+        const Split3 sp = split_pair(fr[c][2 * d], fr[c][2 * d + 1]);
+        aop[0][c][d] = sp.hi; aop[1][c][d] = sp.mid; aop[2][c][d] = sp.lo;
+      }
+    }
+    // ---- Y^T = P+^T A^T; m- = A m+ + G q0 (DYN: f(m+) + F_q q0)
     {
       f32x16 acc = {0};
       BF_UNROLL for (int c = 0; c < 2; ++c) {
@@ -1580,9 +1621,13 @@ kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry,
         acc = mfma_bf6(a, ba, acc);
       }
       store_terms_transposed(Yn, TERM, PITCH, 0, 0, lane, acc);
-      float s = dot_terms32(aop, sm2, lk);
-      s += __shfl_xor(s, 32, 64);
-      sm[lr] = s + gq0;
+      if constexpr (DYN == 0) {
+        float s = dot_terms32(aop, sm2, lk);
+        s += __shfl_xor(s, 32, 64);
+        sm[lr] = s + gq0;
+      } else {
+        sm[lr] = fval + gq0;
+      }
     }
     wave_lds_order();
     // ---- P- = Y A^T + G Q G^T; predicted streams
@@ -1700,8 +1745,10 @@ static int tv_table_on_device(const float* W_host, const float* C_host, long lon
 }
 
 // K = 1: bf_kalman_filter_f32; K >= 1: the Gaussian-sum filter of a linear model (bf_gsf_ekf_f32), components in turn.
+// dyn_kind: 0 = linear (p->A), 1 = Lorenz-96, 2 = sine with scalars dth (identity noise input: p->G == NULL, dq == n); nonlinear
+// chains always run as `multi` (K >= 1).
 int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry, const bf_out_desc* out,
-                   hipStream_t stream, int K, bool multi) {
+                   hipStream_t stream, int K, bool multi, int dyn_kind, const float* dth) {
   constexpr int N = 32;
   const int nr = p->n, mr = p->m, dq = p->dq, dr = p->dr;
   if (nr > N || mr > N) return set_error(BF_EUNSUPPORTED, "one-wave matrix-core Kalman kernel: n <= 32 and m <= 32");
@@ -1724,11 +1771,14 @@ int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
     std::memcpy(&f, &u, 4);
     return f;
   };
-  for (int i = 0; i < nr; ++i)
-    for (int j = 0; j < nr; ++j) {
-      float x = p->A[i * nr + j];
-      for (int t3 = 0; t3 < 3; ++t3) { const unsigned short hb = bf(x); h->A3[t3][i * N + j] = hb; x -= fl(hb); }
-    }
+  if (dyn_kind != 0 && (!multi || p->G || dq != nr)) { delete h; return set_error(BF_EINVAL, "nonlinear chains: identity noise input, multi launch"); }
+  for (int i = 0; i < 8; ++i) h->dth[i] = (dyn_kind != 0 && dth) ? dth[i] : 0.f;
+  if (dyn_kind == 0)
+    for (int i = 0; i < nr; ++i)
+      for (int j = 0; j < nr; ++j) {
+        float x = p->A[i * nr + j];
+        for (int t3 = 0; t3 < 3; ++t3) { const unsigned short hb = bf(x); h->A3[t3][i * N + j] = hb; x -= fl(hb); }
+      }
   for (int i = 0; i < mr; ++i)
     for (int j = 0; j < nr; ++j) {
       float x = p->H[i * nr + j];
@@ -1812,7 +1862,13 @@ int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
     const int rc = begin_multi(out, B, T, K, stream, ov, &llscratch);
     if (rc != BF_OK) { free_tables(); return rc; }
   }
-  if (multi) {
+  if (multi && dyn_kind == 1) {
+    if (tv) hipLaunchKernelGGL((kf_scan_bf32_kernel<true, true, 1>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, chains, T, nr, mr, K, d_tvq, d_tvr);
+    else hipLaunchKernelGGL((kf_scan_bf32_kernel<true, false, 1>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, chains, T, nr, mr, K, nullptr, nullptr);
+  } else if (multi && dyn_kind == 2) {
+    if (tv) hipLaunchKernelGGL((kf_scan_bf32_kernel<true, true, 2>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, chains, T, nr, mr, K, d_tvq, d_tvr);
+    else hipLaunchKernelGGL((kf_scan_bf32_kernel<true, false, 2>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, chains, T, nr, mr, K, nullptr, nullptr);
+  } else if (multi) {
     if (tv) hipLaunchKernelGGL((kf_scan_bf32_kernel<true, true>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, chains, T, nr, mr, K, d_tvq, d_tvr);
     else hipLaunchKernelGGL((kf_scan_bf32_kernel<true, false>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, chains, T, nr, mr, K, nullptr, nullptr);
   } else {

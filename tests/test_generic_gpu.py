@@ -286,3 +286,50 @@ def test_time_varying_kalman_on_the_matrix_cores():
             for k in FIELDS:
                 assert cm.rel_err(getattr(post, k)[b].cpu().numpy(), getattr(ref, k)) < 1e-5, (b, k)
             assert cm.rel_err(ll[b].cpu().numpy(), rll) < 2e-5
+
+
+@pytest.mark.parametrize("model,n,K,tv", [("lorenz96", 16, 4, False), ("lorenz96", 32, 32, False), ("lorenz96", 24, 5, True), ("lorenz96_as_written", 32, 3, False),
+                                          ("sine", 16, 6, False), ("lorenz96", 20, 1, False)])
+def test_extended_kalman_chains_on_the_matrix_cores(model, n, K, tv):
+    """Gaussian-sum filters of NONLINEAR registry dynamics with a linear emission (Lorenz-96 with the even-state emission,
+    gaussfiltax/nonlinearities.py:37-52, at 16 <= n <= 32; the sine map) on the one-wave matrix-core kernel: the Jacobian's
+    row is evaluated analytically at the filtered mean every step (inference.py:328, :61-62) and re-split into bf16 terms in
+    the operand registers.  Against the oracle at 1e-5, against the run-time-dimension kernel, chunked == one shot."""
+    import torch
+    import bayesianfiltering_amd as bfa
+    nl = bfa.nonlinearities
+    m, T, B = n // 2, 14, 3
+    rng = np.random.default_rng(n + K)
+    Q, R = (1e-2 * np.eye(n)).astype(F32), (1e-1 * np.eye(m)).astype(F32)
+    q0 = (0.01 * rng.normal(size=n)).astype(F32)
+    if model.startswith("lorenz96"):
+        mode = "as_written" if model.endswith("as_written") else "matrix_power"
+        m0 = 8 * np.ones(n, F32)
+        fo, fp = om.Lorenz96(n, mode=mode), nl.lorenz96(n, mode=mode)
+    else:
+        m0 = np.zeros(n, F32)
+        fo, fp = om.Sine(n, 1.5), nl.sine(n, 1.5)
+    po = go.ParamsNLSSM(m0, np.eye(n, dtype=F32), fo, q0, Q, om.PickEven(n), np.zeros(m, F32), R)
+    pp = bfa.ParamsNLSSM(m0, np.eye(n, dtype=F32), fp, q0, Q, nl.pick_even(n), np.zeros(m, F32), R)
+    ys = np.stack([go.sample_ssm(po, otf.PRNGKey(b), T)[1] for b in range(B)])
+    if tv:
+        Qt = np.stack([(0.6 + rng.random()) * Q for _ in range(T)]).astype(F32)
+        pp, po = pp._replace(dynamics_noise_covariance=Qt), po._replace(dynamics_noise_covariance=Qt)
+    im = (m0 + 0.5 * rng.normal(size=(B, K, n))).astype(F32)
+    post, ll, carry = bfa.gaussian_sum_filter(pp, ys, K, 1, initial_means=im, return_loglik=True, return_carry=True)
+    with _forced():
+        slow = bfa.gaussian_sum_filter(pp, ys, K, 1, initial_means=im)
+    assert not torch.equal(post.covariances, slow.covariances)          # (another kernel did run: the two round differently)
+    for b in range(B):
+        ref, rll = go.gaussian_sum_filter(po, ys[b], K, initial_means=im[b], return_ll=True)
+        for k in FIELDS:
+            assert cm.rel_err(getattr(post, k)[b].cpu().numpy(), getattr(ref, k)) < 1e-5, (b, k, cm.rel_err(getattr(post, k)[b].cpu().numpy(), getattr(ref, k)))
+            assert cm.rel_err(getattr(post, k)[b].cpu().numpy(), getattr(slow, k)[b].cpu().numpy()) < 1e-5, (b, k)
+        assert np.max(np.abs(post.weights[b].cpu().numpy() - ref.weights)) < 2e-5, b
+        assert cm.rel_err(ll[b].cpu().numpy(), rll) < 2e-5, b
+    h1, c1 = bfa.gaussian_sum_filter(pp if not tv else pp._replace(dynamics_noise_covariance=Qt[:6]), ys[:, :6], K, 1, initial_means=im, return_carry=True)
+    h2, c2 = bfa.gaussian_sum_filter(pp if not tv else pp._replace(dynamics_noise_covariance=Qt[6:]), ys[:, 6:], K, 1, carry=c1, return_carry=True)
+    for k in FIELDS + ("weights",):
+        assert torch.equal(torch.cat([getattr(h1, k), getattr(h2, k)], dim=2), getattr(post, k)), k
+    for x, y_ in zip(c2, carry):
+        assert torch.equal(x, y_)
