@@ -23,7 +23,7 @@ int launch_kf_group(const bf_lgssm* p, const bf_cstream* y, long long B, long lo
                     const bf_out_desc* out, hipStream_t stream, int force_mode, int lanes);
 
 int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
-                   const bf_out_desc* out, hipStream_t stream, int K, bool multi);
+                   const bf_out_desc* out, hipStream_t stream, int K, bool multi, int dyn_kind, const float* dth);
 int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry, const bf_out_desc* out,
                    hipStream_t stream, int K, bool multi, int dyn_kind, const float* dth);
 int launch_kf_generic(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
@@ -234,7 +234,7 @@ int bf_kalman_filter_f32(const bf_lgssm* model, const bf_cstream* y, int64_t B, 
   if (model->n >= 9 && model->n <= 32 && model->m <= 32 && (model->n >= 16 || model->m > 8) && bf::g_kf_small_mode.load() != 0)
     return bf::with_generic_fallback(bf::launch_kf_bf32(model, y, B, T, carry, out, hs, 1, false, 0, nullptr), generic);
   if (model->n >= 24 && model->n <= 64 && model->m <= 32)
-    return bf::with_generic_fallback(bf::launch_kf_mfma(model, y, B, T, carry, out, hs, 1, false), generic);
+    return bf::with_generic_fallback(bf::launch_kf_mfma(model, y, B, T, carry, out, hs, 1, false, 0, nullptr), generic);
   return bf::with_generic_fallback(
       bf::launch_kf_group(model, y, B, T, carry, out, hs, bf::g_kf_emit_mode.load(), bf::g_kf_lanes.load()), generic);
 }
@@ -264,7 +264,7 @@ int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream*
   const int dyn_kind = (model->dyn_id == 1 && model->n_dyn_theta == 5 && model->dq == model->n) ? 1
                      : (model->dyn_id == 4 && model->n_dyn_theta == 1 && model->dq == model->n) ? 2 : 0;
   if (lin_emi && model->flags == 0 && K <= 64 && !out->coll_mean.ptr && !out->coll_cov.ptr &&
-      ((lin_dyn && (small_tiles || big_tiles)) || (dyn_kind != 0 && small_tiles))) {
+      (small_tiles || big_tiles) && (lin_dyn || dyn_kind != 0)) {
     bf_lgssm lg;
     std::memset(&lg, 0, sizeof(lg));
     lg.n = model->n; lg.dq = model->dq; lg.m = model->m; lg.dr = model->dr;
@@ -275,10 +275,11 @@ int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream*
     if (!lin_dyn) {
       float dth[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int i = 0; i < model->n_dyn_theta && i < 8; ++i) dth[i] = model->dyn_theta[i];
-      return bf::with_generic_fallback(bf::launch_kf_bf32(&lg, y, B, T, carry, out, hs, K, true, dyn_kind, dth), generic);
+      if (small_tiles) return bf::with_generic_fallback(bf::launch_kf_bf32(&lg, y, B, T, carry, out, hs, K, true, dyn_kind, dth), generic);
+      return bf::with_generic_fallback(bf::launch_kf_mfma(&lg, y, B, T, carry, out, hs, K, true, dyn_kind, dth), generic);
     }
     if (small_tiles) return bf::with_generic_fallback(bf::launch_kf_bf32(&lg, y, B, T, carry, out, hs, K, K > 1, 0, nullptr), generic);
-    return bf::with_generic_fallback(bf::launch_kf_mfma(&lg, y, B, T, carry, out, hs, K, K > 1), generic);   // 33 <= n <= 64: four waves per trajectory
+    return bf::with_generic_fallback(bf::launch_kf_mfma(&lg, y, B, T, carry, out, hs, K, K > 1, 0, nullptr), generic);   // 33 <= n <= 64: four waves per trajectory
   }
   return bf::with_generic_fallback(
       bf::launch_gsf_ekf(model, y, u, B, T, K, carry, out, hs, bf::g_kf_emit_mode.load(), bf::g_kf_lanes.load()), generic);

@@ -53,6 +53,7 @@ using lds_f4 = const __attribute__((address_space(3))) v4f;
 template <int N, int M>
 struct MfmaConst {  // device-resident (too large for kernel arguments)
   float A[N * N], H[M * N], GQG[N * N], DRD[M * M], Gq0[N], Dr0[M];
+  float dth[8];   // DYN != 0: the registry dynamics' scalars
   unsigned short A3[3][N * N], H3[3][M * N];  // variant 5: A = A3[0] + A3[1] + A3[2] exactly, three bf16 terms (row-major)
 };
 
@@ -1196,7 +1197,9 @@ __device__ __forceinline__ float dot_terms_half(const u32x4 (*x)[4], const float
 // trajectory * K + component reads trajectory c / K's observations and writes component c % K's streams and per-step
 // log-likelihood; the weights follow in gsf_reweight_kernel.  TV: per-step G Q_t G^T / D R_t D^T tables (64 x 64 and 32 x 32
 // floats per step) instead of the constants -- inference.py:21,337-353.
-template <int N, int M, bool MULTI = false, bool TV = false>
+// DYN: 0 = linear; 1 = Lorenz-96, 2 = sine dynamics as extended Kalman chains (see kf_scan_bf32_kernel): the wave's rows of
+// F = df/dx at the filtered mean are re-evaluated and re-split into the A operand registers every step.
+template <int N, int M, bool MULTI = false, bool TV = false, int DYN = 0>
 __global__ void __launch_bounds__(256, 2)
 kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView carry, OutViews out, long long B, long long T,
                      int rot_mode, int nr, int mr, int K, const float* __restrict__ tvq, const float* __restrict__ tvr) {
@@ -1242,7 +1245,7 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
   u32x4 hop[3][4], aop[3][4];
   BF_UNROLL for (int t = 0; t < 3; ++t) BF_UNROLL for (int c = 0; c < 4; ++c) {
     hop[t][c] = *reinterpret_cast<const u32x4*>(&cst->H3[t][lr * N + 16 * c + 8 * lk]);
-    aop[t][c] = *reinterpret_cast<const u32x4*>(&cst->A3[t][(32 * tj + lr) * N + 16 * c + 8 * lk]);
+    if constexpr (DYN == 0) aop[t][c] = *reinterpret_cast<const u32x4*>(&cst->A3[t][(32 * tj + lr) * N + 16 * c + 8 * lk]);
   }
   f32x16 Pacc;  // the wave's tile of P-: carried in registers from phase J to phase H
   const bool col_ok = 32 * tj + lr < nr;
@@ -1364,6 +1367,46 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
 #endif
       BF_UNROLL for (int r = 0; r < 16; ++r) gq[r] = gqg_t[(32 * ti + c_row(r, lane)) * N + 32 * tj + lr];
     }
+    if constexpr (DYN != 0) {   // row 32 tj + lr of F at the filtered mean (mnxt), columns 16 c + 8 lk + e; f of that row
+      gl_cf* th = per_step(cst->dth);
+      const int row = 32 * tj + lr;
+      float fv = 0.f;
+      BF_UNROLL for (int c = 0; c < 4; ++c) {
+        float fr[8];
+        BF_UNROLL for (int e = 0; e < 8; ++e) fr[e] = 0.f;
+        if (row < nr) {
+          if constexpr (DYN == 1) {
+            const float alpha = th[0], beta = th[1], gamma = th[2], dt = th[3];
+            const bool mp = th[4] != 0.f;
+            const int im1 = (row + nr - 1) % nr, ip1 = (row + 1) % nr, im2 = (row + 2 * nr - 2) % nr;
+            const float xi = mnxt[row], ax = mnxt[im1];
+            const float bx = mp ? (mnxt[ip1] - mnxt[im2]) : 0.f;
+            fv = xi + dt * (alpha * (ax * bx) - beta * xi + gamma);
+            BF_UNROLL for (int e = 0; e < 8; ++e) {
+              const int j = 16 * c + 8 * lk + e;
+              float v = 0.f;
+              if (j == row) v += 1.0f - dt * beta;
+              if (mp) {
+                if (j == im1) v += dt * alpha * bx;
+                if (j == ip1) v += dt * alpha * ax;
+                if (j == im2) v -= dt * alpha * ax;
+              }
+              fr[e] = v;
+            }
+          } else {
+            const float w0 = th[0], xi = mnxt[row];
+            fv = sinf(w0 * xi);
+            const float d = w0 * cosf(w0 * xi);
+            BF_UNROLL for (int e = 0; e < 8; ++e) fr[e] = (16 * c + 8 * lk + e == row) ? d : 0.f;
+          }
+        }
+        BF_UNROLL for (int d = 0; d < 4; ++d) {
+          const Split3 sp = split_pair(fr[2 * d], fr[2 * d + 1]);
+          aop[0][c][d] = sp.hi; aop[1][c][d] = sp.mid; aop[2][c][d] = sp.lo;
+        }
+      }
+      if (ti == 0 && lane < 32) { part[32 * tj + lane] = fv; part[N + 32 * tj + lane] = 0.f; }   // (read back as part[.] + part[N + .])
+    }
     {
       f32x16 acc = {0};
       BF_UNROLL for (int c = 0; c < 4; ++c) {
@@ -1374,7 +1417,7 @@ kf_scan_mfma5_kernel(const MfmaConst<N, M>* __restrict__ cst, CView y, CarryView
       }
       store_terms_transposed(Yn, PN_TERM, PITCH, ti, tj, lane, acc);
     }
-    {  // A m+: the two waves holding rows 32 tj + lr take half of the k range each
+    if constexpr (DYN == 0) {  // A m+: the two waves holding rows 32 tj + lr take half of the k range each
       float s = dot_terms_half(aop, mnxt, lk, ti);
       s += __shfl_xor(s, 32, 64);
       if (lane < 32) part[ti * N + 32 * tj + lane] = s;
@@ -1886,7 +1929,7 @@ int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
 // ---------------------------------------------------------------------------------------
 // K = 1, multi = false: bf_kalman_filter_f32; multi: the Gaussian-sum filter of a linear model (bf_gsf_ekf_f32), components in turn.
 int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
-                   const bf_out_desc* out, hipStream_t stream, int K, bool multi) {
+                   const bf_out_desc* out, hipStream_t stream, int K, bool multi, int dyn_kind, const float* dth) {
   constexpr int N = 64, M = 32;
   // Smaller models ride in the (64, 32) tiles zero-padded (variant 5): A, H, G Q G^T padded with zeros keep the padded
   // block of P at exactly zero; the padded observations are y = 0 with unit noise and H rows of zero, independent of the
@@ -1897,6 +1940,7 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
   if (nr > N || mr > M || (padded && g_kf_mfma_variant.load() != 5))
     return set_error(BF_EUNSUPPORTED, "MFMA Kalman kernel: n <= 64 and m <= 32 (smaller than (64, 32) on variant 5 only)");
   const bool tv = p->Q_steps > 1 || p->R_steps > 1;
+  if (dyn_kind != 0 && (!multi || p->G || p->dq != p->n)) return set_error(BF_EINVAL, "nonlinear chains: identity noise input, multi launch");
   if ((tv || multi) && g_kf_mfma_variant.load() != 5)
     return set_error(BF_EUNSUPPORTED, "MFMA Kalman kernel: per-step covariances and Gaussian-sum components need variant 5");
   if (K > 64) return set_error(BF_EUNSUPPORTED, "MFMA Kalman kernel: at most 64 components (one per lane in the weight update)");
@@ -1906,7 +1950,8 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
   MfmaConst<N, M>* h = new MfmaConst<N, M>();  // zero-filled: the constant cache compares contents
   auto Gat = [&](int i, int k) { return p->G ? p->G[i * dq + k] : (i == k ? 1.f : 0.f); };
   auto Dat = [&](int i, int k) { return p->D ? p->D[i * dr + k] : (i == k ? 1.f : 0.f); };
-  for (int i = 0; i < nr; ++i) for (int j = 0; j < nr; ++j) h->A[i * N + j] = p->A[i * nr + j];
+  for (int i = 0; i < 8; ++i) h->dth[i] = (dyn_kind != 0 && dth) ? dth[i] : 0.f;
+  if (dyn_kind == 0) for (int i = 0; i < nr; ++i) for (int j = 0; j < nr; ++j) h->A[i * N + j] = p->A[i * nr + j];
   for (int i = 0; i < mr; ++i) for (int j = 0; j < nr; ++j) h->H[i * N + j] = p->H[i * nr + j];
   {  // x = hi + mid + lo, three bf16 terms (round to nearest even), exact for finite x
     auto bf = [](float x) {
@@ -2029,7 +2074,9 @@ int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
         return hipGetLastError();
       };
       hipError_t le;
-      if (multi) le = tv ? go(kf_scan_mfma5_kernel<N, M, true, true>) : go(kf_scan_mfma5_kernel<N, M, true, false>);
+      if (multi && dyn_kind == 1) le = tv ? go(kf_scan_mfma5_kernel<N, M, true, true, 1>) : go(kf_scan_mfma5_kernel<N, M, true, false, 1>);
+      else if (multi && dyn_kind == 2) le = tv ? go(kf_scan_mfma5_kernel<N, M, true, true, 2>) : go(kf_scan_mfma5_kernel<N, M, true, false, 2>);
+      else if (multi) le = tv ? go(kf_scan_mfma5_kernel<N, M, true, true>) : go(kf_scan_mfma5_kernel<N, M, true, false>);
       else le = tv ? go(kf_scan_mfma5_kernel<N, M, false, true>) : go(kf_scan_mfma5_kernel<N, M, false, false>);
       free_tables();
       if (le != hipSuccess && llscratch) (void)hipFreeAsync(llscratch, stream);

@@ -289,10 +289,12 @@ def test_time_varying_kalman_on_the_matrix_cores():
 
 
 @pytest.mark.parametrize("model,n,K,tv", [("lorenz96", 16, 4, False), ("lorenz96", 32, 32, False), ("lorenz96", 24, 5, True), ("lorenz96_as_written", 32, 3, False),
-                                          ("sine", 16, 6, False), ("lorenz96", 20, 1, False)])
+                                          ("sine", 16, 6, False), ("lorenz96", 20, 1, False), ("lorenz96", 40, 2, False), ("lorenz96", 64, 4, True),
+                                          ("sine", 48, 3, False)])
 def test_extended_kalman_chains_on_the_matrix_cores(model, n, K, tv):
     """Gaussian-sum filters of NONLINEAR registry dynamics with a linear emission (Lorenz-96 with the even-state emission,
-    gaussfiltax/nonlinearities.py:37-52, at 16 <= n <= 32; the sine map) on the one-wave matrix-core kernel: the Jacobian's
+    gaussfiltax/nonlinearities.py:37-52, at 16 <= n <= 64; the sine map) on the matrix-core kernels (one wave per chain up to
+    n = 32, four beyond): the Jacobian's
     row is evaluated analytically at the filtered mean every step (inference.py:328, :61-62) and re-split into bf16 terms in
     the operand registers.  Against the oracle at 1e-5, against the run-time-dimension kernel, chunked == one shot."""
     import torch
