@@ -97,6 +97,50 @@ def cpu_baseline(a, T, target_s=12.0):
                       f"all five streams, {dt:.1f} s"}
 
 
+def cpu_baseline_gsf(y_host, init_host, K, mode, T, target_s=12.0):
+    """configs[2] on the host cores: the C port of the EKF bank + weight update (oracle_gsf_lorenz96_f32), all FULL5-equivalent
+    per-component streams it has (weights, means, covariances), on the first trajectories of the same observations."""
+    from oracle import c_oracle
+    cores = c_oracle.max_threads()
+    n, m = 8, 4
+    th = np.array([1.0, 1.0, 8.0, 0.01, 1.0 if mode == "matrix_power" else 0.0], F32)
+    H = np.zeros((m, n), F32)
+    H[np.arange(m), 2 * np.arange(m)] = 1
+    args = (th, H, 1e-2 * np.eye(n, dtype=F32), 1e-1 * np.eye(m, dtype=F32), np.zeros(n, F32), np.zeros(m, F32))
+    t0 = time.perf_counter()
+    c_oracle.gsf_lorenz96(*args, y_host[:cores, :500], init_host[:cores], np.eye(n, dtype=F32))
+    rate = cores * 500 / (time.perf_counter() - t0)
+    Bs = int(max(cores, min(len(y_host), rate * target_s / T) // cores * cores))
+    t0 = time.perf_counter()
+    c_oracle.gsf_lorenz96(*args, y_host[:Bs], init_host[:Bs], np.eye(n, dtype=F32))
+    dt = time.perf_counter() - t0
+    return {"value": Bs * T / dt, "unit": "timesteps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/c/kf_oracle.c oracle_gsf_lorenz96_f32 (OpenMP over batch), the first B={Bs} trajectories of the same "
+                      f"K={K} n={n} m={m} T={T} workload, weights + means + covariances written, {dt:.1f} s"}
+
+
+def cpu_baseline_bpf(y_host, N, T, target_s=12.0):
+    """configs[3] on the host cores: the C port of the bootstrap particle filter (oracle_bpf_lorenz96_f32: Threefry draws,
+    libm exp, sequential sums), one trajectory per core, on a prefix of the same observations."""
+    from oracle import c_oracle
+    cores = c_oracle.max_threads()
+    n, m = 16, 8
+    th = np.array([1.0, 1.0, 8.0, 0.01, 1.0], F32)
+    args = (th, np.zeros(n, F32), 1e-2 * np.ones(n, F32), 0.5 * np.ones(m, F32), 8 * np.ones(n, F32), np.ones(n, F32))
+    key = np.array([0, 1], np.uint32)
+    Bs = min(cores, len(y_host))
+    t0 = time.perf_counter()
+    c_oracle.bpf_lorenz96(*args, y_host[:Bs, :8], N, key)
+    rate = Bs * 8 / (time.perf_counter() - t0)
+    Ts = int(max(8, min(T, rate * target_s / Bs)))
+    t0 = time.perf_counter()
+    c_oracle.bpf_lorenz96(*args, y_host[:Bs, :Ts], N, key)
+    dt = time.perf_counter() - t0
+    return {"value": Bs * Ts / dt, "unit": "timesteps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/c/kf_oracle.c oracle_bpf_lorenz96_f32 (OpenMP over batch), the first {Ts} steps of the first B={Bs} "
+                      f"trajectories of the same N={N} n={n} m={m} workload, weighted means written, {dt:.1f} s"}
+
+
 def profiled(name):
     """A figure measured by rocprofv3 PMC passes in ANOTHER run and committed under profiles/ (never read as live):
     returns (value, source path) or (None, None)."""
@@ -198,7 +242,8 @@ def make_gsf32(args, rank, world, device):
                            "kernel": "gsf_scan_kernel<8,4,NL=2,EMIT_STAGED,L96_PICK>", "bytes_per_step": bps}
         work = f"Gaussian-sum filter 32 components, Lorenz-96[{args.l96_mode}] state_dim=8 obs_dim=4, T={T} batch={Bt}, FULL5 in T-chunks of {Tc}"
     return dict(kernels=kernels, summary=summary, finite=finite, units=B * T, total_units=Bt * T, scaling="strong", gather_rows=Bt,
-                roofline=roof, workload=work + ", observations drawn from the model", extra={"batch_total": Bt, "batch_this_rank": B, "T": T})
+                roofline=roof, workload=work + ", observations drawn from the model", extra={"batch_total": Bt, "batch_this_rank": B, "T": T},
+                cpu=lambda: cpu_baseline_gsf(y[:4096].cpu().numpy(), init[:4096].cpu().numpy(), K, args.l96_mode, T))
 
 
 def make_kalman64(args, rank, world, device):
@@ -301,7 +346,8 @@ def make_bpf4096(args, rank, world, device):
                 roofline=roof,
                 workload=f"bootstrap particle filter {N} particles, Lorenz-96 state_dim=16 obs_dim=8, T={T} batch={Bt}, SUMMARY output, "
                          "observations drawn from the model",
-                extra={"batch_total": Bt, "batch_this_rank": B, "T": T, "particles": N})
+                extra={"batch_total": Bt, "batch_this_rank": B, "T": T, "particles": N},
+                cpu=lambda: cpu_baseline_bpf(y[:256].cpu().numpy(), N, T))
 
 
 MAKERS = {"kalman4": make_kalman4, "gsf32": make_gsf32, "bpf4096": make_bpf4096, "kalman64": make_kalman64}
@@ -413,8 +459,8 @@ def main():
             "finite_frac": finite_frac,
             "roofline": roof,
         }
-        if args.config in ("kalman4", "kalman64") and world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(w["a"], w["T"])
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = w["cpu"]() if "cpu" in w else cpu_baseline(w["a"], w["T"])
         print(json.dumps(line), flush=True)
     if group:
         dist.destroy_process_group()

@@ -64,3 +64,43 @@ def kalman_filter(a, ys, init_means, init_covs=None, fields=("weights", "means",
 
 def max_threads():
     return load().oracle_max_threads()
+
+
+def gsf_lorenz96(theta, H, Q, R, q0, r0, ys, init_means, P0, fields=("weights", "means", "covariances"), nthreads=0):
+    """The EKF bank + weight update for Lorenz-96 dynamics / linear emission (oracle_gsf_lorenz96_f32).  ys (B, T, m),
+    init_means (B, K, n).  Returns dict of (B, K, T, ...) arrays."""
+    lib = load()
+    lib.oracle_gsf_lorenz96_f32.restype = C.c_int
+    ys = np.ascontiguousarray(ys, F32)
+    B, T, m = ys.shape
+    init_means = np.ascontiguousarray(init_means, F32)
+    K, n = init_means.shape[1], init_means.shape[2]
+    arrs = [np.ascontiguousarray(v, F32) for v in (theta, H, Q, R, q0, r0)]
+    P0 = np.ascontiguousarray(P0, F32)
+    shapes = {"weights": (B, K, T), "means": (B, K, T, n), "covariances": (B, K, T, n, n)}
+    out = {k: (np.empty(shapes[k], F32) if k in fields else None) for k in shapes}
+    rc = lib.oracle_gsf_lorenz96_f32(C.c_int(n), C.c_int(m), C.c_int(K), *[_p(a) for a in arrs], _p(ys), C.c_int64(B), C.c_int64(T),
+                                     _p(init_means), _p(P0), _p(out["weights"]), _p(out["means"]), _p(out["covariances"]), C.c_int(nthreads))
+    if rc != 0:
+        raise RuntimeError("oracle_gsf_lorenz96_f32 failed")
+    return {k: v for k, v in out.items() if v is not None}
+
+
+def bpf_lorenz96(theta, q0, Qdiag, lp_diag, m0, P0diag, ys, N, key, ess_threshold=0.5, nthreads=0):
+    """The bootstrap particle filter for Lorenz-96 dynamics, diagonal covariances, even-state emission
+    (oracle_bpf_lorenz96_f32).  ys (B, T, m).  Returns {'mean': (B, T, n), 'resampled': (B, T)}."""
+    lib = load()
+    lib.oracle_bpf_lorenz96_f32.restype = C.c_int
+    ys = np.ascontiguousarray(ys, F32)
+    B, T, m = ys.shape
+    n = len(m0)
+    arrs = [np.ascontiguousarray(v, F32) for v in (theta, q0, np.sqrt(np.asarray(Qdiag, F32)), np.sqrt(np.asarray(lp_diag, F32)), m0,
+                                                   np.sqrt(np.asarray(P0diag, F32)))]
+    key = np.ascontiguousarray(key, np.uint32)
+    mean = np.empty((B, T, n), F32)
+    res = np.empty((B, T), F32)
+    rc = lib.oracle_bpf_lorenz96_f32(C.c_int(n), C.c_int(m), C.c_int(N), *[_p(a) for a in arrs], _p(ys), C.c_int64(B), C.c_int64(T),
+                                     _p(key), C.c_float(ess_threshold), _p(mean), _p(res), C.c_int(nthreads))
+    if rc != 0:
+        raise RuntimeError("oracle_bpf_lorenz96_f32 failed")
+    return {"mean": mean, "resampled": res}

@@ -180,3 +180,37 @@ def test_golden_unscented_and_augmented_fixtures_reproduce(golden_dir):
     assert np.array_equal(aux["pre_weights"], d["pre_weights"])
     assert post.means.shape == (3, 24, 4) and np.allclose(post.weights, 1.0 / 3.0)      # :765 weights = ones / N0
     assert np.allclose(aux["pre_weights"].sum(axis=1), 1.0, atol=1e-6)
+
+
+def test_c_ports_of_the_gaussian_sum_and_particle_filters_follow_the_numpy_oracle():
+    """oracle/c/kf_oracle.c: oracle_gsf_lorenz96_f32 / oracle_bpf_lorenz96_f32 -- the timed CPU baselines of bench.py's
+    configs[2] and [3] -- against the NumPy oracle on the same inputs: the EKF bank to rounding; the particle filter with
+    identical resampling decisions and ancestors-to-rounding (its sums run sequentially, the NumPy oracle's in tree order)."""
+    n, m, K, T, B = 8, 4, 5, 30, 2
+    Q, R = 1e-2 * np.eye(n, dtype=F32), 1e-1 * np.eye(m, dtype=F32)
+    q0, r0 = np.zeros(n, F32), np.zeros(m, F32)
+    fo = om.Lorenz96(n)
+    th = np.asarray([fo.alpha, fo.beta, fo.gamma, fo.dt, 1.0], F32)
+    po = go.ParamsNLSSM(8 * np.ones(n, F32), np.eye(n, dtype=F32), fo, q0, Q, om.PickEven(n), r0, R)
+    ys = np.stack([go.sample_ssm(po, otf.PRNGKey(b), T)[1] for b in range(B)])
+    im = (8 + np.random.default_rng(0).normal(size=(B, K, n))).astype(F32)
+    H = np.zeros((m, n), F32)
+    H[np.arange(m), 2 * np.arange(m)] = 1
+    got = c_oracle.gsf_lorenz96(th, H, Q, R, q0, r0, ys, im, np.eye(n, dtype=F32))
+    for b in range(B):
+        ref = go.gaussian_sum_filter(po, ys[b], K, initial_means=im[b])
+        assert cm.rel_err(got["means"][b], ref.means) < 2e-6 and cm.rel_err(got["covariances"][b], ref.covariances) < 2e-6
+        assert np.max(np.abs(got["weights"][b] - ref.weights)) < 1e-5
+    # particle filter
+    N = 256
+    Rl = 0.5 * np.eye(m, dtype=F32)
+    pb = go.ParamsBPF(*po[:8], go.GaussianEmissionLogProb(om.PickEven(n), Rl))
+    key = np.array([0, 7], np.uint32)
+    out = c_oracle.bpf_lorenz96(th, q0, np.diag(Q), np.diag(Rl), 8 * np.ones(n, F32), np.ones(n, F32), ys, N, key)
+    for b in range(B):
+        ref, dbg = go.bootstrap_particle_filter(pb, ys[b], N, key=key, debug=True)
+        assert np.array_equal(out["resampled"][b] > 0.5, dbg["resampled"]) and dbg["resampled"].any()
+        mean = np.einsum("itd,it->td", ref["particles"], ref["weights"])
+        t_ok = int(np.argmax(np.abs(out["mean"][b] - mean).max(axis=1) > 1e-3)) if (np.abs(out["mean"][b] - mean).max(axis=1) > 1e-3).any() else T
+        assert t_ok >= 5                      # (a draw within an ulp of a CDF step flips one ancestor; the runs then part ways)
+        assert cm.rel_err(out["mean"][b][:t_ok], mean[:t_ok]) < 1e-4
