@@ -18,7 +18,9 @@
 // lax.associative_scan order (segmented Brent-Kung with __shfl_up), the inverse-CDF search and the
 // gather of the drawn leaves through LDS.
 #pragma once
+#ifndef BF_JIT
 #include <cstring>
+#endif
 #include "bf_common.hpp"
 #include "kf_math.hpp"
 #include "scan_common.hpp"
@@ -26,6 +28,7 @@
 #include "models.hpp"
 #include "gsf_scan.hpp"   // fill_model: EkfModel from the C-ABI struct
 #include "ugsf_scan.hpp"  // unscented node operations (speedy_unscented_agsf, unscented_agsf)
+#include "agsf_geom.hpp"
 
 namespace bf {
 
@@ -285,6 +288,7 @@ __device__ __forceinline__ void optimal_resampling_block(float w, int M, int N, 
 
 // What a tree node does with its Gaussian: the extended-Kalman pair _predict / _condition_on
 // (inference.py:51-105) or the unscented pair (:146-174, :198-224) of speedy_unscented_agsf (:966-1156).
+#ifndef BF_JIT
 template <int N, int M>
 struct EkfNodes {
   using Arg = EkfModel<N, M>;  // by value, in the kernel arguments
@@ -304,32 +308,92 @@ struct EkfNodes {
     return condition_on<N, M>(H, HrRHr, v, m, P);
   }
 };
-template <int N, int DQ, int M, int DR>
+#endif  // BF_JIT
+template <int N, int DQ, int M, int DR, class SP = SpecRuntime>
 struct UkfNodes {
   using Arg = const UkfModel<N, DQ, M, DR>*;  // device-resident
   // tq / tr: sqrtm(Q_t) / sqrtm(R_t) of the step, or NULL
   static constexpr int TVQ = DQ * DQ, TVR = DR * DR;
   static __device__ __forceinline__ void predict(Arg mdl, float* m, float* P, float u0, const float* tq) {
-    ukf_predict(*mdl, m, P, u0, tq ? tq : mdl->sQ);
+    ukf_predict<SP>(*mdl, m, P, u0, tq ? tq : mdl->sQ);
   }
   static __device__ __forceinline__ float condition(Arg mdl, float* m, float* P, const float* yv, float u0, const float* tr) {
-    return ukf_condition_on(*mdl, m, P, yv, u0, tr ? tr : mdl->sR);
+    return ukf_condition_on<SP>(*mdl, m, P, yv, u0, tr ? tr : mdl->sR);
   }
 };
 
-struct AgsfOut {
-  SView w, m, P;
-  int* anc;  // [B][T][N0] index of the leaf each carried component was drawn from (NULL = not emitted)
+#ifdef BF_JIT
+// Extended-Kalman nodes around functions compiled from the caller's source (user_model.hip): the Jacobians of
+// inference.py:58-61 / :82-86 (jacfwd w.r.t. the state and w.r.t. the noise, at the noise bias) by forward-mode dual numbers,
+// one seed direction after the other on the leaf's own lane; F_q Q F_q^T and H_r R H_r^T formed here every step.  The model
+// block is a UkfModel whose sQ / sR (and per-step tables) hold Q / R THEMSELVES (fill_ukf_model_view, raw-covariance flag).
+template <int N, int DQ, int M, int DR>
+struct UserEkfNodes {
+  using Arg = const UkfModel<N, DQ, M, DR>*;
+  static constexpr int TVQ = DQ * DQ, TVR = DR * DR;
+  template <int R_, int C_, int D_>   // J (R_ x C_) S (C_ x C_) J^T: (J S) first, then times J^T -- the reference's association
+  static __device__ __forceinline__ void congruence(const float* J, const float* S, float* out) {
+    float JS[R_ * C_];
+    BF_UNROLL for (int i = 0; i < R_; ++i) BF_UNROLL for (int j = 0; j < C_; ++j) {
+      float s = 0.f;
+      BF_UNROLL for (int k = 0; k < C_; ++k) s = fmaf(J[i * C_ + k], S[k * C_ + j], s);
+      JS[i * C_ + j] = s;
+    }
+    BF_UNROLL for (int i = 0; i < R_; ++i) BF_UNROLL for (int j = 0; j < R_; ++j) {
+      float s = 0.f;
+      BF_UNROLL for (int k = 0; k < C_; ++k) s = fmaf(JS[i * C_ + k], J[j * C_ + k], s);
+      out[i * D_ + j] = s;
+    }
+  }
+  static __device__ __forceinline__ void predict(Arg mdl, float* m, float* P, float u0, const float* tq) {
+    float F[N * N], Fq[N * DQ], fx[N], FqQFq[N * N];
+    bfu::Dual xd[N], qd[DQ], od[N];
+    BF_UNROLL for (int i = 0; i < N; ++i) xd[i] = bfu::Dual(m[i]);
+    BF_UNROLL for (int i = 0; i < DQ; ++i) qd[i] = bfu::Dual(mdl->q0[i]);
+    BF_UNROLL for (int s = 0; s < N + DQ; ++s) {
+      if (s < N) xd[s < N ? s : 0].d = 1.f; else qd[s >= N ? s - N : 0].d = 1.f;
+      bfu::dynamics<bfu::Dual>(xd, qd, bfu::Dual(u0), mdl->uth_dyn, od);
+      if (s < N) xd[s < N ? s : 0].d = 0.f; else qd[s >= N ? s - N : 0].d = 0.f;
+      BF_UNROLL for (int i = 0; i < N; ++i) {
+        if (s < N) F[i * N + (s < N ? s : 0)] = od[i].d; else Fq[i * DQ + (s >= N ? s - N : 0)] = od[i].d;
+        fx[i] = od[i].v;
+      }
+    }
+    congruence<N, DQ, N>(Fq, tq ? tq : mdl->sQ, FqQFq);
+    predict_cov<N>(F, FqQFq, P);  // F P F^T + F_q Q F_q^T
+    BF_UNROLL for (int i = 0; i < N; ++i) m[i] = fx[i];
+  }
+  static __device__ __forceinline__ float condition(Arg mdl, float* m, float* P, const float* yv, float u0, const float* tr) {
+    float H[M * N], Hr[M * DR], hx[M], HrRHr[M * M], v[M];
+    bfu::Dual xd[N], rd[DR], od[M];
+    BF_UNROLL for (int i = 0; i < N; ++i) xd[i] = bfu::Dual(m[i]);
+    BF_UNROLL for (int i = 0; i < DR; ++i) rd[i] = bfu::Dual(mdl->r0[i]);
+    BF_UNROLL for (int s = 0; s < N + DR; ++s) {
+      if (s < N) xd[s < N ? s : 0].d = 1.f; else rd[s >= N ? s - N : 0].d = 1.f;
+      bfu::emission<bfu::Dual>(xd, rd, bfu::Dual(u0), mdl->uth_emi, od);
+      if (s < N) xd[s < N ? s : 0].d = 0.f; else rd[s >= N ? s - N : 0].d = 0.f;
+      BF_UNROLL for (int a = 0; a < M; ++a) {
+        if (s < N) H[a * N + (s < N ? s : 0)] = od[a].d; else Hr[a * DR + (s >= N ? s - N : 0)] = od[a].d;
+        hx[a] = od[a].v;
+      }
+    }
+    congruence<M, DR, M>(Hr, tr ? tr : mdl->sR, HrRHr);
+    BF_UNROLL for (int a = 0; a < M; ++a) v[a] = yv[a] - hx[a];
+    return condition_on<N, M>(H, HrRHr, v, m, P);
+  }
 };
+#endif  // BF_JIT
+
 
 // NW = 1: the MP <= 64 leaves of a trajectory are lanes of one wave, 256 / MP trajectories per 256-thread workgroup.
 // NW > 1: one trajectory per workgroup of 64 NW threads (MP = 64 NW leaves, e.g. the [100, 2, 2] tree of
 // BOT_Experiment_script.py:118); reductions and the cumulative sum continue across waves through LDS.
 template <int N, int M, class NODES, int NW>
-__global__ void __launch_bounds__(NW == 1 ? 256 : 64 * NW)
-agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, AgsfOut out, long long B, long long T, int N0, int N1,
-                 int N2, int MP, float a0, float a1, uint32_t key0, uint32_t key1, int variant, int carry_records,
-                 const float* __restrict__ tvq, const float* __restrict__ tvr) {
+__device__ __forceinline__ void
+agsf_scan_body(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, AgsfOut out, long long B, long long T, int N0, int N1,
+               int N2, int MP, float a0, float a1, uint32_t key0, uint32_t key1, int variant, int carry_records,
+               const float* __restrict__ tvq, const float* __restrict__ tvr) {
+#pragma clang fp contract(fast)   // (stated, not inherited: a build compiled at run time sets contraction off for the caller's functions)
   constexpr int EP = N * N;
   constexpr int REC = N + EP;  // one component record in LDS: mean, covariance
   constexpr int NT = NW == 1 ? 256 : 64 * NW;
@@ -534,14 +598,22 @@ agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, A
 }
 
 template <int N, int M, class NODES, int NW>
+__global__ void __launch_bounds__(NW == 1 ? 256 : 64 * NW)
+agsf_scan_kernel(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, AgsfOut out, long long B, long long T, int N0, int N1,
+                 int N2, int MP, float a0, float a1, uint32_t key0, uint32_t key1, int variant, int carry_records,
+                 const float* __restrict__ tvq, const float* __restrict__ tvr) {
+  agsf_scan_body<N, M, NODES, NW>(mdl, y, uin, carry, out, B, T, N0, N1, N2, MP, a0, a1, key0, key1, variant, carry_records, tvq, tvr);
+}
+
+#ifndef BF_JIT
+template <int N, int M, class NODES, int NW>
 static inline int launch_agsf_geom(typename NODES::Arg arg, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
                                    const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry,
                                    const bf_out_desc* out, int* d_leaf_idx, int variant, int MP, const float* d_tvq, const float* d_tvr,
                                    hipStream_t stream) {
-  constexpr int REC = N + N * N;
   constexpr int NT = NW == 1 ? 256 : 64 * NW;
   const int carry_records = NW == 1 ? 256 : ((nc[0] + 3) & ~3);
-  const size_t lds_bytes = sizeof(float) * ((size_t)NT * REC + (size_t)carry_records * REC + NT + carry_records + 64 + (NW > 1 ? 4 * NT : 0));
+  const size_t lds_bytes = agsf_lds_bytes(N, NW, nc[0]);
   if (lds_bytes > 160 * 1024)
     return set_error(BF_EUNSUPPORTED, "augmented Gaussian-sum filter: %d leaves and %d components of dimension %d exceed the 160 KiB LDS",
                      nc[0] * nc[1] * nc[2], nc[0], N);
@@ -623,5 +695,7 @@ static inline int launch_uagsf(const bf_model* p, const bf_ukf_params* up, const
   return launch_agsf_nodes<N, M, UkfNodes<N, DQ, M, DR>>(d_mdl, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, variant, d_tvq, d_tvr,
                                                          stream);
 }
+
+#endif  // BF_JIT
 
 }  // namespace bf

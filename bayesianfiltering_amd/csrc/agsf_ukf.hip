@@ -3,9 +3,14 @@
 
 namespace bf {
 
+int launch_agsf_user_impl(const bf_model* p, const bf_ukf_params* up, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
+                          const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry, const bf_out_desc* out,
+                          int* d_leaf_idx, int variant, hipStream_t stream);  // user_model.hip
+
 int launch_agsf_ukf(const bf_model* p, const bf_ukf_params* up, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
                     const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry, const bf_out_desc* out,
                     int* d_leaf_idx, int variant, hipStream_t stream) {
+  if (p->user) return launch_agsf_user_impl(p, up, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, variant, stream);
 #define BF_CASE(N_, DQ_, M_, DR_)                                     \
   if (p->n == N_ && p->dq == DQ_ && p->m == M_ && p->dr == DR_)       \
     return launch_uagsf<N_, DQ_, M_, DR_>(p, up, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, variant, stream);

@@ -547,15 +547,20 @@ static inline int fill_ukf_model_view(const bf_model* p, const bf_ukf_params* up
   }
   for (int i = 0; i < DQ; ++i) e.q0[i] = p->q0 ? p->q0[i] : 0.f;
   for (int i = 0; i < DR; ++i) e.r0[i] = p->r0 ? p->r0[i] : 0.f;
-  host_sym_sqrt(p->Q, DQ, e.sQ);
-  host_sym_sqrt(p->R, DR, e.sR);
+  // user_flags & 4: the covariances themselves instead of their square roots (extended-Kalman nodes of the augmented filter)
+  const bool raw = (user_flags & 4) != 0;
+  auto root = [&](const float* src, int d, float* dst) {
+    if (raw) std::memcpy(dst, src, sizeof(float) * (size_t)d * d); else host_sym_sqrt(src, d, dst);
+  };
+  root(p->Q, DQ, e.sQ);
+  root(p->R, DR, e.sR);
   if (p->Q_steps > 1) {
     tvsq->resize((size_t)p->Q_steps * DQ * DQ);
-    for (int t = 0; t < p->Q_steps; ++t) host_sym_sqrt(p->Q + (size_t)t * DQ * DQ, DQ, tvsq->data() + (size_t)t * DQ * DQ);
+    for (int t = 0; t < p->Q_steps; ++t) root(p->Q + (size_t)t * DQ * DQ, DQ, tvsq->data() + (size_t)t * DQ * DQ);
   }
   if (p->R_steps > 1) {
     tvsr->resize((size_t)p->R_steps * DR * DR);
-    for (int t = 0; t < p->R_steps; ++t) host_sym_sqrt(p->R + (size_t)t * DR * DR, DR, tvsr->data() + (size_t)t * DR * DR);
+    for (int t = 0; t < p->R_steps; ++t) root(p->R + (size_t)t * DR * DR, DR, tvsr->data() + (size_t)t * DR * DR);
   }
   auto consts = [&](int L, float& c, float& ws, float& w0, float& wc) {
     const float a2 = up->alpha * up->alpha;

@@ -23,6 +23,7 @@
 #include "bf_common.hpp"
 #include "bpf_scan.hpp"   // BpfArgs / BpfCarry / BpfOut, the run-time-dimension model fill
 #include "ugsf_scan.hpp"  // UkfModelView, fill_ukf_model_view
+#include "agsf_geom.hpp"  // AgsfOut, agsf_lds_bytes
 
 #ifndef BF_ARCH_NAME
 #define BF_ARCH_NAME "gfx950"
@@ -37,6 +38,7 @@ struct bf_user_model {
   std::string dyn_src, emi_src, lp_src;  // kept: the particle-filter kernels are built on first use, per particle capacity
   std::map<int, hipFunction_t> bpf;       // key = PPT * 100 + NW
   hipFunction_t ugsf = nullptr;           // the unscented Gaussian-sum scan, built on first use
+  std::map<int, hipFunction_t> agsf;      // the augmented Gaussian-sum scan; key = kind * 100 + waves per trajectory
   std::vector<hipModule_t> extra_mods;
 };
 
@@ -45,6 +47,7 @@ namespace bf {
 extern const char* const kGenericDeviceSource;  // generic_device.hpp, embedded at build time (jit_sources.hip)
 extern const char* const kSamplingSourceA;      // kf_math.hpp + bf_canon_math.hpp
 extern const char* const kSamplingSourceB;
+extern const char* const kAgsfSource;           // agsf_scan.hpp
 extern const char* const kUgsfSource;           // ugsf_scan.hpp      // scan_common / bf_rng / models / ssm_device / bpf_scan
 
 namespace {
@@ -113,8 +116,7 @@ uint64_t fnv1a(const std::string& s) {
 
 // forward-mode dual numbers + the elementary functions a model may call, for float and Dual alike (namespace bfu: the
 // caller's source is compiled inside it, so unqualified sin / exp / sqrt ... resolve for both instantiations)
-const char* const kDualPrelude = R"BFSRC(
-namespace bfu {
+const char* const kDualCore = R"BFSRC(
 struct Dual {
   float v, d;
   __device__ Dual() : v(0.f), d(0.f) {}
@@ -144,6 +146,8 @@ __device__ inline bool operator<(Dual a, Dual b) { return a.v < b.v; }
 __device__ inline bool operator>(Dual a, Dual b) { return a.v > b.v; }
 __device__ inline bool operator<=(Dual a, Dual b) { return a.v <= b.v; }
 __device__ inline bool operator>=(Dual a, Dual b) { return a.v >= b.v; }
+)BFSRC";
+const char* const kLibmMath = R"BFSRC(
 __device__ inline float sin(float x) { return ::sinf(x); }
 __device__ inline float cos(float x) { return ::cosf(x); }
 __device__ inline float tan(float x) { return ::tanf(x); }
@@ -155,20 +159,23 @@ __device__ inline float atan(float x) { return ::atanf(x); }
 __device__ inline float atan2(float y, float x) { return ::atan2f(y, x); }
 __device__ inline float pow(float x, float p) { return ::powf(x, p); }
 __device__ inline float abs(float x) { return ::fabsf(x); }
-__device__ inline Dual sin(Dual x) { return Dual(::sinf(x.v), ::cosf(x.v) * x.d); }
-__device__ inline Dual cos(Dual x) { return Dual(::cosf(x.v), -::sinf(x.v) * x.d); }
-__device__ inline Dual tan(Dual x) { const float t = ::tanf(x.v); return Dual(t, (1.f + t * t) * x.d); }
-__device__ inline Dual exp(Dual x) { const float e = ::expf(x.v); return Dual(e, e * x.d); }
-__device__ inline Dual log(Dual x) { return Dual(::logf(x.v), x.d / x.v); }
-__device__ inline Dual sqrt(Dual x) { const float s = ::sqrtf(x.v); return Dual(s, x.d / (2.f * s)); }
-__device__ inline Dual tanh(Dual x) { const float t = ::tanhf(x.v); return Dual(t, (1.f - t * t) * x.d); }
-__device__ inline Dual atan(Dual x) { return Dual(::atanf(x.v), x.d / (1.f + x.v * x.v)); }
-__device__ inline Dual atan2(Dual y, Dual x) { const float r2 = x.v * x.v + y.v * y.v; return Dual(::atan2f(y.v, x.v), (x.v * y.d - y.v * x.d) / r2); }
-__device__ inline Dual pow(Dual x, float p) { const float w = ::powf(x.v, p - 1.f); return Dual(w * x.v, p * w * x.d); }
-__device__ inline Dual abs(Dual x) { return x.v < 0.f ? -x : x; }
 __device__ inline void sincos(float x, float* s, float* c) { *s = ::sinf(x); *c = ::cosf(x); }
-__device__ inline void sincos(Dual x, Dual* s, Dual* c) { const float sv = ::sinf(x.v), cv = ::cosf(x.v); *s = Dual(sv, cv * x.d); *c = Dual(cv, -sv * x.d); }
 __device__ inline float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
+)BFSRC";
+// (on top of whichever float functions precede it: libm's for the extended-Kalman scan, the canonical ones for the sampling kernels)
+const char* const kDualMath = R"BFSRC(
+__device__ inline Dual sin(Dual x) { return Dual(sin(x.v), cos(x.v) * x.d); }
+__device__ inline Dual cos(Dual x) { return Dual(cos(x.v), -sin(x.v) * x.d); }
+__device__ inline Dual tan(Dual x) { const float t = tan(x.v); return Dual(t, (1.f + t * t) * x.d); }
+__device__ inline Dual exp(Dual x) { const float e = exp(x.v); return Dual(e, e * x.d); }
+__device__ inline Dual log(Dual x) { return Dual(log(x.v), x.d / x.v); }
+__device__ inline Dual sqrt(Dual x) { const float s = sqrt(x.v); return Dual(s, x.d / (2.f * s)); }
+__device__ inline Dual tanh(Dual x) { const float t = tanh(x.v); return Dual(t, (1.f - t * t) * x.d); }
+__device__ inline Dual atan(Dual x) { return Dual(atan(x.v), x.d / (1.f + x.v * x.v)); }
+__device__ inline Dual atan2(Dual y, Dual x) { const float r2 = x.v * x.v + y.v * y.v; return Dual(atan2(y.v, x.v), (x.v * y.d - y.v * x.d) / r2); }
+__device__ inline Dual pow(Dual x, float p) { const float w = pow(x.v, p - 1.f); return Dual(w * x.v, p * w * x.d); }
+__device__ inline Dual abs(Dual x) { return x.v < 0.f ? -x : x; }
+__device__ inline void sincos(Dual x, Dual* s, Dual* c) { float sv, cv; sincos(x.v, &sv, &cv); *s = Dual(sv, cv * x.d); *c = Dual(cv, -sv * x.d); }
 __device__ inline Dual fma(Dual a, Dual b, Dual c) { return a * b + c; }
 __device__ inline Dual fma(float a, Dual b, Dual c) { return a * b + c; }
 __device__ inline Dual fma(Dual a, float b, Dual c) { return a * b + c; }
@@ -181,7 +188,10 @@ std::string build_source(const char* dyn_src, const char* emi_src, int n, int dq
   if (emi_src) s += "#define BF_USER_EMI 1\n";
   s += "#define BF_N " + std::to_string(n) + "\n#define BF_DQ " + std::to_string(dq) + "\n#define BF_M " + std::to_string(m) +
        "\n#define BF_DR " + std::to_string(dr) + "\n";
-  s += kDualPrelude;
+  s += "namespace bfu {\n";
+  s += kDualCore;
+  s += kLibmMath;
+  s += kDualMath;
   s += "\n// ---- the caller's functions\n";
   if (dyn_src) s += std::string(dyn_src) + "\n";
   if (emi_src) s += std::string(emi_src) + "\n";
@@ -384,9 +394,14 @@ __device__ inline float atan2(float y, float x) { return bf::canon_atan2(y, x); 
 __device__ inline float atan(float x) { return bf::canon_atan(x); }
 __device__ inline float abs(float x) { return __builtin_fabsf(x); }
 __device__ inline float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ inline float tan(float x) { return ::tanf(x); }       // (no canonical definition: none of the sampling paths' twins needs one)
+__device__ inline float tanh(float x) { return ::tanhf(x); }
+__device__ inline float pow(float x, float p) { return ::powf(x, p); }
 )BFSRC";
 
-std::string build_bpf_source(const bf_user_model* um, int ppt, int nw, bool ugsf = false) {
+enum { JIT_BPF = 0, JIT_UGSF = 1, JIT_AGSF_UKF = 2, JIT_AGSF_EKF = 3 };
+
+std::string build_bpf_source(const bf_user_model* um, int ppt, int nw, int kind = JIT_BPF) {
   std::string s = "#define BF_JIT 1\n#include <cstdint>\n#include <type_traits>\n";
   if (um->has_dyn) s += "#define BF_USER_DYN 1\n";
   if (um->has_emi) s += "#define BF_USER_EMI 1\n";
@@ -399,6 +414,10 @@ std::string build_bpf_source(const bf_user_model* um, int ppt, int nw, bool ugsf
        "struct CarryView { const float* w_in; const float* m_in; const float* P_in; float* w_out; float* m_out; float* P_out; }; }\n";
   s += kSamplingSourceA;
   s += kSamplingUserMath;
+  if (kind == JIT_AGSF_EKF) {  // the Jacobians of the extended-Kalman nodes: dual numbers over the same float functions
+    s += kDualCore;
+    s += kDualMath;
+  }
   s += "\n// ---- the caller's functions\n";
   if (um->has_dyn) s += um->dyn_src + "\n";
   if (um->has_emi) s += um->emi_src + "\n";
@@ -407,7 +426,19 @@ std::string build_bpf_source(const bf_user_model* um, int ppt, int nw, bool ugsf
   s += kSamplingSourceB;
   const std::string spec = std::string("bf::SpecUser<") + (um->has_dyn ? "true" : "false") + ", " + (um->has_emi ? "true" : "false") + ", " +
                            (um->has_lp ? "true" : "false") + ">";
-  if (ugsf) {
+  if (kind == JIT_AGSF_UKF || kind == JIT_AGSF_EKF) {
+    s += "namespace bf { struct UView { const float* p; long long sB, sT; }; }\n";
+    s += kUgsfSource;
+    s += kAgsfSource;
+    const std::string nodes = kind == JIT_AGSF_UKF ? "bf::UkfNodes<BF_N, BF_DQ, BF_M, BF_DR, " + spec + ">" : "bf::UserEkfNodes<BF_N, BF_DQ, BF_M, BF_DR>";
+    s += "extern \"C\" __global__ void __launch_bounds__(" + std::to_string(nw == 1 ? 256 : 64 * nw) + ") bf_user_agsf(const bf::UkfModel<BF_N, BF_DQ, BF_M, BF_DR>* "
+         "__restrict__ mdlp, bf::CView y, bf::UView uin, bf::CarryView carry, bf::AgsfOut out, long long B, long long T, int N0, int N1, int N2, int MP, "
+         "float a0, float a1, uint32_t key0, uint32_t key1, int variant, int carry_records, const float* __restrict__ tvq, const float* __restrict__ tvr) {\n"
+         "  bf::agsf_scan_body<BF_N, BF_M, " + nodes + ", " + std::to_string(nw) + ">(mdlp, y, uin, carry, out, B, T, N0, N1, N2, MP, a0, a1, key0, key1, "
+         "variant, carry_records, tvq, tvr);\n}\n";
+    return s;
+  }
+  if (kind == JIT_UGSF) {
     s += kUgsfSource;
     s += "extern \"C\" __global__ void __launch_bounds__(256) bf_user_ugsf(const bf::UkfModel<BF_N, BF_DQ, BF_M, BF_DR>* __restrict__ mdlp, bf::CView y, "
          "const float* __restrict__ uptr, long long u_sB, long long u_sT, bf::CarryView carry, bf::OutViews out, long long B, long long T, int K, int KP, "
@@ -510,7 +541,7 @@ int launch_ugsf_user_impl(const bf_model* p, const bf_ukf_params* up, const bf_c
     std::lock_guard<std::mutex> lock(g_mu);
     if (!um->ugsf) {
       hipModule_t mod = nullptr;
-      rc = build_function(build_bpf_source(um, 0, 0, true), "bf_user_ugsf", &mod, &um->ugsf);
+      rc = build_function(build_bpf_source(um, 0, 0, JIT_UGSF), "bf_user_ugsf", &mod, &um->ugsf);
       if (rc != BF_OK) return rc;
       um->extra_mods.push_back(mod);
     }
@@ -533,6 +564,84 @@ int launch_ugsf_user_impl(const bf_model* p, const bf_ukf_params* up, const bf_c
   void* args[] = {&dv, &yv, &uptr, &u_sB, &u_sT, &cv, &ov, &B, &T, &K, &KP, &d_tvsq, &d_tvsr};
   const int tpb = 256 / KP;
   BF_HIP_CHECK(hipModuleLaunchKernel(um->ugsf, (unsigned)((B + tpb - 1) / tpb), 1, 1, 256, 1, 1, 0, stream, args, nullptr));
+  return BF_OK;
+}
+
+// The augmented Gaussian-sum scan (agsf_scan.hpp: a lane per leaf of the [N0, N1, N2] tree) around the caller's functions.
+// up != NULL: unscented nodes (speedy_unscented_agsf / unscented_agsf, inference.py:966-1156 / 813-965), either function may
+// also come from the registry.  up == NULL: extended-Kalman nodes (inference.py:621-812 / 458-620 / 1157-1300) with the
+// Jacobians by dual numbers -- both functions from source (a registry function has its analytic Jacobian in the compiled kernels).
+int launch_agsf_user_impl(const bf_model* p, const bf_ukf_params* up, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
+                          const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry, const bf_out_desc* out,
+                          int* d_leaf_idx, int variant, hipStream_t stream) {
+  bf_user_model* um = const_cast<bf_user_model*>(p->user);
+  int rc = check_user_model(um, p);
+  if (rc != BF_OK) return rc;
+  if (um->has_lp) return set_error(BF_EINVAL, "a log-density from source belongs to the particle filter, not to the augmented filter");
+  if (!up && !(um->has_dyn && um->has_emi))
+    return set_error(BF_EUNSUPPORTED, "augmented filter with extended-Kalman nodes: give BOTH functions as source (or both from the registry)");
+  if (p->n > 8 || p->dq > 8 || p->m > 8 || p->dr > 8)
+    return set_error(BF_EUNSUPPORTED, "augmented filter with functions from source: dimensions up to 8 (a leaf lives in registers)");
+  if (p->flags != 0) return set_error(BF_EUNSUPPORTED, "legacy-class flags do not apply to the augmented filter");
+  int dev = -1;
+  (void)hipGetDevice(&dev);
+  if (dev != um->device) return set_error(BF_EINVAL, "bf_model.user was loaded on device %d, the current device is %d", um->device, dev);
+  if ((p->Q_steps > 1 && p->Q_steps != T) || (p->R_steps > 1 && p->R_steps != T))
+    return set_error(BF_EINVAL, "time-varying covariances need one matrix per step (Q_steps / R_steps = T = %lld)", T);
+  const long long Mleaf = (long long)nc[0] * nc[1] * nc[2];
+  if (Mleaf > 1024) return set_error(BF_EUNSUPPORTED, "augmented Gaussian-sum filter: %lld leaves per trajectory exceed one workgroup (1024)", Mleaf);
+  if (out->pred_means.ptr || out->pred_covs.ptr || out->coll_mean.ptr || out->coll_cov.ptr || out->loglik.ptr)
+    return set_error(BF_EINVAL, "the augmented filter emits weights, means and covariances only (inference.py:771-775)");
+  int MP = 1;
+  while (MP < Mleaf) MP <<= 1;
+  int nw = 1;
+  if (MP > 64) {
+    if (p->n > 4) return set_error(BF_EUNSUPPORTED, "augmented Gaussian-sum filter: more than 64 leaves per trajectory need state_dim <= 4");
+    nw = MP <= 256 ? 4 : 16;
+    MP = 64 * nw;
+  }
+  const size_t lds_bytes = agsf_lds_bytes(p->n, nw, nc[0]);
+  if (lds_bytes > 160 * 1024)
+    return set_error(BF_EUNSUPPORTED, "augmented Gaussian-sum filter: %d leaves and %d components of dimension %d exceed the 160 KiB LDS",
+                     (int)Mleaf, nc[0], p->n);
+  const int kind = up ? JIT_AGSF_UKF : JIT_AGSF_EKF;
+  hipFunction_t fn = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = um->agsf.find(kind * 100 + nw);
+    if (it == um->agsf.end()) {
+      hipModule_t mod = nullptr;
+      rc = build_function(build_bpf_source(um, 0, nw, kind), "bf_user_agsf", &mod, &fn);
+      if (rc != BF_OK) return rc;
+      um->extra_mods.push_back(mod);
+      um->agsf[kind * 100 + nw] = fn;
+    } else {
+      fn = it->second;
+    }
+  }
+  std::vector<uint32_t> words(ukf_model_words(p->n, p->dq, p->m, p->dr), 0u);
+  std::vector<float> tvq, tvr;
+  const bf_ukf_params unit{1.f, 0.f, 0.f};  // (the extended-Kalman nodes ignore the unscented constants)
+  rc = fill_ukf_model_view(p, up ? up : &unit, ukf_model_view_flat(words.data(), p->n, p->dq, p->m, p->dr),
+                           (um->has_dyn ? 1 : 0) | (um->has_emi ? 2 : 0) | (up ? 0 : 4), &tvq, &tvr);
+  if (rc != BF_OK) return rc;
+  const void* dv = nullptr;
+  rc = device_constants(words.data(), sizeof(uint32_t) * words.size(), stream, &dv);
+  if (rc != BF_OK) return rc;
+  const float *d_tvq = nullptr, *d_tvr = nullptr;
+  if ((rc = upload_table(tvq, stream, &d_tvq)) != BF_OK || (rc = upload_table(tvr, stream, &d_tvr)) != BF_OK) return rc;
+  CView yv{y->ptr, y->sB, y->sT, y->sE};
+  struct { const float* p; long long sB, sT; } uv{u && u->ptr ? u->ptr : nullptr, u ? u->sB : 0, u ? u->sT : 0};  // gsf_scan.hpp: UView
+  CarryView cv{carry->w_in, carry->m_in, carry->P_in, carry->w_out, carry->m_out, carry->P_out};
+  AgsfOut ov{make_sview(out->weights), make_sview(out->means), make_sview(out->covs), d_leaf_idx};
+  const int nt = nw == 1 ? 256 : 64 * nw;
+  int carry_records = nw == 1 ? 256 : ((nc[0] + 3) & ~3);
+  int N0 = nc[0], N1 = nc[1], N2 = nc[2];
+  float a0 = opt[0], a1 = opt[1];
+  uint32_t k0 = key[0], k1 = key[1];
+  const int tpb = nt / MP;
+  void* args[] = {&dv, &yv, &uv, &cv, &ov, &B, &T, &N0, &N1, &N2, &MP, &a0, &a1, &k0, &k1, &variant, &carry_records, &d_tvq, &d_tvr};
+  BF_HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)((B + tpb - 1) / tpb), 1, 1, (unsigned)nt, 1, 1, (unsigned)lds_bytes, stream, args, nullptr));
   return BF_OK;
 }
 

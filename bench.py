@@ -443,7 +443,9 @@ def main():
         roof["kernel_ms"] = kernel_ms
         roof["traffic"] = None         # HBM bytes from PMC counters: not collected inside this run (see profiles/ for the rocprofv3 passes)
         if args.config == "kalman4" and w["extra"]["batch_per_gpu"] == 65536 and w["T"] == 10000:
-            prof, src = profiled("r02_bench_%s_summary.json" % args.layout)
+            prof, src = profiled("r03_bench_%s_summary.json" % args.layout)
+            if prof is None:
+                prof, src = profiled("r02_bench_%s_summary.json" % args.layout)
             if prof and "pmc" in prof:
                 try:
                     roof["traffic_profiled"] = {"bytes": (prof["pmc"]["WRITE_SIZE"]["mean_per_dispatch"] + prof["pmc"]["FETCH_SIZE"]["mean_per_dispatch"]) * 1024.0,

@@ -68,3 +68,44 @@ for w in bf32 ugsf agsf uagsf gsf_collapsed; do
     pmc $w $kern $out/pmc_$w.json "$(cat $out/probe_$w.json)" -- python3 $root/scripts/roofline_probe.py $w
   fi
 done
+
+if [[ $what == *headline* ]]; then
+  echo "== headline bench (default flags)"
+  python3 $root/bench.py > $out/bench_line.json 2> $out/bench_line.err; cut -c1-600 $out/bench_line.json
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/trace.log 2>&1
+  stats $out/trace $out/bench_reference_kernel_stats.csv
+  grep -h '"metric"' $out/trace.log | cut -c1-300 > $out/bench_line_profiled.json
+  export PB=65536 PT=10000 PF=full5 PR=2
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $root/scripts/kf_one.py > $out/pmc_write.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $root/scripts/kf_one.py > $out/pmc_fetch.log 2>&1
+  python3 - <<PY
+import csv, glob, json, collections
+out = "$out"
+summary = {"tag": "r03 headline", "launch": "scripts/kf_one.py PB=65536 PT=10000 PF=full5 (the bench's launch: FULL5, reference layout)",
+           "note": "KiB per dispatch; WRITE_SIZE exact for 16-byte stores; FETCH_SIZE as reported (4-byte LDS-DMA loads: the gfx950 half-count of wide loads is not calibrated for them)"}
+for name in ("pmc_write", "pmc_fetch"):
+    for f in glob.glob(out + "/%s/**/*counter_collection.csv" % name, recursive=True):
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "kf_scan" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            summary.setdefault("pmc", {})[k] = {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)}
+json.dump(summary, open(out + "/bench_reference_summary.json", "w"), indent=1)
+print(json.dumps(summary.get("pmc", {}), indent=0)[:600])
+PY
+  rm -rf $out/trace $out/pmc_write $out/pmc_fetch
+fi
+
+if [[ $what == *others* ]]; then
+  : > $out/other_configs.jsonl
+  for c in "gsf32 --l96-mode as_written" "gsf32" "gsf32 --mode collapsed" "kalman64" "bpf4096"; do
+    tag=$(echo $c | tr -d ' -' )
+    echo "== $c"
+    rocprofv3 --kernel-trace --stats --output-format csv -d $out/t_$tag -- python3 $root/bench.py --config $c --steps 3 --warmup 1 > $out/$tag.log 2>&1
+    grep -h '"metric"' $out/$tag.log >> $out/other_configs.jsonl; grep -h '"metric"' $out/$tag.log | cut -c1-400
+    tail -3 $out/$tag.log | grep -v metric | cut -c1-300
+    stats $out/t_$tag $out/${tag}_kernel_stats.csv
+    rm -rf $out/t_$tag
+  done
+fi

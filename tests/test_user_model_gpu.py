@@ -493,3 +493,69 @@ def test_unscented_filter_with_functions_from_source(K):
     h1, cc = bfa.unscented_gaussian_sum_filter(usr, up, ys[:, :11], K, 1, initial_means=im, return_carry=True)
     h2 = bfa.unscented_gaussian_sum_filter(usr, up, ys[:, 11:], K, 1, carry=cc)
     assert torch.equal(torch.cat([h1.means, h2.means], dim=2), one.means) and torch.equal(torch.cat([h1.weights, h2.weights], dim=2), one.weights)
+
+
+@pytest.mark.parametrize("nodes,nc", [("ekf", (4, 3, 2)), ("ukf", (4, 3, 2)), ("ekf", (20, 3, 3)), ("ukf", (20, 3, 3))])
+def test_augmented_filter_with_functions_from_source(nodes, nc):
+    """The augmented Gaussian-sum filters (gaussfiltax/inference.py:458-1300) take arbitrary f, h like every other filter: the
+    manoeuvring-target dynamics and the bearing-range emission of BOT_Experiment_script.py:31-44 as source strings, compiled at
+    run time into the augmented kernel -- extended-Kalman nodes with the Jacobians by dual numbers (jacfwd w.r.t. state and
+    noise), unscented nodes with the sigma points through the caller's functions -- against their registry twins (analytic
+    Jacobians) and against the oracle; a tree wider than a wave; per-step covariances; two chunks through the carry."""
+    import torch
+    import bayesianfiltering_amd as bfa
+    nl = bfa.nonlinearities
+    T, B = 20, 3
+    mu0 = np.array([2.0, 0.3, 3.0, -0.2], F32)
+    S0 = np.diag([0.1, 0.005, 0.1, 0.01]).astype(F32)
+    Q, R = 1e-3 * np.eye(2, dtype=F32), np.diag([1e-3, 1e-2]).astype(F32)
+    r0 = np.array([0.01, -0.02], F32)
+    inputs = np.array([1] * 7 + [0] * 7 + [2] * 6, F32)
+    po = go.ParamsNLSSM(mu0, S0, om.ManeuverBOT(), np.zeros(2, F32), Q, om.BearingRange(), r0, R)
+    ys = np.stack([go.sample_ssm(po, otf.PRNGKey(30 + b), T, inputs.reshape(T, 1))[1] for b in range(B)])
+    reg = bfa.ParamsNLSSM(mu0, S0, nl.maneuver_bot(), np.zeros(2, F32), Q, nl.bearing_range(), r0, R)
+    f_usr = nl.user_dynamics(BOT_DYN_SRC, 4, noise_dim=2, theta=nl.maneuver_bot().theta)
+    g_usr = nl.user_emission(BOT_EMI_SRC, 4, 2)
+    usr = reg._replace(dynamics_function=f_usr, emission_function=g_usr)
+    up = bfa.ParamsUKF(1, 0, 0)
+    im = (mu0 + 0.05 * np.random.default_rng(1).normal(size=(B, nc[0], 4))).astype(F32)
+
+    def run(p, y=ys, u=inputs, **kw):
+        if nodes == "ekf":
+            return bfa.speedy_augmented_gaussian_sum_filter(p, y, nc, None, 1, (0.1, 0.1), u, initial_means=im, return_leaf_indices=True, **kw)
+        return bfa.speedy_unscented_agsf(p, up, y, nc, None, 1, (0.1, 0.1), u, initial_means=im, return_leaf_indices=True, **kw)
+
+    a, aa = run(reg)
+    b_, ab = run(usr)
+    # the drawn leaves are the same; the moments agree to rounding (analytic Jacobians against dual numbers / the same sigma points)
+    assert np.array_equal(aa["leaf_indices"].cpu().numpy(), ab["leaf_indices"].cpu().numpy())
+    for k in ("weights", "means", "covariances"):
+        assert cm.rel_err(getattr(b_, k).cpu().numpy(), getattr(a, k).cpu().numpy()) < 1e-5, k
+    if nodes == "ukf":   # one function from source, the other from the registry
+        c_, _ = run(reg._replace(emission_function=g_usr))
+        assert cm.rel_err(c_.means.cpu().numpy(), a.means.cpu().numpy()) < 1e-5
+    else:
+        with pytest.raises(Exception, match="BOTH functions"):
+            run(reg._replace(emission_function=g_usr))
+    # the oracle, one trajectory
+    if nc[0] * nc[1] * nc[2] <= 64:
+        if nodes == "ekf":
+            ref, _ = go.speedy_augmented_gaussian_sum_filter(po, ys[0], nc, None, 1, (0.1, 0.1), inputs.reshape(T, 1), initial_means=im[0])
+        else:
+            ref, _ = go.speedy_unscented_agsf(po, go.ParamsUKF(1, 0, 0), ys[0], nc, None, 1, (0.1, 0.1), inputs.reshape(T, 1), initial_means=im[0])
+        for k in ("means", "covariances"):
+            assert cm.rel_err(getattr(b_, k)[0].cpu().numpy(), getattr(ref, k)) < 2e-5, k
+    # per-step covariances
+    rng = np.random.default_rng(5)
+    Rt = np.stack([(0.6 + rng.random()) * R for _ in range(T)]).astype(F32)
+    c1, _ = run(usr._replace(emission_noise_covariance=Rt))
+    c2, _ = run(reg._replace(emission_noise_covariance=Rt))
+    assert cm.rel_err(c1.covariances.cpu().numpy(), c2.covariances.cpu().numpy()) < 1e-5 and not torch.equal(c2.covariances, a.covariances)
+    # two chunks through the carry == one launch
+    h1, x1 = run(usr, y=ys[:, :9], u=inputs[:9], return_carry=True)
+    im_saved = im
+    if nodes == "ekf":
+        h2, _ = bfa.speedy_augmented_gaussian_sum_filter(usr, ys[:, 9:], nc, None, 1, (0.1, 0.1), inputs[9:], carry=x1["carry"])
+    else:
+        h2, _ = bfa.speedy_unscented_agsf(usr, up, ys[:, 9:], nc, None, 1, (0.1, 0.1), inputs[9:], carry=x1["carry"])
+    assert torch.equal(torch.cat([h1.means, h2.means], dim=2), b_.means)
