@@ -322,7 +322,7 @@ struct UkfNodes {
   }
 };
 
-#ifdef BF_JIT
+#ifdef BF_AGSF_USER_EKF_NODES
 // Extended-Kalman nodes around functions compiled from the caller's source (user_model.hip): the Jacobians of
 // inference.py:58-61 / :82-86 (jacfwd w.r.t. the state and w.r.t. the noise, at the noise bias) by forward-mode dual numbers,
 // one seed direction after the other on the leaf's own lane; F_q Q F_q^T and H_r R H_r^T formed here every step.  The model
@@ -382,7 +382,7 @@ struct UserEkfNodes {
     return condition_on<N, M>(H, HrRHr, v, m, P);
   }
 };
-#endif  // BF_JIT
+#endif  // BF_AGSF_USER_EKF_NODES
 
 
 // NW = 1: the MP <= 64 leaves of a trajectory are lanes of one wave, 256 / MP trajectories per 256-thread workgroup.

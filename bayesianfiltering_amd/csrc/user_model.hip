@@ -412,6 +412,7 @@ std::string build_bpf_source(const bf_user_model* um, int ppt, int nw, int kind 
        "struct SView { float* p; long long sB, sK, sT, sE; };\n"
        "struct OutViews { SView w, m, P, pm, pP, ll; SView cm, cP; };\n"
        "struct CarryView { const float* w_in; const float* m_in; const float* P_in; float* w_out; float* m_out; float* P_out; }; }\n";
+  if (kind == JIT_AGSF_EKF) s += "#define BF_AGSF_USER_EKF_NODES 1\n";
   s += kSamplingSourceA;
   s += kSamplingUserMath;
   if (kind == JIT_AGSF_EKF) {  // the Jacobians of the extended-Kalman nodes: dual numbers over the same float functions
