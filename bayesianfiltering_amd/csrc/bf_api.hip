@@ -62,6 +62,7 @@ CallOverrides& call_overrides() {
 extern Option g_bpf_variant;
 extern Option g_bpf_hbm_mode;
 extern Option g_bpf_spec;
+extern Option g_bpf_arith;
 extern Option g_gsf_structured;
 extern Option g_kf_mfma_variant;
 static Option g_kf_emit_mode{-1, OPT_KF_EMIT_MODE};  // -1 = choose from the layout
@@ -179,6 +180,10 @@ static int set_option_impl(const char* name, int value, bool this_call_only) {
   if (name && std::strcmp(name, "bpf_hbm_mode") == 0) {
     if (value < 0 || value > 2) return bf::set_error(BF_EINVAL, "bpf_hbm_mode must be 0, 1 or 2");
     return assign(bf::g_bpf_hbm_mode);
+  }
+  if (name && std::strcmp(name, "bpf_arith") == 0) {
+    if (value < 0 || value > 1) return bf::set_error(BF_EINVAL, "bpf_arith must be 0 or 1");
+    return assign(bf::g_bpf_arith);
   }
   if (name && std::strcmp(name, "bpf_spec") == 0) {
     if (value < 0 || value > 1) return bf::set_error(BF_EINVAL, "bpf_spec must be 0 or 1");

@@ -34,6 +34,9 @@ __host__ __device__ __forceinline__ uint32_t canon_f_bits(float f) {
 // can prove the precondition -- erf_inv's 1 - x^2 with |x| < 1 -- skip a dozen compares, selects and their branches).
 __host__ __device__ __forceinline__ float canon_log_core(float x) {
 #pragma clang fp contract(off)
+#if defined(BF_BPF_HW_ARITH) && defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_logf(x) * 0.693147180559945309f;   // bf_set_option "bpf_arith" = 1: v_log_f32 (log2), 1 ulp
+#endif
   const uint32_t ix = canon_f_bits(x);
   int e = (int)((ix >> 23) & 0xFFu) - 126;                                  // x = m 2^e, m in [0.5, 1)
   const float m = canon_bits_f((ix & 0x007FFFFFu) | 0x3F000000u);
@@ -69,6 +72,9 @@ __host__ __device__ inline float canon_log(float x) {
 
 __host__ __device__ inline float canon_exp(float x) {
 #pragma clang fp contract(off)
+#if defined(BF_BPF_HW_ARITH) && defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);   // bf_set_option "bpf_arith" = 1: v_exp_f32 (2^x), 1 ulp
+#endif
   if (x != x) return x;
   if (x < -86.0f) return 0.0f;
   if (x > 88.0f) return __builtin_inff();

@@ -25,7 +25,7 @@ int set_error(int code, const char* fmt, ...);
 // the calling thread; the next filter entry point on that thread reads it and disarms every override when it returns), so
 // that one caller's choices never leak into another caller's launches.  Reads behave like the std::atomic<int> it replaces.
 enum OptionId { OPT_KF_EMIT_MODE, OPT_KF_LANES, OPT_KF_MFMA_VARIANT, OPT_KF_SMALL_MODE, OPT_FORCE_GENERIC, OPT_GSF_STRUCTURED,
-                OPT_BPF_VARIANT, OPT_BPF_HBM_MODE, OPT_BPF_SPEC, OPT_COUNT };
+                OPT_BPF_VARIANT, OPT_BPF_HBM_MODE, OPT_BPF_SPEC, OPT_BPF_ARITH, OPT_COUNT };
 struct CallOverrides {
   int value[OPT_COUNT];
   bool armed[OPT_COUNT];
@@ -45,10 +45,14 @@ struct Option {
     return *this;
   }
 };
+void begin_call_constants();    // const_cache.hip: constant blocks handed out from here on stay pinned ...
+void release_call_constants();  // ... until the entry point returns (its kernels are enqueued by then)
 struct CallOptionScope {   // at the top of every filter entry point: overrides live for exactly this call
+  CallOptionScope() { begin_call_constants(); }
   ~CallOptionScope() {
     CallOverrides& c = call_overrides();
     for (int i = 0; i < OPT_COUNT; ++i) c.armed[i] = false;
+    release_call_constants();
   }
 };
 

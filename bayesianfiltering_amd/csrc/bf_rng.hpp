@@ -179,6 +179,11 @@ __host__ __device__ __forceinline__ float erfinv_tail_poly(float w0) {
   "v_max_f32 %[" #U_ "], 0xbf7fffff, %[" #U_ "]\n\t"                         \
   "v_mul_f32 %[" #R_ "], %[" #U_ "], %[" #U_ "]\n\t"                         \
   "v_sub_f32 %[" #R_ "], 1.0, %[" #R_ "]\n\t"                                \
+  BF_NRM_FREXP(R_, F_, Y_, Z_)
+#ifdef BF_BPF_HW_ARITH
+#define BF_NRM_FREXP(R_, F_, Y_, Z_)
+#else
+#define BF_NRM_FREXP(R_, F_, Y_, Z_)                                         \
   "v_and_b32 %[" #F_ "], 0x7fffff, %[" #R_ "]\n\t"                           \
   "v_or_b32 %[" #F_ "], 0.5, %[" #F_ "]\n\t"                                 \
   "v_lshrrev_b32 %[" #Z_ "], 23, %[" #R_ "]\n\t"                             \
@@ -189,6 +194,7 @@ __host__ __device__ __forceinline__ float erfinv_tail_poly(float w0) {
   "v_add_f32 %[" #F_ "], %[" #Y_ "], %[" #F_ "]\n\t"                         \
   "v_add_u32 %[" #Z_ "], 0xffffff82, %[" #Z_ "]\n\t"                         \
   "v_cvt_f32_i32 %[" #Z_ "], %[" #Z_ "]\n\t"
+#endif
 #define BF_2(A_, B_) A_ B_
 // one Horner step of both chains: y = y f + K
 #define BF_HORNER2(YA_, FA_, YB_, FB_, K_)                                                      \
@@ -205,6 +211,18 @@ __device__ __forceinline__ void threefry_two_normals_gfx950(uint32_t k0, uint32_
       BF_TFA BF_TFI(k1, k2, 1) BF_TFB BF_TFI(k2, k0, 2) BF_TFA BF_TFI(k0, k1, 3) BF_TFB BF_TFI(k1, k2, 4) BF_TFA BF_TFI(k2, k0, 5)
       BF_NRM_HEAD(x0, ua, ra, fa, ya, za)
       BF_NRM_HEAD(x1, ub, rb, fb, yb, zb)
+#ifdef BF_BPF_HW_ARITH
+      // bf_set_option "bpf_arith" = 1: log(a) = log2(a) ln 2 on the transcendental unit (outputs the polynomial would not
+      // otherwise define are given a value: the block's operands are all early-clobber outputs)
+      "v_log_f32 %[ra], %[ra]\n\t"
+      "v_log_f32 %[rb], %[rb]\n\t"
+      "v_mov_b32 %[ya], 0\n\t"
+      "v_mov_b32 %[yb], 0\n\t"
+      "v_mov_b32 %[za], 0\n\t"
+      "v_mov_b32 %[zb], 0\n\t"
+      "v_mul_f32 %[ra], 0x3f317218, %[ra]\n\t"
+      "v_mul_f32 %[rb], 0x3f317218, %[rb]\n\t"
+#else
       // canon_log_core polynomial, both chains
       "v_mov_b32 %[ya], 0x3d9021bb\n\t"
       "v_mov_b32 %[yb], 0x3d9021bb\n\t"
@@ -225,6 +243,7 @@ __device__ __forceinline__ void threefry_two_normals_gfx950(uint32_t k0, uint32_
       "v_add_f32 %[rb], %[fb], %[yb]\n\t"
       "v_fmac_f32 %[ra], 0x3f318000, %[za]\n\t"
       "v_fmac_f32 %[rb], 0x3f318000, %[zb]\n\t"
+#endif
       // w = -2.5 - log(a); central erf_inv polynomial, both chains
       "v_sub_f32 %[fa], 0xc0200000, %[ra]\n\t"
       "v_sub_f32 %[fb], 0xc0200000, %[rb]\n\t"
@@ -248,6 +267,7 @@ __device__ __forceinline__ void threefry_two_normals_gfx950(uint32_t k0, uint32_
 #undef BF_TFB
 #undef BF_TFI
 #undef BF_NRM_HEAD
+#undef BF_NRM_FREXP
 #undef BF_2
 #undef BF_HORNER2
 #endif

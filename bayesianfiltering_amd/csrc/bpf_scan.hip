@@ -7,6 +7,7 @@ namespace bf {
 Option g_bpf_variant{0, OPT_BPF_VARIANT};   // tuning hook (bf_set_option "bpf_variant")
 Option g_bpf_hbm_mode{0, OPT_BPF_HBM_MODE};  // bf_set_option "bpf_hbm_mode"
 Option g_bpf_spec{1, OPT_BPF_SPEC};      // bf_set_option "bpf_spec"
+Option g_bpf_arith{0, OPT_BPF_ARITH};    // bf_set_option "bpf_arith": 0 = canonical fp32 arithmetic (bit-exact ancestry), 1 = hardware v_exp_f32 / v_log_f32
 
 // Stand-alone resampler: idx[b][:] = choice(key_b, N, (N,), p = w[b]) (the index draw of utils.py:210)
 template <int PPT, int NW>
@@ -50,6 +51,9 @@ BF_DECL(launch_bpf_group_c);
 int launch_bpf_user_impl(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP, float ess,
                          int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o, hipStream_t stream);
 
+int launch_bpf_hw_arith_impl(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP, float ess,
+                             int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o, hipStream_t stream);
+
 int launch_bpf(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP,
                float ess, int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o,
                hipStream_t stream) {
@@ -61,6 +65,8 @@ int launch_bpf(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u,
     return launch_bpf_user_impl(bp, y, u, B, T, NP, ess, resampler, key, carry, o, stream);
   if (bp->ssm.dyn_id == BF_FN_USER || bp->ssm.emi_id == BF_FN_USER)
     return set_error(BF_EINVAL, "dyn_id / emi_id = BF_FN_USER needs bf_model.user (bf_user_model_create)");
+  if (g_bpf_arith == 1)   // the same kernel with the hardware's transcendentals, compiled at run time (user_model.hip)
+    return launch_bpf_hw_arith_impl(bp, y, u, B, T, NP, ess, resampler, key, carry, o, stream);
   bool matched = false;
   int rc = launch_bpf_group_a(bp, y, u, B, T, NP, ess, resampler, key, cr, out, stream, &matched);
   if (matched) return rc;

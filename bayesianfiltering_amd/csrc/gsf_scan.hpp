@@ -84,7 +84,10 @@ constexpr int wrap_mod(int i) {
 // EXT = true adds the optional features -- COLLAPSED outputs and per-step (time-varying) noise covariances --
 // as their own instances (strided stores only), so that the plain instances keep their register budget.
 template <int NS, int M, int NL, int MODE, int SPEC, bool EXT = false>
-__global__ void __launch_bounds__(256, 2)
+#ifndef BF_GSF_NONE_WAVES
+#define BF_GSF_NONE_WAVES 2
+#endif
+__global__ void __launch_bounds__(256, (MODE == EMIT_NONE ? BF_GSF_NONE_WAVES : 2))
 gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutViews out, long long B, long long T, int K,
                 int KP, int lds_per_wave, const float* __restrict__ tv_gqg, const float* __restrict__ tv_drd, int wscalar) {
   using Cfg = GsfCfg<NS, M, NL>;

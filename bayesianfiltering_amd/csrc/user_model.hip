@@ -35,6 +35,7 @@ struct bf_user_model {
   int n = 0, dq = 0, m = 0, dr = 0;
   int device = -1;
   bool has_dyn = false, has_emi = false, has_lp = false;
+  bool hw_arith = false;                  // internal handle of bf_set_option "bpf_arith" = 1: registry functions, hardware transcendentals
   std::string dyn_src, emi_src, lp_src;  // kept: the particle-filter kernels are built on first use, per particle capacity
   std::map<int, hipFunction_t> bpf;       // key = PPT * 100 + NW
   hipFunction_t ugsf = nullptr;           // the unscented Gaussian-sum scan, built on first use
@@ -401,8 +402,9 @@ __device__ inline float pow(float x, float p) { return ::powf(x, p); }
 
 enum { JIT_BPF = 0, JIT_UGSF = 1, JIT_AGSF_UKF = 2, JIT_AGSF_EKF = 3 };
 
-std::string build_bpf_source(const bf_user_model* um, int ppt, int nw, int kind = JIT_BPF) {
+std::string build_bpf_source(const bf_user_model* um, int ppt, int nw, int kind = JIT_BPF, const char* spec_override = nullptr) {
   std::string s = "#define BF_JIT 1\n#include <cstdint>\n#include <type_traits>\n";
+  if (um->hw_arith) s += "#define BF_BPF_HW_ARITH 1\n";
   if (um->has_dyn) s += "#define BF_USER_DYN 1\n";
   if (um->has_emi) s += "#define BF_USER_EMI 1\n";
   if (um->has_lp) s += "#define BF_USER_LP 1\n";
@@ -425,8 +427,9 @@ std::string build_bpf_source(const bf_user_model* um, int ppt, int nw, int kind 
   if (um->has_lp) s += um->lp_src + "\n";
   s += "}  // namespace bfu\n";
   s += kSamplingSourceB;
-  const std::string spec = std::string("bf::SpecUser<") + (um->has_dyn ? "true" : "false") + ", " + (um->has_emi ? "true" : "false") + ", " +
-                           (um->has_lp ? "true" : "false") + ">";
+  const std::string spec = spec_override ? std::string(spec_override)
+                                         : std::string("bf::SpecUser<") + (um->has_dyn ? "true" : "false") + ", " + (um->has_emi ? "true" : "false") + ", " +
+                                               (um->has_lp ? "true" : "false") + ">";
   if (kind == JIT_AGSF_UKF || kind == JIT_AGSF_EKF) {
     s += "namespace bf { struct UView { const float* p; long long sB, sT; }; }\n";
     s += kUgsfSource;
@@ -456,10 +459,41 @@ std::string build_bpf_source(const bf_user_model* um, int ppt, int nw, int kind 
 }  // namespace
 
 
+static int launch_bpf_jit(bf_user_model* um, const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP,
+                          float ess, int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o, hipStream_t stream);
+
 int launch_bpf_user_impl(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP, float ess,
                          int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o, hipStream_t stream) {
+  return launch_bpf_jit(const_cast<bf_user_model*>(bp->ssm.user), bp, y, u, B, T, NP, ess, resampler, key, carry, o, stream);
+}
+
+// bf_set_option "bpf_arith" = 1: the registry model's kernel rebuilt with v_log_f32 / v_exp_f32 in place of the defined
+// arithmetic (BF_BPF_HW_ARITH in bf_canon_math.hpp / bf_rng.hpp), on an internal handle per (dimensions, device)
+int launch_bpf_hw_arith_impl(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP, float ess,
+                             int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o, hipStream_t stream) {
   const bf_model* p = &bp->ssm;
-  bf_user_model* um = const_cast<bf_user_model*>(p->user);
+  int dev = -1;
+  BF_HIP_CHECK(hipGetDevice(&dev));
+  const std::string mem_key = "hw_arith:" + std::to_string(p->n) + "," + std::to_string(p->dq) + "," + std::to_string(p->m) + "," + std::to_string(p->dr) +
+                              "@" + std::to_string(dev);
+  bf_user_model* um = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_models.find(mem_key);
+    if (it != g_models.end()) {
+      um = it->second;
+    } else {
+      um = new bf_user_model;
+      um->n = p->n; um->dq = p->dq; um->m = p->m; um->dr = p->dr; um->device = dev; um->hw_arith = true;
+      g_models[mem_key] = um;
+    }
+  }
+  return launch_bpf_jit(um, bp, y, u, B, T, NP, ess, resampler, key, carry, o, stream);
+}
+
+static int launch_bpf_jit(bf_user_model* um, const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP,
+                          float ess, int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o, hipStream_t stream) {
+  const bf_model* p = &bp->ssm;
   if (um->n != p->n || um->dq != p->dq || um->m != p->m || um->dr != p->dr)
     return set_error(BF_EINVAL, "bf_model.user was compiled for (n, dq, m, dr) = (%d, %d, %d, %d) but the model says (%d, %d, %d, %d)",
                      um->n, um->dq, um->m, um->dr, p->n, p->dq, p->m, p->dr);
@@ -475,26 +509,37 @@ int launch_bpf_user_impl(const bf_bpf_model* bp, const bf_cstream* y, const bf_c
   else if (NP <= 256) { ppt = 1; nw = 4; }
   else if (NP <= 1024) { ppt = 1; nw = 16; }
   else if (NP <= 4096 && N <= 16) { ppt = 4; nw = 16; }
-  else return set_error(BF_EUNSUPPORTED, "particle filter with functions from source: at most 4096 particles for state_dim <= 16, 1024 beyond");
+  else return set_error(BF_EUNSUPPORTED, "particle filter compiled at run time (functions from source, or bpf_arith = 1): at most 4096 particles for state_dim <= 16, 1024 beyond");
+  // the model, word for word the BpfModel<N, DQ, M> of the kernel
+  std::vector<uint32_t> words(bpf_model_words(N, p->dq, M), 0u);
+  const int flags = (um->has_dyn ? 1 : 0) | (um->has_emi ? 2 : 0) | (um->has_lp ? 4 : 0);
+  const BpfModelView view = bpf_model_view_flat(words.data(), N, p->dq, M);
+  int rc = fill_bpf_model_view(bp, view, flags, bp->lp_theta, bp->n_lp_theta);
+  if (rc != BF_OK) return rc;
+  // registry models (the hardware-arithmetic build): the model structure as a compile-time spec where bpf_scan.hpp has one
+  const char* spec = nullptr;
+  int spec_id = 0;
+  if (um->hw_arith) {
+    const bool l96_pick = N == p->dq && N >= 8 && 2 * M <= N + 1 && *view.dyn_id == DYN_LORENZ96 && *view.emi_id == EMI_LINEAR && *view.g_identity &&
+                          *view.lq_diag && *view.lr_diag && *view.h_pick;
+    spec = l96_pick ? "bf::SpecFixed<bf::DYN_LORENZ96, bf::EMI_LINEAR, true, true, true, true>" : "bf::SpecRuntime";
+    spec_id = l96_pick ? 2 : 1;
+  }
   hipFunction_t fn = nullptr;
   {
     std::lock_guard<std::mutex> lock(g_mu);
-    auto it = um->bpf.find(ppt * 100 + nw);
+    const int fkey = spec_id * 10000 + ppt * 100 + nw;
+    auto it = um->bpf.find(fkey);
     if (it != um->bpf.end()) {
       fn = it->second;
     } else {
       hipModule_t mod = nullptr;
-      const int rc = build_function(build_bpf_source(um, ppt, nw), "bf_user_bpf", &mod, &fn);
+      rc = build_function(build_bpf_source(um, ppt, nw, JIT_BPF, spec), "bf_user_bpf", &mod, &fn);
       if (rc != BF_OK) return rc;
       um->extra_mods.push_back(mod);
-      um->bpf[ppt * 100 + nw] = fn;
+      um->bpf[fkey] = fn;
     }
   }
-  // the model, word for word the BpfModel<N, DQ, M> of the kernel
-  std::vector<uint32_t> words(bpf_model_words(N, p->dq, M), 0u);
-  const int flags = (um->has_dyn ? 1 : 0) | (um->has_emi ? 2 : 0) | (um->has_lp ? 4 : 0);
-  int rc = fill_bpf_model_view(bp, bpf_model_view_flat(words.data(), N, p->dq, M), flags, bp->lp_theta, bp->n_lp_theta);
-  if (rc != BF_OK) return rc;
   const void* dv = nullptr;
   rc = device_constants(words.data(), sizeof(uint32_t) * words.size(), stream, &dv);
   if (rc != BF_OK) return rc;

@@ -373,6 +373,8 @@ def main():
                          "region, barriers, max-over-ranks -- even with ONE rank (also the default under torchrun --nproc-per-node 1)")
     ap.add_argument("--config", default="kalman4", choices=sorted(MAKERS),
                     help="kalman4 = BASELINE configs[1] (headline, default); gsf32 / bpf4096 / kalman64 = configs[2..4]")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="bf_set_option(NAME, VALUE) before the run (tuning experiments; repeatable), e.g. --option bpf_arith=1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -395,6 +397,11 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from bayesianfiltering_amd import distributed as bdist
+    if args.option:
+        from bayesianfiltering_amd import _lib
+        for kv in args.option:
+            name, _, value = kv.partition("=")
+            _lib.check(_lib.require_gpu().bf_set_option(name.encode(), int(value)))
     w = MAKERS[args.config](args, rank, world, device)
 
     gathered = {"t": None}
@@ -460,6 +467,7 @@ def main():
                        "parallelism": f"batch-sharded x{world}" + (" + RCCL all-gather of summaries" if group else "")},
             "finite_frac": finite_frac,
             "roofline": roof,
+            **({"options": args.option} if args.option else {}),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = w["cpu"]() if "cpu" in w else cpu_baseline(w["a"], w["T"])

@@ -145,6 +145,12 @@ int bf_device_count(void);
  *   "bpf_spec":     1 (default) = models whose structure has a compile-time instance (Lorenz-96 dynamics with identity noise
  *                   input, diagonal chol(Q), selection emission, diagonal chol(R)) run on it; 0 = the run-time instance
  *                   (same results bit for bit).
+ *   "bpf_arith":    arithmetic of the particle filter's weight path (the normal draws' erf_inv, the exp of the weights): 0
+ *                   (default) = the engine's DEFINED fp32 arithmetic (IEEE operations in a fixed order; resampling indices
+ *                   reproducible bit for bit); 1 = the hardware's v_log_f32 / v_exp_f32 (1 ulp, not
+ *                   reproducible across architectures; results agree with mode 0 to rounding until a uniform draw lands within
+ *                   that rounding of a CDF step).  Mode 1 compiles the kernel at run time (needs hiprtc, like bf_user_model_create)
+ *                   and serves particle counts up to 4 096 with registry functions.
  * bf_set_option changes the PROCESS-WIDE default.  A library or a thread that must not disturb -- or be disturbed by -- other
  * callers uses bf_set_call_option instead: it arms the same option on the CALLING THREAD for the NEXT filter entry point
  * called on that thread (bf_kalman_filter_f32, bf_gsf_ekf_f32, bf_ugsf_ukf_f32, bf_agsf_*, bf_bpf_f32, bf_sample_ssm_f32,

@@ -473,3 +473,58 @@ def test_compile_time_model_instance_equals_the_run_time_one(n, N):
         assert torch.equal(res[1][0][k], res[0][0][k]), k
     assert torch.equal(res[1][1].particles, res[0][1].particles) and torch.equal(res[1][1].weights, res[0][1].weights)
     assert torch.equal(res[1][1].key, res[0][1].key)
+
+
+@pytest.mark.parametrize("n,N", [(8, 256), (16, 4096), (3, 1000)])
+def test_hardware_arithmetic_option_agrees_to_rounding(n, N):
+    """bf_set_option "bpf_arith" = 1 (per call: options={"bpf_arith": 1}): the same kernel with v_log_f32 / v_exp_f32 where the
+    default build has the engine's defined fp32 arithmetic -- for callers who want the speed and do not need resampling indices
+    reproducible bit for bit.  The two builds draw the same Threefry bits and differ by ~1 ulp per transcendental: the weighted
+    means agree to rounding step after step until a uniform draw lands within that rounding of a CDF step (from there the runs
+    are two equally valid samples; with 4 096 draws per step that happens within the first few steps), the resampling decisions agree while they do, and the libm-arithmetic oracle -- the third
+    rounding of the same recursion -- sits at the same distance from both."""
+    import torch
+    bfa, nl = _bfa()
+    T, B = 12, 2
+    if n == 3:
+        m = 1
+        pp = bfa.ParamsBPF(np.array([0.0, 1.0, 1.05], F32), np.eye(3, dtype=F32), nl.lorenz63(10.0, 28.0, 2.667, 0.01), np.zeros(3, F32),
+                           0.1 * np.eye(3, dtype=F32), nl.quadratic(3, 0.05), np.zeros(1, F32), np.eye(1, dtype=F32),
+                           nl.gaussian_log_prob(nl.quadratic(3, 0.05), np.eye(1, dtype=F32)))
+        po = go.ParamsBPF(*pp[:2], om.Lorenz63(), pp[3], pp[4], om.Quadratic(3, 0.05), pp[6], pp[7],
+                          go.GaussianEmissionLogProb(om.Quadratic(3, 0.05), np.eye(1, dtype=F32)))
+    else:
+        m = n // 2
+        g = nl.pick_even(n)
+        R = 0.5 * np.eye(m, dtype=F32)
+        pp = bfa.ParamsBPF(8 * np.ones(n, F32), np.eye(n, dtype=F32), nl.lorenz96(n), np.zeros(n, F32), 1e-2 * np.eye(n, dtype=F32), g,
+                           np.zeros(m, F32), R, nl.gaussian_log_prob(g, R))
+        po = go.ParamsBPF(*pp[:2], om.Lorenz96(n), pp[3], pp[4], om.PickEven(n), pp[6], pp[7], go.GaussianEmissionLogProb(om.PickEven(n), R))
+    ys = cm.device_observations(bfa.ParamsNLSSM(*pp[:8]), (n, n, m, m), B, T, seed=7 + n).cpu().numpy()
+    key = np.array([1, 9], np.uint32)
+    # without resampling nothing can branch: every step's weighted mean, ESS and evidence agree to rounding
+    a0 = bfa.bootstrap_particle_filter(pp, ys, N, key, None, 0.0, output="summary")
+    h0 = bfa.bootstrap_particle_filter(pp, ys, N, key, None, 0.0, output="summary", options={"bpf_arith": 1})
+    assert not torch.equal(a0["mean"], h0["mean"])                                         # another arithmetic ...
+    for k in ("mean", "ess", "logz"):
+        fin = torch.isfinite(a0[k]) & torch.isfinite(h0[k])
+        assert fin.float().mean() > 0.9
+        assert cm.rel_err(h0[k][fin].cpu().numpy(), a0[k][fin].cpu().numpy()) < 2e-5, k     # ... the same filter
+    # with resampling: the same decisions and means to rounding until the first ancestor differs
+    a = bfa.bootstrap_particle_filter(pp, ys, N, key, output="summary")
+    h = bfa.bootstrap_particle_filter(pp, ys, N, key, output="summary", options={"bpf_arith": 1})
+    again = bfa.bootstrap_particle_filter(pp, ys, N, key, output="summary")
+    assert torch.equal(torch.nan_to_num(a["mean"]), torch.nan_to_num(again["mean"]))     # the override lasted one call
+    am, hm = a["mean"].cpu().numpy(), h["mean"].cpu().numpy()
+    for b in range(B):
+        d = np.abs(am[b] - hm[b]).max(axis=1) / np.abs(am[b]).max()
+        t_ok = int(np.argmax(d > 1e-4)) if (d > 1e-4).any() else T
+        assert t_ok >= (1 if N > 1024 else 4), (b, d)      # (4 096 draws per step: a draw within an ulp of a CDF step comes early)
+        assert np.array_equal(a["resampled"][b, :t_ok].cpu().numpy(), h["resampled"][b, :t_ok].cpu().numpy())
+        assert np.isfinite(hm[b]).all()
+        if N <= 1024:
+            ref = go.bootstrap_particle_filter(po, ys[b], N, key=key)
+            rm = np.einsum("itd,it->td", ref["particles"], ref["weights"])
+            dl = np.abs(rm - hm[b]).max(axis=1) / np.abs(rm).max()
+            assert (dl[:4] < 1e-4).all(), (b, dl)
+    assert float(h["resampled"].mean()) > 0

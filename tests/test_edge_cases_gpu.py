@@ -158,3 +158,31 @@ def test_call_options_apply_to_one_call_only():
     again = bfa.kalman_filter(p, ys, return_loglik=True)
     assert torch.equal(again[0].covariances, default[0].covariances)
     assert lib.bf_set_call_option(b"no_such_option", 1) == _lib.BF_EINVAL
+
+
+def test_constant_cache_under_eviction_pressure():
+    """csrc/const_cache.hip keeps at most 128 device-resident constant blocks and evicts least-recently-used -- never a block a
+    call in progress was handed (it is pinned until the entry point returns).  150 distinct models, each with per-step
+    covariance tables (three blocks per call), then the first one again: same bits as its first run."""
+    import torch
+    import bayesianfiltering_amd as bfa
+    nl = bfa.nonlinearities
+    rng = np.random.default_rng(0)
+    T, B, n, m = 6, 4, 4, 2
+    ys = torch.randn((B, T, m), device="cuda")
+
+    def model(i):
+        r = np.random.default_rng(i)
+        A = (0.9 * np.eye(n) + 0.01 * r.normal(size=(n, n))).astype(F32)
+        H = r.normal(size=(m, n)).astype(F32)
+        Qt = np.stack([(0.05 + 0.01 * t) * np.eye(n) for t in range(T)]).astype(F32) * (1 + 0.001 * i)
+        Rt = np.stack([(0.3 + 0.01 * t) * np.eye(m) for t in range(T)]).astype(F32)
+        return bfa.ParamsNLSSM(np.zeros(n, F32), np.eye(n, dtype=F32), nl.linear_dynamics(A, np.eye(n, dtype=F32)), np.zeros(n, F32), Qt,
+                               nl.linear_emission(H), np.zeros(m, F32), Rt)
+    first = bfa.gaussian_sum_filter(model(0), ys, 2, 1, initial_means=np.zeros((B, 2, n), F32))
+    keep = first.covariances.clone()
+    for i in range(1, 150):
+        out = bfa.gaussian_sum_filter(model(i), ys, 2, 1, initial_means=np.zeros((B, 2, n), F32))
+    assert torch.isfinite(out.means).all()
+    again = bfa.gaussian_sum_filter(model(0), ys, 2, 1, initial_means=np.zeros((B, 2, n), F32))
+    assert torch.equal(again.covariances, keep)
