@@ -512,3 +512,54 @@ def test_cfg5_full5_chunks_of_100_at_benchmark_size():
     cm.record("cfg5_full5_B32768_chunks_of_100", **seen)
     for k, e in seen.items():
         assert max(e) < 1e-5, (k, seen)
+
+
+def test_cfg4_summary_output_at_benchmark_size():
+    """configs[3] exactly as bench.py launches it: B = 8 192 trajectories, N = 4 096 particles, n = 16, m = 8, T = 2 000, SUMMARY
+    output, observations drawn from the model (bench.py's seed) -- one workgroup per trajectory on `bpf_scan_kernel<16,16,8,4,16,
+    SpecFixed<...>>`.  (a) every element of every summary equal between the one-shot launch and 4 x 500 steps through the carry;
+    (b) trajectories first / middle / last filtered ALONE (B = 1 launches) equal their rows of the full batch bit for bit -- a
+    trajectory's result does not depend on its neighbours or its place in the grid; (c) the first 10 steps of those trajectories
+    against the canonical-arithmetic oracle: resampling decisions and ESS bit for bit, weighted means to rounding (the summary's sum
+    over particles runs in the kernel's tree order); (d) the ESS rule wherever the filter is finite (> 98 % of the trajectories whose observations are)."""
+    import torch
+    import bayesianfiltering_amd as bfa
+    import bench
+    nl = bfa.nonlinearities
+    B, T, N, n, m = 8192, 2000, 4096, 16, 8
+    gfn = nl.pick_even(n)
+    R = 0.5 * np.eye(m, dtype=F32)
+    p = bfa.ParamsBPF(8 * np.ones(n, F32), np.eye(n, dtype=F32), nl.lorenz96(n), np.zeros(n, F32), 1e-2 * np.eye(n, dtype=F32), gfn,
+                      np.zeros(m, F32), R, nl.gaussian_log_prob(gfn, R))
+    y = bench.simulate_on_device(bfa.ParamsNLSSM(*p[:8]), (n, n, m, m), B, T, seed=4000)
+    key = np.array([0, 1], np.uint32)
+    one = bfa.bootstrap_particle_filter(p, y, N, key, output="summary")
+    parts, c = [], None
+    for t0 in range(0, T, 500):
+        o, c = bfa.bootstrap_particle_filter(p, y[:, t0:t0 + 500], N, key if c is None else None, output="summary", carry=c, return_carry=True)
+        parts.append(o)
+    for k in ("mean", "ess", "logz", "resampled"):
+        assert _same_bits(torch.cat([o[k] for o in parts], dim=1), one[k]), k
+    del parts, c
+    po = go.ParamsBPF(8 * np.ones(n, F32), np.eye(n, dtype=F32), om.Lorenz96(n), np.zeros(n, F32), 1e-2 * np.eye(n, dtype=F32), om.PickEven(n),
+                      np.zeros(m, F32), R, go.GaussianEmissionLogProb(om.PickEven(n), R))
+    for b in (0, 4097, B - 1):
+        alone = bfa.bootstrap_particle_filter(p, y[b:b + 1], N, key, output="summary", options={"bpf_hbm_mode": 1})
+        for k in ("mean", "ess", "logz", "resampled"):
+            assert _same_bits(alone[k][0], one[k][b]), (b, k)
+        yb = y[b, :10].cpu().numpy()
+        ref, dbg = go.bootstrap_particle_filter(po, yb, N, key=key, debug=True, arith="canonical")
+        assert np.array_equal(one["resampled"][b, :10].cpu().numpy() > 0.5, dbg["resampled"])
+        assert np.array_equal(np.ascontiguousarray(one["ess"][b, :10].cpu().numpy(), F32).view(np.uint32), dbg["ess"].view(np.uint32))
+        mean = np.einsum("itd,it->td", ref["particles"].astype(np.float64), ref["weights"].astype(np.float64))
+        assert cm.rel_err(one["mean"][b, :10].cpu().numpy(), mean) < 2e-6
+    ok = torch.isfinite(y).all(dim=(1, 2))
+    assert float(ok.float().mean()) > 0.7
+    # (a particle cloud can leave the finite numbers where the data did not: every particle integrates the same explicit-Euler
+    # Lorenz-96 with its own noise; measured: a fraction of a per cent of the trajectories)
+    fin = torch.isfinite(one["mean"]).all(dim=(1, 2))
+    frac = float((fin & ok).float().sum() / ok.float().sum())
+    assert frac > 0.98, frac
+    ess, res = one["ess"][fin], one["resampled"][fin]
+    assert float(ess.min()) >= 1.0 - 1e-3 and float(ess.max()) <= N * (1 + 1e-5)
+    assert bool(((ess < 0.5 * N) == (res == 1)).all())
