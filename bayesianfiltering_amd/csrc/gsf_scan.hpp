@@ -412,10 +412,22 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
         mu[cc] = reduce_k_lane(w * mj[cc]);
         dj[cc] = mj[cc] - mu[cc];
       }
+      // Every lane of the trajectory holds every sum.  With at least n^2 / NL component slots the lane of component q keeps
+      // the q-th of its group's NS * CPL entries and the whole matrix goes out in ONE store instruction per step (64 lanes x 4
+      // bytes, contiguous for a contiguous stream); otherwise the lanes of component 0 store them one by one.
+      const bool spread = KP >= NS * CPL;
       const bool writer = traj_ok && k == 0;
-      if (out.cm.p && writer) BF_UNROLL for (int cc = 0; cc < CPL; ++cc)
-          out.cm.p[b * out.cm.sB + t * out.cm.sT + (jl * CPL + cc) * out.cm.sE] = mu[cc];
+      if (out.cm.p) {
+        if (spread) {
+          float keep = mu[0];
+          BF_UNROLL for (int cc = 1; cc < CPL; ++cc) keep = (k == cc) ? mu[cc] : keep;
+          if (traj_ok && k < CPL) out.cm.p[b * out.cm.sB + t * out.cm.sT + (jl * CPL + k) * out.cm.sE] = keep;
+        } else if (writer) {
+          BF_UNROLL for (int cc = 0; cc < CPL; ++cc) out.cm.p[b * out.cm.sB + t * out.cm.sT + (jl * CPL + cc) * out.cm.sE] = mu[cc];
+        }
+      }
       if (out.cP.p) {
+        float keep = 0.f;
         static_for<0, NS>([&](auto I) {
           constexpr int i = decltype(I)::value;
           // deviation of the row held in slot i (relative coordinates in the Lorenz-96 instance)
@@ -424,9 +436,12 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
           else di = group_bcast<NL, i / CPL>(dj[i % CPL]);
           BF_UNROLL for (int cc = 0; cc < CPL; ++cc) {
             const float s = reduce_k_lane(w * fmaf(di, dj[cc], Pc[cc][i]));
-            if (writer) out.cP.p[b * out.cP.sB + t * out.cP.sT + (rowabs(i) * NS + jl * CPL + cc) * out.cP.sE] = s;
+            if (spread) keep = (k == i * CPL + cc) ? s : keep;
+            else if (writer) out.cP.p[b * out.cP.sB + t * out.cP.sT + (rowabs(i) * NS + jl * CPL + cc) * out.cP.sE] = s;
           }
         });
+        if (spread && traj_ok && k < NS * CPL)
+          out.cP.p[b * out.cP.sB + t * out.cP.sT + (rowabs(k / CPL) * NS + jl * CPL + k % CPL) * out.cP.sE] = keep;
       }
     }
 
