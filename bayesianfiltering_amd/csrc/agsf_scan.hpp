@@ -650,6 +650,10 @@ static inline int launch_agsf_nodes(typename NODES::Arg arg, const bf_cstream* y
       MP = 256;
       BF_GEOM(4);
     }
+    if (MP <= 512) {  // e.g. the [100, 2, 2] tree of BOT_Experiment_script.py:118: 400 leaves on 8 waves, two trajectories per CU
+      MP = 512;
+      BF_GEOM(8);
+    }
     MP = 1024;
     BF_GEOM(16);
   } else {

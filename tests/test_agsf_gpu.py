@@ -192,10 +192,11 @@ def test_optimal_variant(nc):
     assert np.allclose(aux["carry"].weights.cpu().numpy()[0], ref.weights[:, -1], rtol=3e-4, atol=1e-7)
 
 
-@pytest.mark.parametrize("nc,unscented", [((100, 2, 2), False), ((3, 5, 7), False), ((20, 3, 3), True), ((70, 1, 1), False)])
+@pytest.mark.parametrize("nc,unscented", [((100, 2, 2), False), ((3, 5, 7), False), ((20, 3, 3), True), ((70, 1, 1), False),
+                                          ((100, 2, 2), True), ((130, 2, 3), False)])
 def test_trees_wider_than_a_wave(nc, unscented):
-    """num_components = [100, 2, 2] is what BOT_Experiment_script.py:118 runs: 400 leaves = one 1024-thread workgroup
-    per trajectory (reductions and the cumulative sum continue across waves); 105 and 180 leaves use 256 threads."""
+    """num_components = [100, 2, 2] is what BOT_Experiment_script.py:118 runs: 400 leaves = one 512-thread workgroup
+    per trajectory (reductions and the cumulative sum continue across waves); 105 and 180 leaves use 256 threads, 780 leaves 1024."""
     bfa, nl = _nl()
     T, B = 8, 2
     mu0 = np.array([2.0, 0.3, 3.0, -0.2], F32)
