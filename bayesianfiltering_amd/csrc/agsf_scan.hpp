@@ -646,6 +646,10 @@ static inline int launch_agsf_nodes(typename NODES::Arg arg, const bf_cstream* y
 #define BF_GEOM(NW_) return launch_agsf_geom<N, M, NODES, NW_>(arg, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, variant, MP, d_tvq, d_tvr, stream)
   if (MP <= 64) BF_GEOM(1);
   if constexpr (N <= 4) {  // the multi-wave geometries are built for the small state dimensions only (build time, LDS)
+    if (MP <= 128) {  // e.g. the [5, 5, 5] tree of the reference's own test (docs/tests/test_inference.py): 125 leaves on 2 waves
+      MP = 128;
+      BF_GEOM(2);
+    }
     if (MP <= 256) {
       MP = 256;
       BF_GEOM(4);

@@ -643,7 +643,7 @@ int launch_agsf_user_impl(const bf_model* p, const bf_ukf_params* up, const bf_c
   int nw = 1;
   if (MP > 64) {
     if (p->n > 4) return set_error(BF_EUNSUPPORTED, "augmented Gaussian-sum filter: more than 64 leaves per trajectory need state_dim <= 4");
-    nw = MP <= 256 ? 4 : (MP <= 512 ? 8 : 16);
+    nw = MP <= 128 ? 2 : (MP <= 256 ? 4 : (MP <= 512 ? 8 : 16));
     MP = 64 * nw;
   }
   const size_t lds_bytes = agsf_lds_bytes(p->n, nw, nc[0]);

@@ -94,7 +94,7 @@ def test_augmented_gaussian_sum_filter():                                # :84-8
 
 
 def test_augmented_gaussian_sum_filter_optimal():                        # :89-92
-    """The reference's own tree, num_components = [5, 5, 5]: 125 leaves, one 256-thread workgroup per trajectory."""
+    """The reference's own tree, num_components = [5, 5, 5]: 125 leaves, one 128-thread workgroup per trajectory."""
     bfa, po, pp = _params(25e-6)
     ys = _data(bfa, pp)
     post, aux = bfa.augmented_gaussian_sum_filter_optimal(pp, ys, [5, 5, 5], opt_args=(0.1, 0.1), inputs=INPUTS)
