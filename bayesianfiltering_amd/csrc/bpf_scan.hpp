@@ -639,7 +639,9 @@ static inline int launch_bpf_dims(const bf_bpf_model* bp, const bf_cstream* y, c
   auto by_capacity = [&](auto spec) -> int {
     using SP = decltype(spec);
     if (NP <= 64) return launch_bpf_cfg<N, DQ, M, 1, 1, SP>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
+    if (NP <= 128) return launch_bpf_cfg<N, DQ, M, 1, 2, SP>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);   // (the reference's usual 100)
     if (NP <= 256) return launch_bpf_cfg<N, DQ, M, 1, 4, SP>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
+    if (NP <= 512) return launch_bpf_cfg<N, DQ, M, 1, 8, SP>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
     if (NP <= 1024) return launch_bpf_cfg<N, DQ, M, 1, 16, SP>(d_mdl, y, u, B, T, NP, ess, resampler, key, cr, out, stream);
     if (NP <= 4096) {
       // two geometries for the largest capacity: 1024 threads x 4 particles (128-VGPR budget, variant 0, the default) or

@@ -506,7 +506,9 @@ static int launch_bpf_jit(bf_user_model* um, const bf_bpf_model* bp, const bf_cs
   // smallest particle capacity that holds NP (the geometries of bpf_scan.hpp: particles in registers)
   int ppt, nw;
   if (NP <= 64) { ppt = 1; nw = 1; }
+  else if (NP <= 128) { ppt = 1; nw = 2; }
   else if (NP <= 256) { ppt = 1; nw = 4; }
+  else if (NP <= 512) { ppt = 1; nw = 8; }
   else if (NP <= 1024) { ppt = 1; nw = 16; }
   else if (NP <= 4096 && N <= 16) { ppt = 4; nw = 16; }
   else return set_error(BF_EUNSUPPORTED, "particle filter compiled at run time (functions from source, or bpf_arith = 1): at most 4096 particles for state_dim <= 16, 1024 beyond");
