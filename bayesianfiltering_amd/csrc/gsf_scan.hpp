@@ -426,7 +426,38 @@ gsf_scan_kernel(EkfModel<NS, M> mdl, CView y, UView uin, CarryView carry, OutVie
           BF_UNROLL for (int cc = 0; cc < CPL; ++cc) out.cm.p[b * out.cm.sB + t * out.cm.sT + (jl * CPL + cc) * out.cm.sE] = mu[cc];
         }
       }
-      if (out.cP.p) {
+      // 32 entries per lane group on one wave of 32 components x 2 lanes (BASELINE configs[2]): a reduce-scatter instead of 32
+      // all-reduces.  Rows of 16 lanes sum by rotation as in reduce_k_lane; then entries j, 8 + j, 16 + j, 24 + j share the two
+      // cross-row steps (pair16 / pair32_reduce_scatter: the four totals land in the four rows) and the lane of component
+      // q = 8 (row) + j keeps its own.  Same operands in the same order as the all-reduce: the same bits, a third of the
+      // instructions.
+      bool scattered = false;
+      if constexpr (NS * CPL == 32 && NL == 2) if (out.cP.p && seg == 64) {
+        scattered = true;
+        float di[NS];
+        static_for<0, NS>([&](auto I) {
+          constexpr int i = decltype(I)::value;
+          if constexpr (L96) di[i] = group_rot<NL, i / CPL>(dj[i % CPL]);
+          else di[i] = group_bcast<NL, i / CPL>(dj[i % CPL]);
+        });
+        float keep = 0.f;
+        static_for<0, 8>([&](auto J) {
+          constexpr int j = decltype(J)::value;
+          float t[4];
+          static_for<0, 4>([&](auto Mq) {
+            constexpr int e = 8 * decltype(Mq)::value + j, i = e / CPL, cc = e % CPL;
+            float v = w * fmaf(di[i], dj[cc], Pc[cc][i]);
+            v += dpp_mov<0x122>(v);  // row_ror:2
+            v += dpp_mov<0x124>(v);  // row_ror:4
+            v += dpp_mov<0x128>(v);  // row_ror:8
+            t[decltype(Mq)::value] = v;
+          });
+          const float r = pair32_reduce_scatter(pair16_reduce_scatter(t[0], t[1]), pair16_reduce_scatter(t[2], t[3]));
+          keep = ((k & 7) == j) ? r : keep;
+        });
+        if (traj_ok) out.cP.p[b * out.cP.sB + t * out.cP.sT + (rowabs(k / CPL) * NS + jl * CPL + k % CPL) * out.cP.sE] = keep;
+      }
+      if (out.cP.p && !scattered) {
         float keep = 0.f;
         static_for<0, NS>([&](auto I) {
           constexpr int i = decltype(I)::value;

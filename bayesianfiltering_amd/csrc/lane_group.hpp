@@ -71,6 +71,19 @@ __device__ __forceinline__ float xor32_combine(float v, Op op) {
   return op(a, b);
 }
 
+// Two different values at once: x + (x of the lane 16 away) lands in the even rows of 16 lanes, y + (y of the lane 16 away)
+// in the odd rows -- the swap exchanges the first operand's odd rows with the second's even rows, so ONE swap and ONE add
+// reduce two values where xor16_combine spends them on one.  Same operands in every sum, so the same bits.
+__device__ __forceinline__ float pair16_reduce_scatter(float x, float y) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+  return x + y;
+}
+// likewise across the two halves of the wave: the lower 32 lanes end with x's total, the upper 32 with y's
+__device__ __forceinline__ float pair32_reduce_scatter(float x, float y) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+  return x + y;
+}
+
 // sum over the NL lanes of the group, result in every lane (xor butterfly: 1, 2, 4, ...)
 template <int NL>
 __device__ __forceinline__ float group_sum(float v) {

@@ -340,7 +340,8 @@ def test_time_varying_covariances():
         bfa.bootstrap_particle_filter(bp, ys[0], 64, bfa.PRNGKey(0))
 
 
-@pytest.mark.parametrize("case", ["l96_structured", "l96_dense_lanes4", "cv_k100_two_waves", "bot_k3"])
+@pytest.mark.parametrize("case", ["l96_structured", "l96_dense_lanes4", "cv_k100_two_waves", "bot_k3", "l96_structured_k32", "l96_dense_k32",
+                                  "l96_structured_k64"])
 def test_collapsed_mode_matches_collapse_of_the_streams(case):
     """COLLAPSED mode: the in-scan moment matching equals utils.collapse (utils.py:10-18) applied to the
     oracle's per-step mixture, for chains inside one wave, across waves (K = 100) and padded K."""
@@ -349,6 +350,10 @@ def test_collapsed_mode_matches_collapse_of_the_streams(case):
     inputs = None
     if case.startswith("l96"):
         n, K, T, B = 8, 8, 12, 4
+        # K = 32 at two lanes per component is BASELINE configs[2]'s geometry (one wave per trajectory: the covariance entries
+        # leave through the reduce-scatter of gsf_scan.hpp); K = 64 spans two waves
+        K = 32 if case.endswith("k32") else (64 if case.endswith("k64") else 8)
+        B = 5 if K > 8 else 4
         po = go.ParamsNLSSM(np.zeros(8, F32), np.eye(8, dtype=F32), om.Lorenz96(8), np.zeros(8, F32),
                             1e-2 * np.eye(8, dtype=F32), om.PickEven(8), np.zeros(4, F32), 1e-1 * np.eye(4, dtype=F32))
         pp = bfa.ParamsNLSSM(np.zeros(8, F32), np.eye(8, dtype=F32), nl.lorenz96(8), np.zeros(8, F32),
@@ -364,6 +369,9 @@ def test_collapsed_mode_matches_collapse_of_the_streams(case):
     if case == "l96_dense_lanes4":
         _opt(b"gsf_structured", 0)
         _opt(b"kf_lanes", 4)
+    if case == "l96_dense_k32":
+        _opt(b"gsf_structured", 0)
+        _opt(b"kf_lanes", 2)
     try:
         post, (cmean, ccov) = bfa.gaussian_sum_filter(pp, ys, K, 1, initial_means=init, return_collapsed=True)
         only = bfa.gaussian_sum_filter(pp, ys, K, 1, initial_means=init, fields=(), return_collapsed=True)
