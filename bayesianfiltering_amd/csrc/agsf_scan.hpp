@@ -471,10 +471,20 @@ agsf_scan_body(typename NODES::Arg mdl, CView y, UView uin, CarryView carry, Ags
     return v;
   };
 
+  // observation and input of step t + 1 are fetched while step t runs (a load issued at the top of its own step would put
+  // an HBM round trip on every step's critical path)
+  float ynext[M], unext;
+  BF_UNROLL for (int a = 0; a < M; ++a) ynext[a] = y.p[b * y.sB + a * y.sE];
+  unext = uin.p ? uin.p[b * uin.sB + 0 * uin.sT] : 0.f;
   for (long long t = 0; t < T; ++t) {
     float yv[M];
-    BF_UNROLL for (int a = 0; a < M; ++a) yv[a] = y.p[b * y.sB + t * y.sT + a * y.sE];
-    const float u0 = uin.p ? uin.p[b * uin.sB + t * uin.sT] : 0.f;
+    BF_UNROLL for (int a = 0; a < M; ++a) yv[a] = ynext[a];
+    const float u0 = unext;
+    {
+      const long long tn = t + 1 < T ? t + 1 : t;
+      BF_UNROLL for (int a = 0; a < M; ++a) ynext[a] = y.p[b * y.sB + tn * y.sT + a * y.sE];
+      unext = uin.p ? uin.p[b * uin.sB + tn * uin.sT] : 0.f;
+    }
 
     // ---- z-sample of the (i0, i1) node and its prediction (:675-698)
     float mz[N], P[EP];

@@ -342,10 +342,20 @@ __device__ __forceinline__ void ugsf_scan_body(const UkfModel<N, DQ, M, DR>* __r
   BF_UNROLL for (int i = 0; i < N; ++i) m[i] = carry.m_in[chain * N + i];
   w = comp_ok ? (carry.w_in ? carry.w_in[chain] : 1.0f / (float)K) : 0.f;
 
+  // observation and input of step t + 1 are fetched while step t runs (a load issued at the top of its own step would put
+  // an HBM round trip on every step's critical path)
+  float ynext[M], unext;
+  BF_UNROLL for (int a = 0; a < M; ++a) ynext[a] = y.p[b * y.sB + a * y.sE];
+  unext = uptr ? uptr[b * u_sB + 0 * u_sT] : 0.f;
   for (long long t = 0; t < T; ++t) {
     float yv[M];
-    BF_UNROLL for (int a = 0; a < M; ++a) yv[a] = y.p[b * y.sB + t * y.sT + a * y.sE];
-    const float u0 = uptr ? uptr[b * u_sB + t * u_sT] : 0.f;
+    BF_UNROLL for (int a = 0; a < M; ++a) yv[a] = ynext[a];
+    const float u0 = unext;
+    {
+      const long long tn = t + 1 < T ? t + 1 : t;
+      BF_UNROLL for (int a = 0; a < M; ++a) ynext[a] = y.p[b * y.sB + tn * y.sT + a * y.sE];
+      unext = uptr ? uptr[b * u_sB + tn * u_sT] : 0.f;
+    }
     float ll;
 
     // ================= _ukf_condition_on_nonadditive (inference.py:198-224)
