@@ -74,12 +74,24 @@ __device__ __forceinline__ void sym_sqrt(float* a) {
         const float apq = a[p * N + q];
         const float app = a[p * N + p], aqq = a[q * N + q];
         // rotation angle: tan(2 phi) = 2 a_pq / (a_qq - a_pp), the smaller root t = tan(phi)
+        // (single-instruction reciprocal / square roots, 1 ulp: the rotation only has to shrink a_pq -- what an ulp in t, c
+        // leaves behind goes in the next sweep, and the sweeps stop on the measured off-diagonal mass; IEEE division and
+        // square root cost ten instructions each, three times per rotation)
+#if defined(__HIP_DEVICE_COMPILE__)
+        const float theta = (aqq - app) * __builtin_amdgcn_rcpf(2.f * apq);
+        float t = __builtin_amdgcn_rcpf(fabsf(theta) + __builtin_amdgcn_sqrtf(fmaf(theta, theta, 1.f)));
+#else
         const float theta = (aqq - app) / (2.f * apq);
         float t = 1.f / (fabsf(theta) + sqrtf(fmaf(theta, theta, 1.f)));
+#endif
         t = theta < 0.f ? -t : t;
         const bool skip = !(fabsf(apq) > 1e-30f);  // already zero (or NaN): identity rotation
         t = skip ? 0.f : t;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const float c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.f)), s = t * c;
+#else
         const float c = 1.f / sqrtf(fmaf(t, t, 1.f)), s = t * c;
+#endif
         a[p * N + p] = app - t * apq;
         a[q * N + q] = aqq + t * apq;
         a[p * N + q] = 0.f;

@@ -448,8 +448,7 @@ def test_unscented_filter_with_functions_from_source(K):
     """unscented_gaussian_sum_filter (gaussfiltax/inference.py:379-456) pushes sigma points through ARBITRARY f(x, q, u),
     h(x, r, u) (:146-224): Lorenz-63 dynamics and the quadratic emission of docs/experiments/exp_lorentz63.py as source
     strings, compiled at run time into the unscented kernel, against their registry twins and against the oracle.
-    * twins agree to the last few ulps (<= 1e-5 relative over 30 steps of the chaotic map, measured 6e-6; bit for bit over the first steps when
-      only h comes from source), not bit for bit throughout: the unscented kernel's sigma-point algebra is compiled with
+    * twins agree to the last few ulps (<= 1e-5 relative over 30 steps of the chaotic map, measured 6e-6), not bit for bit: the unscented kernel's sigma-point algebra is compiled with
       floating-point contraction, and the compiler's fusion choices depend on the code inlined into it (measured: keeping f out
       of line makes dynamics twins bit-identical over 6 steps at 1.5 x the registry path's run time; the particle filter,
       whose weight path is contraction-free by definition, IS bit-identical to its twins);
@@ -475,7 +474,6 @@ def test_unscented_filter_with_functions_from_source(K):
         b_, lb = bfa.unscented_gaussian_sum_filter(usr, up, ys, K, 1, initial_means=im, return_loglik=True)
         for k in FIELDS[1:]:
             assert cm.rel_err(getattr(b_, k).cpu().numpy(), getattr(a, k).cpu().numpy()) < 1e-5, k
-            assert np.array_equal(_bits(getattr(b_, k)[:, :, :3]), _bits(getattr(a, k)[:, :, :3])) or usr.dynamics_function is f_usr, k
         assert np.max(np.abs(b_.weights.cpu().numpy() - a.weights.cpu().numpy())) < 2e-5   # (mixture weights amplify: exp of a log-likelihood difference)
         assert cm.rel_err(lb.cpu().numpy(), la.cpu().numpy()) < 1e-5
     if K <= 5:
