@@ -322,67 +322,6 @@ struct UkfNodes {
   }
 };
 
-#ifdef BF_AGSF_USER_EKF_NODES
-// Extended-Kalman nodes around functions compiled from the caller's source (user_model.hip): the Jacobians of
-// inference.py:58-61 / :82-86 (jacfwd w.r.t. the state and w.r.t. the noise, at the noise bias) by forward-mode dual numbers,
-// one seed direction after the other on the leaf's own lane; F_q Q F_q^T and H_r R H_r^T formed here every step.  The model
-// block is a UkfModel whose sQ / sR (and per-step tables) hold Q / R THEMSELVES (fill_ukf_model_view, raw-covariance flag).
-template <int N, int DQ, int M, int DR>
-struct UserEkfNodes {
-  using Arg = const UkfModel<N, DQ, M, DR>*;
-  static constexpr int TVQ = DQ * DQ, TVR = DR * DR;
-  template <int R_, int C_, int D_>   // J (R_ x C_) S (C_ x C_) J^T: (J S) first, then times J^T -- the reference's association
-  static __device__ __forceinline__ void congruence(const float* J, const float* S, float* out) {
-    float JS[R_ * C_];
-    BF_UNROLL for (int i = 0; i < R_; ++i) BF_UNROLL for (int j = 0; j < C_; ++j) {
-      float s = 0.f;
-      BF_UNROLL for (int k = 0; k < C_; ++k) s = fmaf(J[i * C_ + k], S[k * C_ + j], s);
-      JS[i * C_ + j] = s;
-    }
-    BF_UNROLL for (int i = 0; i < R_; ++i) BF_UNROLL for (int j = 0; j < R_; ++j) {
-      float s = 0.f;
-      BF_UNROLL for (int k = 0; k < C_; ++k) s = fmaf(JS[i * C_ + k], J[j * C_ + k], s);
-      out[i * D_ + j] = s;
-    }
-  }
-  static __device__ __forceinline__ void predict(Arg mdl, float* m, float* P, float u0, const float* tq) {
-    float F[N * N], Fq[N * DQ], fx[N], FqQFq[N * N];
-    bfu::Dual xd[N], qd[DQ], od[N];
-    BF_UNROLL for (int i = 0; i < N; ++i) xd[i] = bfu::Dual(m[i]);
-    BF_UNROLL for (int i = 0; i < DQ; ++i) qd[i] = bfu::Dual(mdl->q0[i]);
-    BF_UNROLL for (int s = 0; s < N + DQ; ++s) {
-      if (s < N) xd[s < N ? s : 0].d = 1.f; else qd[s >= N ? s - N : 0].d = 1.f;
-      bfu::dynamics<bfu::Dual>(xd, qd, bfu::Dual(u0), mdl->uth_dyn, od);
-      if (s < N) xd[s < N ? s : 0].d = 0.f; else qd[s >= N ? s - N : 0].d = 0.f;
-      BF_UNROLL for (int i = 0; i < N; ++i) {
-        if (s < N) F[i * N + (s < N ? s : 0)] = od[i].d; else Fq[i * DQ + (s >= N ? s - N : 0)] = od[i].d;
-        fx[i] = od[i].v;
-      }
-    }
-    congruence<N, DQ, N>(Fq, tq ? tq : mdl->sQ, FqQFq);
-    predict_cov<N>(F, FqQFq, P);  // F P F^T + F_q Q F_q^T
-    BF_UNROLL for (int i = 0; i < N; ++i) m[i] = fx[i];
-  }
-  static __device__ __forceinline__ float condition(Arg mdl, float* m, float* P, const float* yv, float u0, const float* tr) {
-    float H[M * N], Hr[M * DR], hx[M], HrRHr[M * M], v[M];
-    bfu::Dual xd[N], rd[DR], od[M];
-    BF_UNROLL for (int i = 0; i < N; ++i) xd[i] = bfu::Dual(m[i]);
-    BF_UNROLL for (int i = 0; i < DR; ++i) rd[i] = bfu::Dual(mdl->r0[i]);
-    BF_UNROLL for (int s = 0; s < N + DR; ++s) {
-      if (s < N) xd[s < N ? s : 0].d = 1.f; else rd[s >= N ? s - N : 0].d = 1.f;
-      bfu::emission<bfu::Dual>(xd, rd, bfu::Dual(u0), mdl->uth_emi, od);
-      if (s < N) xd[s < N ? s : 0].d = 0.f; else rd[s >= N ? s - N : 0].d = 0.f;
-      BF_UNROLL for (int a = 0; a < M; ++a) {
-        if (s < N) H[a * N + (s < N ? s : 0)] = od[a].d; else Hr[a * DR + (s >= N ? s - N : 0)] = od[a].d;
-        hx[a] = od[a].v;
-      }
-    }
-    congruence<M, DR, M>(Hr, tr ? tr : mdl->sR, HrRHr);
-    BF_UNROLL for (int a = 0; a < M; ++a) v[a] = yv[a] - hx[a];
-    return condition_on<N, M>(H, HrRHr, v, m, P);
-  }
-};
-#endif  // BF_AGSF_USER_EKF_NODES
 
 
 // NW = 1: the MP <= 64 leaves of a trajectory are lanes of one wave, 256 / MP trajectories per 256-thread workgroup.

@@ -60,6 +60,9 @@ CallOverrides& call_overrides() {
 
 // tuning options: process-wide defaults (atomics) with per-call overrides (bf_common.hpp: Option)
 extern Option g_bpf_variant;
+bool gsf_user_regs_eligible(const bf_model* p, int K, const bf_out_desc* out);   // user_model.hip
+int launch_gsf_user_regs_impl(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int K, const bf_carry* carry,
+                              const bf_out_desc* out, hipStream_t stream);
 extern Option g_bpf_hbm_mode;
 extern Option g_bpf_spec;
 extern Option g_bpf_arith;
@@ -256,6 +259,8 @@ int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream*
   if (!carry->m_in || !carry->P_in) return bf::set_error(BF_EINVAL, "carry.m_in and carry.P_in are required");
   hipStream_t hs = static_cast<hipStream_t>(stream);
   auto generic = [&]() { return bf::launch_gsf_generic(model, y, u, B, T, K, carry, out, hs); };
+  if (model->user && bf::g_force_generic.load() == 0 && bf::gsf_user_regs_eligible(model, K, out))   // from source, n <= 8: state in registers
+    return bf::launch_gsf_user_regs_impl(model, y, u, B, T, K, carry, out, hs);
   if (model->user || model->dyn_id == BF_FN_USER || model->emi_id == BF_FN_USER) return generic();  // compiled from source
   if (bf::g_force_generic.load()) return generic();
   // a LINEAR model beyond the register kernels (n >= 9): the Gaussian-sum filter's K components take turns on the matrix-core

@@ -21,6 +21,7 @@
 // same segmented xor-butterfly (adjacent-pair tree) as in gsf_scan.hpp.  Outputs go out as strided
 // dword stores: a step is ~10^4 VALU operations, the stores are not what bounds it.
 #pragma once
+#include <type_traits>
 #ifndef BF_JIT
 #include <cstring>
 #include <cmath>
@@ -314,7 +315,103 @@ __device__ __forceinline__ void ukf_predict(const UkfModel<N, DQ, M, DR>& mdl, f
   BF_UNROLL for (int i = 0; i < N; ++i) m[i] = mu[i];
 }
 
-template <int N, int DQ, int M, int DR, class SP = SpecRuntime>
+#ifdef BF_USER_EKF_NODES
+// Extended-Kalman node operations around functions compiled from the caller's source (user_model.hip): _predict /
+// _condition_on (inference.py:51-105) with the Jacobians of :58-61 / :82-86 -- jacfwd w.r.t. the state AND w.r.t. the noise, at
+// the noise bias -- by forward-mode dual numbers, one seed direction after the other on the chain's own lane; F_q Q F_q^T and
+// H_r R H_r^T are formed here every step.  A function that is not from source must be the registry's linear one (A x + G q,
+// H x + D r: its Jacobians are the matrices).  The model block is a UkfModel whose sQ / sR (and per-step tables) hold Q / R
+// THEMSELVES (fill_ukf_model_view, raw-covariance flag).  Used by the augmented filter's tree nodes (agsf_scan.hpp) and, one
+// lane per (trajectory, component), by the Gaussian-sum scan below.
+template <int N, int DQ, int M, int DR, class SP>
+struct UserEkfNodes {
+  using Arg = const UkfModel<N, DQ, M, DR>*;
+  static constexpr int TVQ = DQ * DQ, TVR = DR * DR;
+  template <int R_, int C_, int D_>   // J (R_ x C_) S (C_ x C_) J^T: (J S) first, then times J^T -- the reference's association
+  static __device__ __forceinline__ void congruence(const float* J, const float* S, float* out) {
+    float JS[R_ * C_];
+    BF_UNROLL for (int i = 0; i < R_; ++i) BF_UNROLL for (int j = 0; j < C_; ++j) {
+      float s = 0.f;
+      BF_UNROLL for (int k = 0; k < C_; ++k) s = fmaf(J[i * C_ + k], S[k * C_ + j], s);
+      JS[i * C_ + j] = s;
+    }
+    BF_UNROLL for (int i = 0; i < R_; ++i) BF_UNROLL for (int j = 0; j < R_; ++j) {
+      float s = 0.f;
+      BF_UNROLL for (int k = 0; k < C_; ++k) s = fmaf(JS[i * C_ + k], J[j * C_ + k], s);
+      out[i * D_ + j] = s;
+    }
+  }
+  static __device__ __forceinline__ void predict(Arg mdl, float* m, float* P, float u0, const float* tq) {
+    float F[N * N], Fq[N * DQ], fx[N], FqQFq[N * N];
+#ifdef BF_USER_DYN
+    if constexpr (SP::user_dyn) {
+      bfu::Dual xd[N], qd[DQ], od[N];
+      BF_UNROLL for (int i = 0; i < N; ++i) xd[i] = bfu::Dual(m[i]);
+      BF_UNROLL for (int i = 0; i < DQ; ++i) qd[i] = bfu::Dual(mdl->q0[i]);
+      BF_UNROLL for (int s = 0; s < N + DQ; ++s) {
+        if (s < N) xd[s < N ? s : 0].d = 1.f; else qd[s >= N ? s - N : 0].d = 1.f;
+        bfu::dynamics<bfu::Dual>(xd, qd, bfu::Dual(u0), mdl->uth_dyn, od);
+        if (s < N) xd[s < N ? s : 0].d = 0.f; else qd[s >= N ? s - N : 0].d = 0.f;
+        BF_UNROLL for (int i = 0; i < N; ++i) {
+          if (s < N) F[i * N + (s < N ? s : 0)] = od[i].d; else Fq[i * DQ + (s >= N ? s - N : 0)] = od[i].d;
+          fx[i] = od[i].v;
+        }
+      }
+    } else
+#endif
+    {  // the registry's linear dynamics A x + G q
+      BF_UNROLL for (int i = 0; i < N * N; ++i) F[i] = mdl->A[i];
+      BF_UNROLL for (int i = 0; i < N * DQ; ++i) Fq[i] = mdl->Gm[i];
+      BF_UNROLL for (int i = 0; i < N; ++i) {
+        float s = 0.f, g = 0.f;
+        BF_UNROLL for (int k = 0; k < N; ++k) s = fmaf(mdl->A[i * N + k], m[k], s);
+        BF_UNROLL for (int k = 0; k < DQ; ++k) g = fmaf(mdl->Gm[i * DQ + k], mdl->q0[k], g);
+        fx[i] = s + g;
+      }
+    }
+    congruence<N, DQ, N>(Fq, tq ? tq : mdl->sQ, FqQFq);
+    predict_cov<N>(F, FqQFq, P);  // F P F^T + F_q Q F_q^T
+    BF_UNROLL for (int i = 0; i < N; ++i) m[i] = fx[i];
+  }
+  static __device__ __forceinline__ float condition(Arg mdl, float* m, float* P, const float* yv, float u0, const float* tr) {
+    float H[M * N], Hr[M * DR], hx[M], HrRHr[M * M], v[M];
+#ifdef BF_USER_EMI
+    if constexpr (SP::user_emi) {
+      bfu::Dual xd[N], rd[DR], od[M];
+      BF_UNROLL for (int i = 0; i < N; ++i) xd[i] = bfu::Dual(m[i]);
+      BF_UNROLL for (int i = 0; i < DR; ++i) rd[i] = bfu::Dual(mdl->r0[i]);
+      BF_UNROLL for (int s = 0; s < N + DR; ++s) {
+        if (s < N) xd[s < N ? s : 0].d = 1.f; else rd[s >= N ? s - N : 0].d = 1.f;
+        bfu::emission<bfu::Dual>(xd, rd, bfu::Dual(u0), mdl->uth_emi, od);
+        if (s < N) xd[s < N ? s : 0].d = 0.f; else rd[s >= N ? s - N : 0].d = 0.f;
+        BF_UNROLL for (int a = 0; a < M; ++a) {
+          if (s < N) H[a * N + (s < N ? s : 0)] = od[a].d; else Hr[a * DR + (s >= N ? s - N : 0)] = od[a].d;
+          hx[a] = od[a].v;
+        }
+      }
+    } else
+#endif
+    {  // the registry's linear emission H x + D r
+      BF_UNROLL for (int i = 0; i < M * N; ++i) H[i] = mdl->Hm[i];
+      BF_UNROLL for (int i = 0; i < M * DR; ++i) Hr[i] = mdl->Dm[i];
+      BF_UNROLL for (int a = 0; a < M; ++a) {
+        float s = 0.f, g = 0.f;
+        BF_UNROLL for (int k = 0; k < N; ++k) s = fmaf(mdl->Hm[a * N + k], m[k], s);
+        BF_UNROLL for (int k = 0; k < DR; ++k) g = fmaf(mdl->Dm[a * DR + k], mdl->r0[k], g);
+        hx[a] = s + g;
+      }
+    }
+    congruence<M, DR, M>(Hr, tr ? tr : mdl->sR, HrRHr);
+    BF_UNROLL for (int a = 0; a < M; ++a) v[a] = yv[a] - hx[a];
+    return condition_on<N, M>(H, HrRHr, v, m, P);
+  }
+};
+#endif  // BF_USER_EKF_NODES
+
+// NODES = void: the unscented operations above (sQ / sR: square roots).  Any other NODES (UserEkfNodes): its condition / predict
+// pair on the same lane-per-(trajectory, component) scan -- the Gaussian-sum filter of inference.py:333-371 with the caller's
+// functions in registers (sQ / sR: the covariances themselves).
+template <int N, int DQ, int M, int DR, class SP = SpecRuntime, class NODES = void>
 __device__ __forceinline__ void ugsf_scan_body(const UkfModel<N, DQ, M, DR>* __restrict__ mdlp, CView y, const float* __restrict__ uptr, long long u_sB,
                  long long u_sT, CarryView carry, OutViews out, long long B, long long T, int K, int KP,
                  const float* __restrict__ tvsq, const float* __restrict__ tvsr) {
@@ -371,7 +468,8 @@ __device__ __forceinline__ void ugsf_scan_body(const UkfModel<N, DQ, M, DR>* __r
     float ll;
 
     // ================= _ukf_condition_on_nonadditive (inference.py:198-224)
-    ll = ukf_condition_on<SP>(mdl, m, P, yv, u0, tvsr ? tvsr + t * (DR * DR) : mdl.sR);
+    if constexpr (std::is_void<NODES>::value) ll = ukf_condition_on<SP>(mdl, m, P, yv, u0, tvsr ? tvsr + t * (DR * DR) : mdl.sR);
+    else ll = NODES::condition(mdlp, m, P, yv, u0, tvsr ? tvsr + t * (DR * DR) : nullptr);
 
     // ================= reweight (inference.py:424-427)
     {
@@ -389,7 +487,8 @@ __device__ __forceinline__ void ugsf_scan_body(const UkfModel<N, DQ, M, DR>* __r
     }
 
     // ================= _ukf_predict_nonadditive (inference.py:146-174)
-    ukf_predict<SP>(mdl, m, P, u0, tvsq ? tvsq + t * (DQ * DQ) : mdl.sQ);
+    if constexpr (std::is_void<NODES>::value) ukf_predict<SP>(mdl, m, P, u0, tvsq ? tvsq + t * (DQ * DQ) : mdl.sQ);
+    else NODES::predict(mdlp, m, P, u0, tvsq ? tvsq + t * (DQ * DQ) : nullptr);
     if (chain_ok) {
       if (out.pm.p) BF_UNROLL for (int i = 0; i < N; ++i) out.pm.p[b * out.pm.sB + k * out.pm.sK + t * out.pm.sT + i * out.pm.sE] = m[i];
       if (out.pP.p) BF_UNROLL for (int i = 0; i < EP; ++i) out.pP.p[b * out.pP.sB + k * out.pP.sK + t * out.pP.sT + i * out.pP.sE] = P[i];

@@ -39,6 +39,7 @@ struct bf_user_model {
   std::string dyn_src, emi_src, lp_src;  // kept: the particle-filter kernels are built on first use, per particle capacity
   std::map<int, hipFunction_t> bpf;       // key = PPT * 100 + NW
   hipFunction_t ugsf = nullptr;           // the unscented Gaussian-sum scan, built on first use
+  hipFunction_t gsf_regs = nullptr;       // the Gaussian-sum scan with the state in registers (n <= 8), built on first use
   std::map<int, hipFunction_t> agsf;      // the augmented Gaussian-sum scan; key = kind * 100 + waves per trajectory
   std::vector<hipModule_t> extra_mods;
 };
@@ -400,7 +401,7 @@ __device__ inline float tanh(float x) { return ::tanhf(x); }
 __device__ inline float pow(float x, float p) { return ::powf(x, p); }
 )BFSRC";
 
-enum { JIT_BPF = 0, JIT_UGSF = 1, JIT_AGSF_UKF = 2, JIT_AGSF_EKF = 3 };
+enum { JIT_BPF = 0, JIT_UGSF = 1, JIT_AGSF_UKF = 2, JIT_AGSF_EKF = 3, JIT_GSF_REGS = 4 };
 
 std::string build_bpf_source(const bf_user_model* um, int ppt, int nw, int kind = JIT_BPF, const char* spec_override = nullptr) {
   std::string s = "#define BF_JIT 1\n#include <cstdint>\n#include <type_traits>\n";
@@ -414,10 +415,10 @@ std::string build_bpf_source(const bf_user_model* um, int ppt, int nw, int kind 
        "struct SView { float* p; long long sB, sK, sT, sE; };\n"
        "struct OutViews { SView w, m, P, pm, pP, ll; SView cm, cP; };\n"
        "struct CarryView { const float* w_in; const float* m_in; const float* P_in; float* w_out; float* m_out; float* P_out; }; }\n";
-  if (kind == JIT_AGSF_EKF) s += "#define BF_AGSF_USER_EKF_NODES 1\n";
+  if (kind == JIT_AGSF_EKF || kind == JIT_GSF_REGS) s += "#define BF_USER_EKF_NODES 1\n";
   s += kSamplingSourceA;
   s += kSamplingUserMath;
-  if (kind == JIT_AGSF_EKF) {  // the Jacobians of the extended-Kalman nodes: dual numbers over the same float functions
+  if (kind == JIT_AGSF_EKF || kind == JIT_GSF_REGS) {  // the Jacobians of the extended-Kalman nodes: dual numbers over the same float functions
     s += kDualCore;
     s += kDualMath;
   }
@@ -434,12 +435,20 @@ std::string build_bpf_source(const bf_user_model* um, int ppt, int nw, int kind 
     s += "namespace bf { struct UView { const float* p; long long sB, sT; }; }\n";
     s += kUgsfSource;
     s += kAgsfSource;
-    const std::string nodes = kind == JIT_AGSF_UKF ? "bf::UkfNodes<BF_N, BF_DQ, BF_M, BF_DR, " + spec + ">" : "bf::UserEkfNodes<BF_N, BF_DQ, BF_M, BF_DR>";
+    const std::string nodes = kind == JIT_AGSF_UKF ? "bf::UkfNodes<BF_N, BF_DQ, BF_M, BF_DR, " + spec + ">" : "bf::UserEkfNodes<BF_N, BF_DQ, BF_M, BF_DR, " + spec + ">";
     s += "extern \"C\" __global__ void __launch_bounds__(" + std::to_string(nw == 1 ? 256 : 64 * nw) + ") bf_user_agsf(const bf::UkfModel<BF_N, BF_DQ, BF_M, BF_DR>* "
          "__restrict__ mdlp, bf::CView y, bf::UView uin, bf::CarryView carry, bf::AgsfOut out, long long B, long long T, int N0, int N1, int N2, int MP, "
          "float a0, float a1, uint32_t key0, uint32_t key1, int variant, int carry_records, const float* __restrict__ tvq, const float* __restrict__ tvr) {\n"
          "  bf::agsf_scan_body<BF_N, BF_M, " + nodes + ", " + std::to_string(nw) + ">(mdlp, y, uin, carry, out, B, T, N0, N1, N2, MP, a0, a1, key0, key1, "
          "variant, carry_records, tvq, tvr);\n}\n";
+    return s;
+  }
+  if (kind == JIT_GSF_REGS) {   // the Gaussian-sum scan with extended-Kalman operations, one lane per (trajectory, component)
+    s += kUgsfSource;
+    s += "extern \"C\" __global__ void __launch_bounds__(256) bf_user_gsf_regs(const bf::UkfModel<BF_N, BF_DQ, BF_M, BF_DR>* __restrict__ mdlp, bf::CView y, "
+         "const float* __restrict__ uptr, long long u_sB, long long u_sT, bf::CarryView carry, bf::OutViews out, long long B, long long T, int K, int KP, "
+         "const float* __restrict__ tvq, const float* __restrict__ tvr) {\n  bf::ugsf_scan_body<BF_N, BF_DQ, BF_M, BF_DR, " + spec +
+         ", bf::UserEkfNodes<BF_N, BF_DQ, BF_M, BF_DR, " + spec + ">>(mdlp, y, uptr, u_sB, u_sT, carry, out, B, T, K, KP, tvq, tvr);\n}\n";
     return s;
   }
   if (kind == JIT_UGSF) {
@@ -615,6 +624,63 @@ int launch_ugsf_user_impl(const bf_model* p, const bf_ukf_params* up, const bf_c
   return BF_OK;
 }
 
+// bf_gsf_ekf_f32 with functions from source and small dimensions: the Gaussian-sum scan of inference.py:333-371 with one lane per
+// (trajectory, component), mean and covariance in registers, the Jacobians by dual numbers (ugsf_scan.hpp: UserEkfNodes) -- two
+// orders of magnitude faster than the run-time-dimension kernel the same handle also carries (state in LDS, any n), which remains
+// the path for n > 8, for a nonlinear registry function beside one from source, legacy flags, collapsed streams and K > 256.
+bool gsf_user_regs_eligible(const bf_model* p, int K, const bf_out_desc* out) {
+  const bf_user_model* um = p->user;
+  if (!um || um->has_lp || p->flags != 0) return false;
+  if (p->n > 8 || p->dq > 8 || p->m > 8 || p->dr > 8 || K > 256) return false;
+  if (out->coll_mean.ptr || out->coll_cov.ptr) return false;
+  if (!(um->has_dyn || p->dyn_id == DYN_LINEAR) || !(um->has_emi || p->emi_id == EMI_LINEAR)) return false;
+  return true;
+}
+
+int launch_gsf_user_regs_impl(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int K, const bf_carry* carry,
+                              const bf_out_desc* out, hipStream_t stream) {
+  bf_user_model* um = const_cast<bf_user_model*>(p->user);
+  int rc = check_user_model(um, p);
+  if (rc != BF_OK) return rc;
+  int dev = -1;
+  (void)hipGetDevice(&dev);
+  if (dev != um->device) return set_error(BF_EINVAL, "bf_model.user was loaded on device %d, the current device is %d", um->device, dev);
+  if ((p->Q_steps > 1 && p->Q_steps != T) || (p->R_steps > 1 && p->R_steps != T))
+    return set_error(BF_EINVAL, "time-varying covariances need one matrix per step (Q_steps / R_steps = T = %lld)", T);
+  int KP = 1;
+  while (KP < K) KP <<= 1;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!um->gsf_regs) {
+      hipModule_t mod = nullptr;
+      rc = build_function(build_bpf_source(um, 0, 0, JIT_GSF_REGS), "bf_user_gsf_regs", &mod, &um->gsf_regs);
+      if (rc != BF_OK) return rc;
+      um->extra_mods.push_back(mod);
+    }
+  }
+  std::vector<uint32_t> words(ukf_model_words(p->n, p->dq, p->m, p->dr), 0u);
+  std::vector<float> tvq, tvr;
+  const bf_ukf_params unit{1.f, 0.f, 0.f};  // (the extended-Kalman operations ignore the unscented constants)
+  rc = fill_ukf_model_view(p, &unit, ukf_model_view_flat(words.data(), p->n, p->dq, p->m, p->dr), (um->has_dyn ? 1 : 0) | (um->has_emi ? 2 : 0) | 4, &tvq,
+                           &tvr);
+  if (rc != BF_OK) return rc;
+  const void* dv = nullptr;
+  rc = device_constants(words.data(), sizeof(uint32_t) * words.size(), stream, &dv);
+  if (rc != BF_OK) return rc;
+  const float *d_tvq = nullptr, *d_tvr = nullptr;
+  if ((rc = upload_table(tvq, stream, &d_tvq)) != BF_OK || (rc = upload_table(tvr, stream, &d_tvr)) != BF_OK) return rc;
+  CView yv{y->ptr, y->sB, y->sT, y->sE};
+  CarryView cv{carry->w_in, carry->m_in, carry->P_in, carry->w_out, carry->m_out, carry->P_out};
+  OutViews ov{make_sview(out->weights), make_sview(out->means), make_sview(out->covs),
+              make_sview(out->pred_means), make_sview(out->pred_covs), make_sview(out->loglik)};
+  const float* uptr = (u && u->ptr) ? u->ptr : nullptr;
+  long long u_sB = u ? u->sB : 0, u_sT = u ? u->sT : 0;
+  void* args[] = {&dv, &yv, &uptr, &u_sB, &u_sT, &cv, &ov, &B, &T, &K, &KP, &d_tvq, &d_tvr};
+  const int tpb = 256 / KP;
+  BF_HIP_CHECK(hipModuleLaunchKernel(um->gsf_regs, (unsigned)((B + tpb - 1) / tpb), 1, 1, 256, 1, 1, 0, stream, args, nullptr));
+  return BF_OK;
+}
+
 // The augmented Gaussian-sum scan (agsf_scan.hpp: a lane per leaf of the [N0, N1, N2] tree) around the caller's functions.
 // up != NULL: unscented nodes (speedy_unscented_agsf / unscented_agsf, inference.py:966-1156 / 813-965), either function may
 // also come from the registry.  up == NULL: extended-Kalman nodes (inference.py:621-812 / 458-620 / 1157-1300) with the
@@ -626,8 +692,9 @@ int launch_agsf_user_impl(const bf_model* p, const bf_ukf_params* up, const bf_c
   int rc = check_user_model(um, p);
   if (rc != BF_OK) return rc;
   if (um->has_lp) return set_error(BF_EINVAL, "a log-density from source belongs to the particle filter, not to the augmented filter");
-  if (!up && !(um->has_dyn && um->has_emi))
-    return set_error(BF_EUNSUPPORTED, "augmented filter with extended-Kalman nodes: give BOTH functions as source (or both from the registry)");
+  if (!up && !((um->has_dyn || p->dyn_id == DYN_LINEAR) && (um->has_emi || p->emi_id == EMI_LINEAR)))
+    return set_error(BF_EUNSUPPORTED, "augmented filter with extended-Kalman nodes: give BOTH functions as source (beside a function from source "
+                                      "only the registry's linear one can stand: its Jacobian needs no differentiation)");
   if (p->n > 8 || p->dq > 8 || p->m > 8 || p->dr > 8)
     return set_error(BF_EUNSUPPORTED, "augmented filter with functions from source: dimensions up to 8 (a leaf lives in registers)");
   if (p->flags != 0) return set_error(BF_EUNSUPPORTED, "legacy-class flags do not apply to the augmented filter");

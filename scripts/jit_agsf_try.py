@@ -23,14 +23,26 @@ struct SView { float* p; long long sB, sK, sT, sE; };
 struct OutViews { SView w, m, P, pm, pP, ll; SView cm, cP; };
 struct CarryView { const float* w_in; const float* m_in; const float* P_in; float* w_out; float* m_out; float* P_out; }; }
 """
-s += ("#define BF_AGSF_USER_EKF_NODES 1\n" if kind == "ekf" else "") + text("kf_math.hpp") + text("bf_canon_math.hpp") + consts["kSamplingUserMath"]
-if kind == "ekf":
+s += ("#define BF_USER_EKF_NODES 1\n" if kind in ("ekf", "gsf") else "") + text("kf_math.hpp") + text("bf_canon_math.hpp") + consts["kSamplingUserMath"]
+if kind in ("ekf", "gsf"):
     s += consts["kDualCore"] + consts["kDualMath"]
 s += dyn + emi + "}  // namespace bfu\n"
 for h in ("scan_common.hpp", "bf_rng.hpp", "models.hpp", "ssm_device.hpp", "bpf_scan.hpp"):
     s += text(h)
 s += "namespace bf { struct UView { const float* p; long long sB, sT; }; }\n" + text("ugsf_scan.hpp") + text("agsf_geom.hpp") + text("agsf_scan.hpp")
-nodes = "bf::UkfNodes<BF_N, BF_DQ, BF_M, BF_DR, bf::SpecUser<true, true, false>>" if kind == "ukf" else "bf::UserEkfNodes<BF_N, BF_DQ, BF_M, BF_DR>"
+nodes = "bf::UkfNodes<BF_N, BF_DQ, BF_M, BF_DR, bf::SpecUser<true, true, false>>" if kind == "ukf" else "bf::UserEkfNodes<BF_N, BF_DQ, BF_M, BF_DR, bf::SpecUser<true, true, false>>"
+if kind == "gsf":
+    s += """extern "C" __global__ void __launch_bounds__(256) bf_user_gsf_regs(const bf::UkfModel<BF_N, BF_DQ, BF_M, BF_DR>* __restrict__ mdlp, bf::CView y,
+  const float* __restrict__ uptr, long long u_sB, long long u_sT, bf::CarryView carry, bf::OutViews out, long long B, long long T, int K, int KP,
+  const float* __restrict__ tvq, const float* __restrict__ tvr) {
+  bf::ugsf_scan_body<BF_N, BF_DQ, BF_M, BF_DR, bf::SpecUser<true, true, false>, %s>(mdlp, y, uptr, u_sB, u_sT, carry, out, B, T, K, KP, tvq, tvr);
+}
+""" % nodes
+    rc, log = compile_src(s)
+    print("rc", rc)
+    errs = [l for l in log.splitlines() if "error" in l]
+    print("\n".join(errs[:25]) if errs else log[:1500])
+    sys.exit(0)
 s += """extern "C" __global__ void __launch_bounds__(%d) bf_user_agsf(const bf::UkfModel<BF_N, BF_DQ, BF_M, BF_DR>* __restrict__ mdlp, bf::CView y, bf::UView uin,
   bf::CarryView carry, bf::AgsfOut out, long long B, long long T, int N0, int N1, int N2, int MP, float a0, float a1, uint32_t key0, uint32_t key1, int variant,
   int carry_records, const float* __restrict__ tvq, const float* __restrict__ tvr) {

@@ -106,7 +106,10 @@ def test_growth_source_twin_matches_registry():
     # the values agree bit for bit on the first step (same kernel, same prior, same expression) ...
     with _forced_generic():
         ag = bfa.gaussian_sum_filter(reg, ys, K, 1, u, initial_means=im)
-    assert np.array_equal(_bits(ag.predicted_means[:, 0]), _bits(b.predicted_means[:, 0]))
+        bg = bfa.gaussian_sum_filter(usr, ys, K, 1, u, initial_means=im)   # (by default a source model of this size runs in registers)
+    assert np.array_equal(_bits(ag.predicted_means[:, 0]), _bits(bg.predicted_means[:, 0]))
+    for k in FIELDS:
+        assert cm.rel_err(getattr(bg, k).cpu().numpy(), getattr(b, k).cpu().numpy()) < 5e-4, k
     # ... and the runs to the conditioning of this model: |f'| reaches 25 and the posterior is bimodal, so the last-bit
     # difference between the two derivative expressions grows over 60 steps
     for k in FIELDS:
@@ -208,9 +211,11 @@ def test_user_model_errors_and_cache():
     for _ in range(20):                                               # compiled once: later calls find the module
         bfa.gaussian_sum_filter(base._replace(dynamics_function=nl.user_dynamics(GROWTH_SRC, 1)), ys, 1, initial_means=np.zeros((1, 1), F32))
     assert time.perf_counter() - t0 < 2.0
-    # the augmented kernels take registry functions only
-    with pytest.raises(_lib.BayesFiltError):
-        bfa.speedy_augmented_gaussian_sum_filter(base._replace(dynamics_function=f), ys, (2, 2, 2), initial_means=np.zeros((2, 1), F32))
+    # the augmented filter's extended-Kalman nodes: beside a function from source only the registry's LINEAR one can stand
+    bfa.speedy_augmented_gaussian_sum_filter(base._replace(dynamics_function=f), ys, (2, 2, 2), initial_means=np.zeros((2, 1), F32))
+    with pytest.raises(_lib.BayesFiltError, match="BOTH functions"):
+        bfa.speedy_augmented_gaussian_sum_filter(base._replace(dynamics_function=f, emission_function=nl.quadratic(1, 0.05)), ys, (2, 2, 2),
+                                                 initial_means=np.zeros((2, 1), F32))
 
 
 LINEAR_SRC = """
