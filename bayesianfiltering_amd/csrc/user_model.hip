@@ -40,6 +40,7 @@ struct bf_user_model {
   std::map<int, hipFunction_t> bpf;       // key = PPT * 100 + NW
   hipFunction_t ugsf = nullptr;           // the unscented Gaussian-sum scan, built on first use
   hipFunction_t gsf_regs = nullptr;       // the Gaussian-sum scan with the state in registers (n <= 8), built on first use
+  hipFunction_t sample = nullptr;         // NonlinearSSM.sample, built on first use
   std::map<int, hipFunction_t> agsf;      // the augmented Gaussian-sum scan; key = kind * 100 + waves per trajectory
   std::vector<hipModule_t> extra_mods;
 };
@@ -50,6 +51,7 @@ extern const char* const kGenericDeviceSource;  // generic_device.hpp, embedded 
 extern const char* const kSamplingSourceA;      // kf_math.hpp + bf_canon_math.hpp
 extern const char* const kSamplingSourceB;
 extern const char* const kAgsfSource;           // agsf_scan.hpp
+extern const char* const kSampleSource;         // sample_ssm.hpp
 extern const char* const kUgsfSource;           // ugsf_scan.hpp      // scan_common / bf_rng / models / ssm_device / bpf_scan
 
 namespace {
@@ -401,7 +403,7 @@ __device__ inline float tanh(float x) { return ::tanhf(x); }
 __device__ inline float pow(float x, float p) { return ::powf(x, p); }
 )BFSRC";
 
-enum { JIT_BPF = 0, JIT_UGSF = 1, JIT_AGSF_UKF = 2, JIT_AGSF_EKF = 3, JIT_GSF_REGS = 4 };
+enum { JIT_BPF = 0, JIT_UGSF = 1, JIT_AGSF_UKF = 2, JIT_AGSF_EKF = 3, JIT_GSF_REGS = 4, JIT_SAMPLE = 5 };
 
 std::string build_bpf_source(const bf_user_model* um, int ppt, int nw, int kind = JIT_BPF, const char* spec_override = nullptr) {
   std::string s = "#define BF_JIT 1\n#include <cstdint>\n#include <type_traits>\n";
@@ -441,6 +443,14 @@ std::string build_bpf_source(const bf_user_model* um, int ppt, int nw, int kind 
          "float a0, float a1, uint32_t key0, uint32_t key1, int variant, int carry_records, const float* __restrict__ tvq, const float* __restrict__ tvr) {\n"
          "  bf::agsf_scan_body<BF_N, BF_M, " + nodes + ", " + std::to_string(nw) + ">(mdlp, y, uin, carry, out, B, T, N0, N1, N2, MP, a0, a1, key0, key1, "
          "variant, carry_records, tvq, tvr);\n}\n";
+    return s;
+  }
+  if (kind == JIT_SAMPLE) {   // NonlinearSSM.sample with the caller's functions (sample_ssm.hpp), a lane per trajectory
+    s += kSampleSource;
+    s += "extern \"C\" __global__ void __launch_bounds__(64) bf_user_sample(const bf::BpfModel<BF_N, BF_DQ, BF_M>* __restrict__ mdlp, "
+         "const bf::EmissionNoise<BF_M>* __restrict__ enp, const uint32_t* __restrict__ keys, const float* __restrict__ uptr, long long u_sB, long long u_sT, "
+         "float* __restrict__ states, float* __restrict__ emis, long long B, long long T) {\n  bf::sample_ssm_body<BF_N, BF_DQ, BF_M, " + spec +
+         ">(mdlp, enp, keys, uptr, u_sB, u_sT, states, emis, B, T);\n}\n";
     return s;
   }
   if (kind == JIT_GSF_REGS) {   // the Gaussian-sum scan with extended-Kalman operations, one lane per (trajectory, component)
@@ -621,6 +631,61 @@ int launch_ugsf_user_impl(const bf_model* p, const bf_ukf_params* up, const bf_c
   void* args[] = {&dv, &yv, &uptr, &u_sB, &u_sT, &cv, &ov, &B, &T, &K, &KP, &d_tvsq, &d_tvsr};
   const int tpb = 256 / KP;
   BF_HIP_CHECK(hipModuleLaunchKernel(um->ugsf, (unsigned)((B + tpb - 1) / tpb), 1, 1, 256, 1, 1, 0, stream, args, nullptr));
+  return BF_OK;
+}
+
+// NonlinearSSM.sample (gaussfiltax/models.py:240-289) with the caller's f(x, q, u) / h(x, r, u): sample_ssm.hpp compiled around them
+// (a lane per trajectory, Threefry draws in JAX's layout -- the keys a reference run would consume)
+int launch_sample_user_impl(const bf_bpf_model* bp, const uint32_t* d_keys, const bf_cstream* u, long long B, long long T, float* d_states,
+                            float* d_emis, hipStream_t stream) {
+  const bf_model* p = &bp->ssm;
+  bf_user_model* um = const_cast<bf_user_model*>(p->user);
+  int rc = check_user_model(um, p);
+  if (rc != BF_OK) return rc;
+  if (p->dr != p->m) return set_error(BF_EUNSUPPORTED, "sample_ssm: emission noise dimension must equal the emission dimension");
+  if (p->n > 32 || p->dq > 32 || p->m > 32) return set_error(BF_EUNSUPPORTED, "sample_ssm with functions from source: dimensions up to 32 (a trajectory's state lives in registers)");
+  int dev = -1;
+  (void)hipGetDevice(&dev);
+  if (dev != um->device) return set_error(BF_EINVAL, "bf_model.user was loaded on device %d, the current device is %d", um->device, dev);
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!um->sample) {
+      hipModule_t mod = nullptr;
+      rc = build_function(build_bpf_source(um, 0, 0, JIT_SAMPLE), "bf_user_sample", &mod, &um->sample);
+      if (rc != BF_OK) return rc;
+      um->extra_mods.push_back(mod);
+    }
+  }
+  const int N = p->n, DQ = p->dq, M = p->m;
+  // [BpfModel<N, DQ, M> words][EmissionNoise<M>: 4 ints, Dm (M x M), LRn (M x M), r0 (M)] in one constant block
+  const size_t mw = bpf_model_words(N, DQ, M), ew = 4 + 2 * (size_t)M * M + M;
+  std::vector<uint32_t> words(mw + ew, 0u);
+  bf_bpf_model tmp = *bp;
+  tmp.lp_cov = p->R;      // chol(R) through the particle filter's model fill: the emission-noise covariance stands in for the log-density's
+  tmp.r_eval = nullptr;
+  const BpfModelView view = bpf_model_view_flat(words.data(), N, DQ, M);
+  rc = fill_bpf_model_view(&tmp, view, (um->has_dyn ? 1 : 0) | (um->has_emi ? 2 : 0), nullptr, 0);
+  if (rc != BF_OK) return rc;
+  int* ei = reinterpret_cast<int*>(words.data() + mw);
+  float* ef = reinterpret_cast<float*>(words.data() + mw + 4);
+  ei[0] = 1;                                            // d_identity
+  ei[1] = (!um->has_emi && p->emi_id == EMI_STOCH_VOL) ? 1 : 0;
+  if (!um->has_emi && p->emi_id == EMI_LINEAR) {
+    ei[0] = 0;
+    for (int i = 0; i < M * M; ++i) ef[i] = p->emi_theta[M * N + i];
+  }
+  for (int i = 0; i < M * M; ++i) ef[M * M + i] = view.LR[i];
+  for (int i = 0; i < M; ++i) ef[2 * M * M + i] = p->r0 ? p->r0[i] : 0.f;
+  if (ei[1]) return set_error(BF_EUNSUPPORTED, "sample_ssm: the stochastic-volatility emission beside a dynamics function from source is not built; give h as source too");
+  const void* dv = nullptr;
+  rc = device_constants(words.data(), sizeof(uint32_t) * words.size(), stream, &dv);
+  if (rc != BF_OK) return rc;
+  const void* d_mdl = dv;
+  const void* d_en = static_cast<const uint32_t*>(dv) + mw;
+  const float* uptr = (u && u->ptr) ? u->ptr : nullptr;
+  long long u_sB = u ? u->sB : 0, u_sT = u ? u->sT : 0;
+  void* args[] = {&d_mdl, &d_en, &d_keys, &uptr, &u_sB, &u_sT, &d_states, &d_emis, &B, &T};
+  BF_HIP_CHECK(hipModuleLaunchKernel(um->sample, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, stream, args, nullptr));
   return BF_OK;
 }
 
