@@ -7,6 +7,8 @@ int launch_agsf_user_impl(const bf_model* p, const bf_ukf_params* up, const bf_c
                           const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry, const bf_out_desc* out,
                           int* d_leaf_idx, int variant, hipStream_t stream);  // user_model.hip
 
+const bf_user_model* registry_jit_handle(const bf_model* p, bool hw_arith);   // user_model.hip
+
 int launch_agsf_ekf(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, const int32_t nc[3],
                     const uint32_t key[2], const float opt[2], const bf_carry* carry, const bf_out_desc* out, int* d_leaf_idx,
                     int variant, hipStream_t stream) {
@@ -22,6 +24,14 @@ int launch_agsf_ekf(const bf_model* p, const bf_cstream* y, const bf_cstream* u,
   BF_CASE(4, 2);
   BF_CASE(8, 4);
 #undef BF_CASE
+  // no compiled instance for these dimensions: a linear model runs on the kernel compiled now (its Jacobians are its matrices;
+  // the registry's nonlinear functions have their analytic Jacobians in the compiled instances only)
+  if (p->dyn_id == DYN_LINEAR && p->emi_id == EMI_LINEAR) {
+    bf_model jit = *p;
+    jit.user = registry_jit_handle(p, false);
+    if (!jit.user) return set_error(BF_ENOGPU, "no current device");
+    return launch_agsf_user_impl(&jit, nullptr, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, variant, stream);
+  }
   return set_error(BF_EUNSUPPORTED, "augmented Gaussian-sum filter: (n=%d, m=%d) is not compiled in", p->n, p->m);
 }
 

@@ -7,6 +7,8 @@ int launch_agsf_user_impl(const bf_model* p, const bf_ukf_params* up, const bf_c
                           const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry, const bf_out_desc* out,
                           int* d_leaf_idx, int variant, hipStream_t stream);  // user_model.hip
 
+const bf_user_model* registry_jit_handle(const bf_model* p, bool hw_arith);   // user_model.hip
+
 int launch_agsf_ukf(const bf_model* p, const bf_ukf_params* up, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
                     const int32_t nc[3], const uint32_t key[2], const float opt[2], const bf_carry* carry, const bf_out_desc* out,
                     int* d_leaf_idx, int variant, hipStream_t stream) {
@@ -20,8 +22,11 @@ int launch_agsf_ukf(const bf_model* p, const bf_ukf_params* up, const bf_cstream
   BF_CASE(4, 2, 2, 2);
   BF_CASE(4, 4, 2, 2);
 #undef BF_CASE
-  return set_error(BF_EUNSUPPORTED, "unscented augmented filter: (n=%d, dq=%d, m=%d, dr=%d) is not compiled in", p->n, p->dq, p->m,
-                   p->dr);
+  // no compiled instance for these dimensions: the same kernel, compiled now (needs hiprtc; dimensions up to 8)
+  bf_model jit = *p;
+  jit.user = registry_jit_handle(p, false);
+  if (!jit.user) return set_error(BF_ENOGPU, "no current device");
+  return launch_agsf_user_impl(&jit, up, y, u, B, T, nc, key, opt, carry, out, d_leaf_idx, variant, stream);
 }
 
 }  // namespace bf

@@ -51,6 +51,7 @@ BF_DECL(launch_bpf_group_c);
 int launch_bpf_user_impl(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP, float ess,
                          int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o, hipStream_t stream);
 
+const bf_user_model* registry_jit_handle(const bf_model* p, bool hw_arith);   // user_model.hip
 int launch_bpf_hw_arith_impl(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP, float ess,
                              int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o, hipStream_t stream);
 
@@ -74,8 +75,11 @@ int launch_bpf(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u,
   if (matched) return rc;
   rc = launch_bpf_group_c(bp, y, u, B, T, NP, ess, resampler, key, cr, out, stream, &matched);
   if (matched) return rc;
-  const bf_model* p = &bp->ssm;
-  return set_error(BF_EUNSUPPORTED, "bootstrap particle filter: (n=%d, dq=%d, m=%d) is not compiled in", p->n, p->dq, p->m);
+  // no compiled instance for these dimensions: the same kernel, compiled now (needs hiprtc; in-register particle counts)
+  bf_bpf_model jit = *bp;
+  jit.ssm.user = registry_jit_handle(&bp->ssm, false);
+  if (!jit.ssm.user) return set_error(BF_ENOGPU, "no current device");
+  return launch_bpf_user_impl(&jit, y, u, B, T, NP, ess, resampler, key, carry, o, stream);
 }
 
 }  // namespace bf

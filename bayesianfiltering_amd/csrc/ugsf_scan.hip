@@ -7,6 +7,8 @@ namespace bf {
 int launch_ugsf_user_impl(const bf_model* p, const bf_ukf_params* up, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
                           int K, const bf_carry* carry, const bf_out_desc* out, hipStream_t stream);
 
+const bf_user_model* registry_jit_handle(const bf_model* p, bool hw_arith);   // user_model.hip
+
 int launch_ugsf_ukf(const bf_model* p, const bf_ukf_params* up, const bf_cstream* y, const bf_cstream* u, long long B,
                     long long T, int K, const bf_carry* carry, const bf_out_desc* out, hipStream_t stream) {
   if (p->user)   // functions from the caller's source: the kernel compiled at run time for this model (user_model.hip)
@@ -26,8 +28,11 @@ int launch_ugsf_ukf(const bf_model* p, const bf_ukf_params* up, const bf_cstream
   BF_CASE(4, 4, 2, 2);
   BF_CASE(8, 8, 4, 4);   // Lorenz-96 with the even-state emission (nonlinearities.py:37-50)
 #undef BF_CASE
-  return set_error(BF_EUNSUPPORTED, "unscented Gaussian-sum filter: (n=%d, dq=%d, m=%d, dr=%d) is not compiled in", p->n, p->dq,
-                   p->m, p->dr);
+  // no compiled instance for these dimensions: the same kernel, compiled now (needs hiprtc; dimensions up to 8)
+  bf_model jit = *p;
+  jit.user = registry_jit_handle(p, false);
+  if (!jit.user) return set_error(BF_ENOGPU, "no current device");
+  return launch_ugsf_user_impl(&jit, up, y, u, B, T, K, carry, out, stream);
 }
 
 }  // namespace bf

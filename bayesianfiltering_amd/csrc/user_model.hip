@@ -486,28 +486,33 @@ int launch_bpf_user_impl(const bf_bpf_model* bp, const bf_cstream* y, const bf_c
   return launch_bpf_jit(const_cast<bf_user_model*>(bp->ssm.user), bp, y, u, B, T, NP, ess, resampler, key, carry, o, stream);
 }
 
-// bf_set_option "bpf_arith" = 1: the registry model's kernel rebuilt with v_log_f32 / v_exp_f32 in place of the defined
-// arithmetic (BF_BPF_HW_ARITH in bf_canon_math.hpp / bf_rng.hpp), on an internal handle per (dimensions, device)
+// An internal handle without sources, per (dimensions, device, arithmetic): the sampling kernels compiled at run time for a
+// REGISTRY model -- bf_set_option "bpf_arith" = 1 (v_log_f32 / v_exp_f32 in place of the defined arithmetic: BF_BPF_HW_ARITH in
+// bf_canon_math.hpp / bf_rng.hpp), and every (n, dq, m, dr) the compiled instance tables of the particle / unscented / augmented
+// kernels do not hold (bpf_scan.hip, ugsf_scan.hip, agsf_ukf.hip, agsf_scan.hip put it into a copy of the model and take the
+// from-source path: "not compiled in" becomes "compiled now").
+const bf_user_model* registry_jit_handle(const bf_model* p, bool hw_arith) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  const std::string mem_key = std::string(hw_arith ? "hw_arith:" : "registry:") + std::to_string(p->n) + "," + std::to_string(p->dq) + "," +
+                              std::to_string(p->m) + "," + std::to_string(p->dr) + "@" + std::to_string(dev);
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_models.find(mem_key);
+  if (it != g_models.end()) return it->second;
+  bf_user_model* um = new bf_user_model;
+  um->n = p->n; um->dq = p->dq; um->m = p->m; um->dr = p->dr; um->device = dev; um->hw_arith = hw_arith;
+  g_models[mem_key] = um;
+  return um;
+}
+
 int launch_bpf_hw_arith_impl(const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP, float ess,
                              int resampler, const uint32_t key[2], const bf_bpf_carry* carry, const bf_bpf_out* o, hipStream_t stream) {
-  const bf_model* p = &bp->ssm;
-  int dev = -1;
-  BF_HIP_CHECK(hipGetDevice(&dev));
-  const std::string mem_key = "hw_arith:" + std::to_string(p->n) + "," + std::to_string(p->dq) + "," + std::to_string(p->m) + "," + std::to_string(p->dr) +
-                              "@" + std::to_string(dev);
-  bf_user_model* um = nullptr;
-  {
-    std::lock_guard<std::mutex> lock(g_mu);
-    auto it = g_models.find(mem_key);
-    if (it != g_models.end()) {
-      um = it->second;
-    } else {
-      um = new bf_user_model;
-      um->n = p->n; um->dq = p->dq; um->m = p->m; um->dr = p->dr; um->device = dev; um->hw_arith = true;
-      g_models[mem_key] = um;
-    }
-  }
-  return launch_bpf_jit(um, bp, y, u, B, T, NP, ess, resampler, key, carry, o, stream);
+  const bf_user_model* um = registry_jit_handle(&bp->ssm, true);
+  if (!um) return set_error(BF_ENOGPU, "no current device");
+  return launch_bpf_jit(const_cast<bf_user_model*>(um), bp, y, u, B, T, NP, ess, resampler, key, carry, o, stream);
 }
 
 static int launch_bpf_jit(bf_user_model* um, const bf_bpf_model* bp, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int NP,

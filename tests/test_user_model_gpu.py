@@ -603,3 +603,57 @@ def test_sampling_with_functions_from_source():
     for b in range(3):
         xr, yr = go.sample_ssm(go.ParamsNLSSM(m0, P0, fo, q0, Qp, ho, r0p, Rp), keys[b], 40)
         assert cm.rel_err(xs[b].cpu().numpy(), xr) < 2e-5 and cm.rel_err(ys[b].cpu().numpy(), yr) < 2e-5
+
+
+def test_registry_models_at_dimensions_without_a_compiled_instance():
+    """The particle / unscented / augmented kernels hold compiled instances for the dimensions of the reference's experiments; any
+    other (n, dq, m, dr) used to end in BF_EUNSUPPORTED ("not compiled in").  The same kernels are now compiled at run time for
+    such a registry model (the from-source machinery on an internal handle): Lorenz-96 with n = 10 / 5 in the particle and
+    unscented filters, a 5-state linear model in the unscented and both augmented filters -- against the oracle."""
+    import bayesianfiltering_amd as bfa
+    nl = bfa.nonlinearities
+    # ---- particle filter: Lorenz-96 n = 10, m = 5 (no (10, 10, 5) instance)
+    n, m, N, T = 10, 5, 256, 10
+    R = 0.5 * np.eye(m, dtype=F32)
+    g = nl.pick_even(n)
+    pp = bfa.ParamsBPF(8 * np.ones(n, F32), np.eye(n, dtype=F32), nl.lorenz96(n), np.zeros(n, F32), 1e-2 * np.eye(n, dtype=F32), g,
+                       np.zeros(m, F32), R, nl.gaussian_log_prob(g, R))
+    po = go.ParamsBPF(*pp[:2], om.Lorenz96(n), pp[3], pp[4], om.PickEven(n), pp[6], pp[7], go.GaussianEmissionLogProb(om.PickEven(n), R))
+    ys = np.stack([go.sample_ssm(go.ParamsNLSSM(*po[:8]), otf.PRNGKey(60 + b), T)[1] for b in range(2)])
+    key = np.array([0, 3], np.uint32)
+    out = bfa.bootstrap_particle_filter(pp, ys, N, key, output="both", return_ancestors=True)
+    for b in range(2):
+        ref, dbg = go.bootstrap_particle_filter(po, ys[b], N, key=key, debug=True, arith="canonical")
+        assert np.array_equal(out["ancestors"][b].cpu().numpy().T, dbg["ancestors"]) and dbg["resampled"].any()
+        assert np.array_equal(np.ascontiguousarray(out["weights"][b].cpu().numpy(), F32).view(np.uint32), ref["weights"].view(np.uint32))
+        assert np.array_equal(np.ascontiguousarray(out["particles"][b].cpu().numpy(), F32).view(np.uint32), ref["particles"].view(np.uint32))
+    # ---- unscented Gaussian-sum filter: Lorenz-96 n = 6, m = 3 (no (6, 6, 3, 3) instance)
+    n, m, K, T = 6, 3, 5, 15
+    pn = bfa.ParamsNLSSM(8 * np.ones(n, F32), np.eye(n, dtype=F32), nl.lorenz96(n), np.zeros(n, F32), 1e-2 * np.eye(n, dtype=F32), nl.pick_even(n),
+                         np.zeros(m, F32), 1e-1 * np.eye(m, dtype=F32))
+    on = go.ParamsNLSSM(*pn[:2], om.Lorenz96(n), pn[3], pn[4], om.PickEven(n), pn[6], pn[7])
+    ys = np.stack([go.sample_ssm(on, otf.PRNGKey(70 + b), T)[1] for b in range(2)])
+    im = (8 + np.random.default_rng(2).normal(size=(2, K, n))).astype(F32)
+    post = bfa.unscented_gaussian_sum_filter(pn, bfa.ParamsUKF(1, 0, 0), ys, K, 1, initial_means=im)
+    for b in range(2):
+        ref = go.unscented_gaussian_sum_filter(on, go.ParamsUKF(1, 0, 0), ys[b], K, initial_means=im[b])
+        for k in ("means", "covariances", "predicted_means"):
+            assert cm.rel_err(getattr(post, k)[b].cpu().numpy(), getattr(ref, k)) < 2e-5, k
+    # ---- a 5-state linear model in the unscented and the augmented filters
+    rng = np.random.default_rng(5)
+    n, m, T, nc = 5, 2, 12, (3, 2, 2)
+    A = (0.9 * np.eye(n) + 0.03 * rng.normal(size=(n, n))).astype(F32)
+    H = rng.normal(size=(m, n)).astype(F32)
+    pl = bfa.ParamsNLSSM(np.zeros(n, F32), np.eye(n, dtype=F32), nl.linear_dynamics(A), np.zeros(n, F32), 0.05 * np.eye(n, dtype=F32),
+                         nl.linear_emission(H), np.zeros(m, F32), 0.2 * np.eye(m, dtype=F32))
+    ol = go.ParamsNLSSM(*pl[:2], om.Linear(A), pl[3], pl[4], om.Linear(H), pl[6], pl[7])
+    ys = go.sample_ssm(ol, otf.PRNGKey(80), T)[1]
+    im = rng.normal(size=(nc[0], n)).astype(F32)
+    for fn_e, fn_o, extra in ((bfa.speedy_augmented_gaussian_sum_filter, go.speedy_augmented_gaussian_sum_filter, ()),
+                              (bfa.speedy_unscented_agsf, go.speedy_unscented_agsf, (1,))):
+        a_e = (pl,) + ((bfa.ParamsUKF(1, 0, 0),) if extra else ()) + (ys, nc)
+        a_o = (ol,) + ((go.ParamsUKF(1, 0, 0),) if extra else ()) + (ys, nc)
+        post, _ = fn_e(*a_e, initial_means=im)
+        ref, _ = fn_o(*a_o, initial_means=im)
+        for k in ("means", "covariances"):
+            assert cm.rel_err(getattr(post, k).cpu().numpy(), getattr(ref, k)) < 3e-5, (fn_e.__name__, k)
