@@ -88,21 +88,21 @@ __device__ __forceinline__ float chunk_total_bk(float v, float* red) {
 
 // one particle through the dynamics with its own noise draw (inference.py:1342-1345: q = q0 + chol(Q) z from the
 // particle's key), written back in place, and its emission log-density (:1348-1349)
-template <int N, int DQ, int M>
+template <int N, int DQ, int M, class SP = SpecRuntime>
 __device__ __forceinline__ float propagate_particle(const BpfModel<N, DQ, M>& mdl, U32x2 ki, float* xp, float u0, const float* yv) {
   float x[N], q[DQ], xn[N];
   BF_UNROLL for (int d = 0; d < N; ++d) x[d] = xp[d];
-  draw_dynamics_noise<N, DQ, M>(mdl, ki, q);
-  dyn_value<N, DQ, M>(mdl, x, q, u0, xn);
+  draw_dynamics_noise<N, DQ, M, SP>(mdl, ki, q);
+  dyn_value<N, DQ, M, SP>(mdl, x, q, u0, xn);       // (SP::user_dyn / user_emi / user_lp: the caller's functions from source)
   BF_UNROLL for (int d = 0; d < N; ++d) xp[d] = xn[d];
-  return emission_loglik<N, DQ, M>(mdl, xn, u0, yv);
+  return emission_loglik<N, DQ, M, SP>(mdl, xn, u0, yv);
 }
 
-template <int N, int DQ, int M>
-__global__ void __launch_bounds__(BIG_NT)
-bpf_big_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const float* __restrict__ uptr, long long u_sB, long long u_sT,
-               BpfCarry carry, BpfOut out, BigScratch sc, long long B, long long T, int NP, float ess_threshold, int resampler,
-               uint32_t key0, uint32_t key1) {
+template <int N, int DQ, int M, class SP = SpecRuntime>
+__device__ __forceinline__ void
+bpf_big_body(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const float* __restrict__ uptr, long long u_sB, long long u_sT,
+             BpfCarry carry, BpfOut out, BigScratch sc, long long B, long long T, int NP, float ess_threshold, int resampler,
+             uint32_t key0, uint32_t key1) {
   const BpfModel<N, DQ, M>& mdl = *mdlp;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -198,7 +198,7 @@ bpf_big_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const float
       float ll = -__builtin_inff();
       if (valid) {
         const U32x2 ki = threefry_split(k0, k1, (uint32_t)i + 1u, (uint32_t)NP + 1u);
-        ll = propagate_particle<N, DQ, M>(mdl, ki, xa + (long long)i * N, u0, yv);
+        ll = propagate_particle<N, DQ, M, SP>(mdl, ki, xa + (long long)i * N, u0, yv);
         gl[i] = ll;
       }
       const float cm = block_reduce(ll, nanmax);
@@ -344,6 +344,15 @@ bpf_big_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const float
 }
 
 template <int N, int DQ, int M>
+__global__ void __launch_bounds__(BIG_NT)
+bpf_big_kernel(const BpfModel<N, DQ, M>* __restrict__ mdlp, CView y, const float* __restrict__ uptr, long long u_sB, long long u_sT,
+               BpfCarry carry, BpfOut out, BigScratch sc, long long B, long long T, int NP, float ess_threshold, int resampler,
+               uint32_t key0, uint32_t key1) {
+  bpf_big_body<N, DQ, M, SpecRuntime>(mdlp, y, uptr, u_sB, u_sT, carry, out, sc, B, T, NP, ess_threshold, resampler, key0, key1);
+}
+
+#ifndef BF_JIT
+template <int N, int DQ, int M>
 static inline int launch_bpf_big_dims(const BpfModel<N, DQ, M>* d_mdl, const bf_cstream* y, const bf_cstream* u, long long B, long long T,
                                  int NP, float ess, int resampler, const uint32_t key[2], const BpfCarry& cr, const BpfOut& out,
                                  hipStream_t stream) {
@@ -370,5 +379,6 @@ static inline int launch_bpf_big_dims(const BpfModel<N, DQ, M>* d_mdl, const bf_
   BF_HIP_CHECK(fe);
   return BF_OK;
 }
+#endif  // BF_JIT
 
 }  // namespace bf

@@ -21,7 +21,7 @@
 #include <string>
 #include <vector>
 #include "bf_common.hpp"
-#include "bpf_scan.hpp"   // BpfArgs / BpfCarry / BpfOut, the run-time-dimension model fill
+#include "bpf_big.hpp"    // (brings bpf_scan.hpp) BpfArgs / BpfCarry / BpfOut / BigScratch, the run-time-dimension model fill
 #include "ugsf_scan.hpp"  // UkfModelView, fill_ukf_model_view
 #include "agsf_geom.hpp"  // AgsfOut, agsf_lds_bytes
 
@@ -41,6 +41,7 @@ struct bf_user_model {
   hipFunction_t ugsf = nullptr;           // the unscented Gaussian-sum scan, built on first use
   hipFunction_t gsf_regs = nullptr;       // the Gaussian-sum scan with the state in registers (n <= 8), built on first use
   hipFunction_t sample = nullptr;         // NonlinearSSM.sample, built on first use
+  hipFunction_t bpf_big = nullptr;        // the particle filter with the particles in HBM, built on first use
   std::map<int, hipFunction_t> agsf;      // the augmented Gaussian-sum scan; key = kind * 100 + waves per trajectory
   std::vector<hipModule_t> extra_mods;
 };
@@ -52,6 +53,7 @@ extern const char* const kSamplingSourceA;      // kf_math.hpp + bf_canon_math.h
 extern const char* const kSamplingSourceB;
 extern const char* const kAgsfSource;           // agsf_scan.hpp
 extern const char* const kSampleSource;         // sample_ssm.hpp
+extern const char* const kBpfBigSource;         // bpf_big.hpp
 extern const char* const kUgsfSource;           // ugsf_scan.hpp      // scan_common / bf_rng / models / ssm_device / bpf_scan
 
 namespace {
@@ -403,7 +405,7 @@ __device__ inline float tanh(float x) { return ::tanhf(x); }
 __device__ inline float pow(float x, float p) { return ::powf(x, p); }
 )BFSRC";
 
-enum { JIT_BPF = 0, JIT_UGSF = 1, JIT_AGSF_UKF = 2, JIT_AGSF_EKF = 3, JIT_GSF_REGS = 4, JIT_SAMPLE = 5 };
+enum { JIT_BPF = 0, JIT_UGSF = 1, JIT_AGSF_UKF = 2, JIT_AGSF_EKF = 3, JIT_GSF_REGS = 4, JIT_SAMPLE = 5, JIT_BPF_BIG = 6 };
 
 std::string build_bpf_source(const bf_user_model* um, int ppt, int nw, int kind = JIT_BPF, const char* spec_override = nullptr) {
   std::string s = "#define BF_JIT 1\n#include <cstdint>\n#include <type_traits>\n";
@@ -443,6 +445,14 @@ std::string build_bpf_source(const bf_user_model* um, int ppt, int nw, int kind 
          "float a0, float a1, uint32_t key0, uint32_t key1, int variant, int carry_records, const float* __restrict__ tvq, const float* __restrict__ tvr) {\n"
          "  bf::agsf_scan_body<BF_N, BF_M, " + nodes + ", " + std::to_string(nw) + ">(mdlp, y, uin, carry, out, B, T, N0, N1, N2, MP, a0, a1, key0, key1, "
          "variant, carry_records, tvq, tvr);\n}\n";
+    return s;
+  }
+  if (kind == JIT_BPF_BIG) {   // the particle filter with the particles in HBM (bpf_big.hpp): up to 2^20 particles per trajectory
+    s += kBpfBigSource;
+    s += "extern \"C\" __global__ void __launch_bounds__(1024) bf_user_bpf_big(const bf::BpfModel<BF_N, BF_DQ, BF_M>* __restrict__ mdlp, bf::CView y, "
+         "const float* __restrict__ uptr, long long u_sB, long long u_sT, bf::BpfCarry carry, bf::BpfOut out, bf::BigScratch sc, long long B, long long T, "
+         "int NP, float ess_threshold, int resampler, uint32_t key0, uint32_t key1) {\n  bf::bpf_big_body<BF_N, BF_DQ, BF_M, " + spec +
+         ">(mdlp, y, uptr, u_sB, u_sT, carry, out, sc, B, T, NP, ess_threshold, resampler, key0, key1);\n}\n";
     return s;
   }
   if (kind == JIT_SAMPLE) {   // NonlinearSSM.sample with the caller's functions (sample_ssm.hpp), a lane per trajectory
@@ -535,7 +545,7 @@ static int launch_bpf_jit(bf_user_model* um, const bf_bpf_model* bp, const bf_cs
   else if (NP <= 512) { ppt = 1; nw = 8; }
   else if (NP <= 1024) { ppt = 1; nw = 16; }
   else if (NP <= 4096 && N <= 16) { ppt = 4; nw = 16; }
-  else return set_error(BF_EUNSUPPORTED, "particle filter compiled at run time (functions from source, or bpf_arith = 1): at most 4096 particles for state_dim <= 16, 1024 beyond");
+  else { ppt = 0; nw = 16; }   // beyond the register capacities: the particles live in HBM (bpf_big.hpp), up to 2^20 per trajectory
   // the model, word for word the BpfModel<N, DQ, M> of the kernel
   std::vector<uint32_t> words(bpf_model_words(N, p->dq, M), 0u);
   const int flags = (um->has_dyn ? 1 : 0) | (um->has_emi ? 2 : 0) | (um->has_lp ? 4 : 0);
@@ -550,6 +560,46 @@ static int launch_bpf_jit(bf_user_model* um, const bf_bpf_model* bp, const bf_cs
                           *view.lq_diag && *view.lr_diag && *view.h_pick;
     spec = l96_pick ? "bf::SpecFixed<bf::DYN_LORENZ96, bf::EMI_LINEAR, true, true, true, true>" : "bf::SpecRuntime";
     spec_id = l96_pick ? 2 : 1;
+  }
+  const void* dv = nullptr;
+  if (ppt == 0) {
+    if (NP > 1024 * 1024) return set_error(BF_EUNSUPPORTED, "bootstrap particle filter: %d particles exceed the capacity of %d per trajectory", NP, 1024 * 1024);
+    hipFunction_t big = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(g_mu);
+      if (!um->bpf_big) {
+        hipModule_t mod = nullptr;
+        rc = build_function(build_bpf_source(um, 0, 0, JIT_BPF_BIG, spec), "bf_user_bpf_big", &mod, &um->bpf_big);
+        if (rc != BF_OK) return rc;
+        um->extra_mods.push_back(mod);
+      }
+      big = um->bpf_big;
+    }
+    rc = device_constants(words.data(), sizeof(uint32_t) * words.size(), stream, &dv);
+    if (rc != BF_OK) return rc;
+    const size_t per = (size_t)B * NP;
+    float* buf = nullptr;
+    BF_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&buf), sizeof(float) * per * (2 * (size_t)N + 3) + sizeof(int) * per, stream));
+    BigScratch sc;
+    sc.xa = buf;
+    sc.xb = sc.xa + per * N;
+    sc.w = sc.xb + per * N;
+    sc.ll = sc.w + per;
+    sc.cdf = sc.ll + per;
+    sc.anc = reinterpret_cast<int*>(sc.cdf + per);
+    CView yv{y->ptr, y->sB, y->sT, y->sE};
+    const float* uptr = (u && u->ptr) ? u->ptr : nullptr;
+    long long u_sB = u ? u->sB : 0, u_sT = u ? u->sT : 0;
+    BpfCarry cr{carry ? carry->x_in : nullptr, carry ? carry->w_in : nullptr, carry ? carry->key_in : nullptr,
+                carry ? carry->x_out : nullptr, carry ? carry->w_out : nullptr, carry ? carry->key_out : nullptr};
+    BpfOut ov{o->weights, o->w_sB, o->w_sN, o->w_sT, o->particles, o->x_sB, o->x_sN, o->x_sT, o->ancestors, o->mean, o->ess, o->logz, o->resampled};
+    uint32_t k0 = key[0], k1 = key[1];
+    void* args[] = {&dv, &yv, &uptr, &u_sB, &u_sT, &cr, &ov, &sc, &B, &T, &NP, &ess, &resampler, &k0, &k1};
+    const hipError_t le = hipModuleLaunchKernel(big, (unsigned)B, 1, 1, 1024, 1, 1, 0, stream, args, nullptr);
+    const hipError_t fe = hipFreeAsync(buf, stream);
+    BF_HIP_CHECK(le);
+    BF_HIP_CHECK(fe);
+    return BF_OK;
   }
   hipFunction_t fn = nullptr;
   {
@@ -566,7 +616,6 @@ static int launch_bpf_jit(bf_user_model* um, const bf_bpf_model* bp, const bf_cs
       um->bpf[fkey] = fn;
     }
   }
-  const void* dv = nullptr;
   rc = device_constants(words.data(), sizeof(uint32_t) * words.size(), stream, &dv);
   if (rc != BF_OK) return rc;
   BpfArgs<1, 1, 1> a;   // (the argument struct does not depend on the dimensions)

@@ -365,7 +365,7 @@ def _bits_eq(a, b):
     return np.array_equal(np.ascontiguousarray(a.cpu().numpy(), F32).view(np.uint32), np.ascontiguousarray(b.cpu().numpy(), F32).view(np.uint32))
 
 
-@pytest.mark.parametrize("N", [100, 1000, 4096])
+@pytest.mark.parametrize("N", [100, 1000, 4096, 10000, 70000])
 def test_particle_filter_bot_source_twins_match_the_registry_bit_for_bit(N):
     import bayesianfiltering_amd as bfa
     nl = bfa.nonlinearities
@@ -392,6 +392,10 @@ def test_particle_filter_bot_source_twins_match_the_registry_bit_for_bit(N):
                              emission_distribution_log_prob=nl.gaussian_log_prob(g_usr, R, r0))):                  # both
         b_ = bfa.bootstrap_particle_filter(usr, ys, N, key, inputs, output="both", return_ancestors=True)
         for k in ("weights", "particles", "mean", "ess", "logz", "resampled"):
+            if k == "mean" and N > 4096:   # (beyond 4 096 particles the build from source keeps them in HBM -- the reference's 10^4 ... 5 10^5
+                # particle runs -- while the registry twin may still fit its registers: the summary's sum runs in another order)
+                assert cm.rel_err(b_[k].cpu().numpy(), a[k].cpu().numpy()) < 1e-6
+                continue
             assert _bits_eq(a[k], b_[k]), k
         assert np.array_equal(a["ancestors"].cpu().numpy(), b_["ancestors"].cpu().numpy())
 
