@@ -895,7 +895,18 @@ int bf_user_model_create_lp(const char* dynamics_src, const char* emission_src, 
   if (n <= 0 || dq <= 0 || m <= 0 || dr <= 0 || n > 64 || dq > 64 || m > 64 || dr > 64)
     return set_error(BF_EINVAL, "bf_user_model_create: dimensions must be in 1..64");
   const bool gsf = dynamics_src || emission_src;   // the Gaussian-sum scan is built now; the particle-filter kernels on first use
-  const std::string src = build_source(dynamics_src, emission_src, n, dq, m, dr) + (log_prob_src ? std::string("// lp: ") + log_prob_src : std::string());
+  // (the log-density belongs to the particle kernel, built on first use; here it only makes the handle's key unique: every
+  // line of it as a comment)
+  std::string lp_comment;
+  if (log_prob_src) {
+    lp_comment = "// lp: ";
+    for (const char* c = log_prob_src; *c; ++c) {
+      lp_comment += *c;
+      if (*c == '\n') lp_comment += "// ";
+    }
+    lp_comment += "\n";
+  }
+  const std::string src = build_source(dynamics_src, emission_src, n, dq, m, dr) + lp_comment;
   // the code object depends on the source, the target and the compiler: all three are in the key (the HIP runtime's version
   // stands for hiprtc's, which ships with it -- known without loading hiprtc on a cache hit)
   int rtver = 0;

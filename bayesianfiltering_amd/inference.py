@@ -239,8 +239,12 @@ class _Model:
     """Host-side build of bf_model from a ParamsNLSSM / ParamsBPF holding registry functions."""
 
     def __init__(self, params, log_prob_source=None):
-        f = require_device_function(params.dynamics_function, "dynamics", "params.dynamics_function")
-        h = require_device_function(params.emission_function, "emission", "params.emission_function")
+        # (a plain Python function of NumPy operations is recorded and compiled: its dimensions come from the parameters)
+        n0 = int(np.size(params.initial_mean))
+        dq0 = int(np.shape(params.dynamics_noise_covariance)[-1]) if np.ndim(params.dynamics_noise_covariance) >= 2 else 1
+        dr0 = int(np.shape(params.emission_noise_covariance)[-1]) if np.ndim(params.emission_noise_covariance) >= 2 else 1
+        f = require_device_function(params.dynamics_function, "dynamics", "params.dynamics_function", n0, dq0)
+        h = require_device_function(params.emission_function, "emission", "params.emission_function", n0, dr0)
         self.n, self.dq, self.m, self.dr = f.out_dim, f.noise_dim, h.out_dim, h.noise_dim
         if f.in_dim != self.n or h.in_dim != self.n:
             raise ValueError("dynamics / emission functions do not match the state dimension")
@@ -643,6 +647,17 @@ def bootstrap_particle_filter(params, emissions, num_particles: int, key=None, i
     if output not in ("full", "summary", "both"):
         raise ValueError("output must be 'full', 'summary' or 'both'")
     lp = params.emission_distribution_log_prob
+    if not isinstance(lp, (GaussianLogProb, UserLogProb)) and callable(lp):
+        # a plain Python function of NumPy operations: recorded and compiled (nonlinearities.trace_log_prob)
+        from .nonlinearities import trace_log_prob
+        from .trace import TraceError
+        n0 = int(np.size(params.initial_mean))
+        dr0 = int(np.shape(params.emission_noise_covariance)[-1]) if np.ndim(params.emission_noise_covariance) >= 2 else 1
+        h0 = require_device_function(params.emission_function, "emission", "params.emission_function", n0, dr0)
+        try:
+            lp = trace_log_prob(lp, n0, h0.out_dim)
+        except TraceError as e:
+            raise TypeError(f"params.emission_distribution_log_prob: {e}") from e
     if not isinstance(lp, (GaussianLogProb, UserLogProb)):
         raise TypeError("params.emission_distribution_log_prob must be a nonlinearities.GaussianLogProb (around a registry or "
                         "source emission function) or a nonlinearities.user_log_prob(source, ...): Python callables cannot run "

@@ -1,0 +1,130 @@
+"""bayesianfiltering_amd.trace: Python functions of NumPy operations recorded into the device-source templates.  CPU tests: the
+generated source is compiled with g++ for T = float (and for a minimal dual number) and compared with the Python function."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from bayesianfiltering_amd import trace
+
+F32 = np.float32
+DT, ACC = 0.5, 0.02
+
+
+def f_bot(x, q, u):
+    """docs/experiments/BOT_Experiment_script.py:31-40 with jax.numpy replaced by numpy."""
+    u0 = u[0]
+    FCV = np.array([[1, DT, 0, 0], [0, 1, 0, 0], [0, 0, 1, DT], [0, 0, 0, 1.0]])
+
+    def FCT(x, a):
+        om = 0.1 * a / np.sqrt(x[1] ** 2 + x[3] ** 2)
+        s, c = np.sin(DT * om), np.cos(DT * om)
+        return np.array([[1, s / om, 0, -(1 - c) / om], [0, c, 0, -s], [0, (1 - c) / om, 1, s / om], [0, s, 0, c]])
+    G = np.array([[0.5, 0], [1, 0], [0, 0.5], [0, 1.0]])
+    M = 0.5 * (u0 - 1) * (u0 - 2) * FCV - u0 * (u0 - 2) * FCT(x, ACC) + 0.5 * u0 * (u0 - 1) * FCT(x, -ACC)
+    return M @ x + G @ q
+
+
+def h_bot(x, r, u):
+    return np.array([np.arctan2(x[2], x[0]), np.sqrt(x[0] ** 2 + x[2] ** 2)]) + r
+
+
+def lp_laplace(x, y, u):
+    return -np.abs(y[0] - 0.05 * np.sum(x ** 2)) / 0.7 - np.log(2 * 0.7)
+
+
+HOST = """#include <cmath>
+#define __device__
+namespace bfu {
+struct Dual { float v, d; Dual() : v(0), d(0) {} Dual(float a) : v(a), d(0) {} Dual(float a, float b) : v(a), d(b) {} };
+inline Dual operator+(Dual a, Dual b) { return Dual(a.v + b.v, a.d + b.d); }
+inline Dual operator-(Dual a, Dual b) { return Dual(a.v - b.v, a.d - b.d); }
+inline Dual operator*(Dual a, Dual b) { return Dual(a.v * b.v, a.d * b.v + a.v * b.d); }
+inline Dual operator/(Dual a, Dual b) { float q = a.v / b.v; return Dual(q, (a.d - q * b.d) / b.v); }
+inline Dual operator-(Dual a) { return Dual(-a.v, -a.d); }
+inline bool operator<(Dual a, Dual b) { return a.v < b.v; }
+inline bool operator>(Dual a, Dual b) { return a.v > b.v; }
+using std::sin; using std::cos; using std::tan; using std::exp; using std::log; using std::sqrt; using std::tanh; using std::atan; using std::atan2;
+using std::pow; using std::abs;
+inline Dual sin(Dual x) { return Dual(std::sin(x.v), std::cos(x.v) * x.d); }
+inline Dual cos(Dual x) { return Dual(std::cos(x.v), -std::sin(x.v) * x.d); }
+inline Dual sqrt(Dual x) { float s = std::sqrt(x.v); return Dual(s, x.d / (2 * s)); }
+inline Dual exp(Dual x) { float e = std::exp(x.v); return Dual(e, e * x.d); }
+inline Dual log(Dual x) { return Dual(std::log(x.v), x.d / x.v); }
+inline Dual abs(Dual x) { return x.v < 0 ? -x : x; }
+inline Dual atan2(Dual y, Dual x) { float r2 = x.v * x.v + y.v * y.v; return Dual(std::atan2(y.v, x.v), (x.v * y.d - y.v * x.d) / r2); }
+%s
+}
+extern "C" void f_val(const float* x, const float* w, float u, float* out) { bfu::%s<float>(x, w, u, nullptr, out); }
+extern "C" void f_jac(const float* x, const float* w, float u, int seed, float* out) {   // d out / d x[seed]
+  bfu::Dual xd[16], wd[16], od[16];
+  for (int i = 0; i < %d; ++i) xd[i] = bfu::Dual(x[i], i == seed ? 1.f : 0.f);
+  for (int i = 0; i < %d; ++i) wd[i] = bfu::Dual(w[i]);
+  bfu::%s<bfu::Dual>(xd, wd, bfu::Dual(u), nullptr, od);
+  for (int i = 0; i < %d; ++i) out[i] = od[i].d;
+}
+"""
+
+
+def _build(tmp_path, src, entry, n, dw, m, tag):
+    cpp = tmp_path / f"{tag}.cpp"
+    so = tmp_path / f"{tag}.so"
+    cpp.write_text(HOST % (src, entry, n, dw, entry, m))
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-o", str(so), str(cpp)])
+    return ctypes.CDLL(str(so))
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def test_traced_bot_model_compiles_and_matches_the_python_function(tmp_path):
+    src_f, nf = trace.dynamics_source(f_bot, 4, 2)
+    src_h, nh = trace.emission_source(h_bot, 4, 2)
+    assert (nf, nh) == (4, 2) and "template <class T> __device__ void dynamics(" in src_f
+    lf = _build(tmp_path, src_f, "dynamics", 4, 2, 4, "f")
+    lh = _build(tmp_path, src_h, "emission", 4, 2, 2, "h")
+    rng = np.random.default_rng(0)
+    for u in (0.0, 1.0, 2.0):
+        x = (np.array([2, 0.3, 3, -0.2]) + 0.1 * rng.normal(size=4)).astype(F32)
+        w = (0.1 * rng.normal(size=2)).astype(F32)
+        out = np.zeros(4, F32)
+        lf.f_val(_p(x), _p(w), ctypes.c_float(u), _p(out))
+        assert np.max(np.abs(out - f_bot(x.astype(np.float64), w.astype(np.float64), np.array([u])))) < 1e-4
+        oh = np.zeros(2, F32)
+        lh.f_val(_p(x), _p(w), ctypes.c_float(u), _p(oh))
+        assert np.max(np.abs(oh - h_bot(x.astype(np.float64), w.astype(np.float64), np.array([u])))) < 1e-6
+        # the dual-number instantiation = the Jacobian (central differences of the Python function in float64)
+        for s in range(4):
+            jac = np.zeros(2, F32)
+            lh.f_jac(_p(x), _p(w), ctypes.c_float(u), s, _p(jac))
+            e = np.zeros(4)
+            e[s] = 1e-6
+            fd = (h_bot(x.astype(np.float64) + e, w.astype(np.float64), [u]) - h_bot(x.astype(np.float64) - e, w.astype(np.float64), [u])) / 2e-6
+            assert np.max(np.abs(jac - fd)) < 1e-4
+
+
+def test_log_prob_and_where():
+    src = trace.log_prob_source(lp_laplace, 3, 1)
+    assert "__device__ T log_prob(const T* x, const float* y, T u, const float* th)" in src and "abs(" in src and "return T(" in src
+    sat = trace.emission_source(lambda x, r, u: trace.where(trace.greater(x[:1], 1.0), 1.0 + 0.1 * (x[:1] - 1.0), x[:1]) + r, 2, 1)[0]
+    sat1 = trace.emission_source(lambda x, r, u: trace.where(x[0] > 1.0, 1.0 + 0.1 * (x[0] - 1.0), x[0]) + r, 2, 1)[0]
+    assert sat1.count('?') == 1
+    assert "?" in sat and "const bool c" in sat
+
+
+def test_untraceable_functions_say_why():
+    with pytest.raises(trace.TraceError, match="truth value"):
+        trace.dynamics_source(lambda x, q, u: x if x[0] > 0 else -x, 2, 2)
+    with pytest.raises(trace.TraceError, match="could not be recorded"):
+        trace.dynamics_source(lambda x, q, u: np.linalg.inv(np.outer(x, x)) @ q, 2, 2)
+    with pytest.raises(trace.TraceError):
+        trace.emission_source(lambda x, r, u: "not numbers", 2, 1)
+
+
+def test_structural_zeros_and_ones_fold():
+    src, n = trace.dynamics_source(lambda x, q, u: np.eye(3) @ x + 0.0 * q + q, 3, 3)
+    body = src.split("{", 1)[1]
+    assert n == 3 and "*" not in body and "x[0] + q[0]" in body

@@ -203,8 +203,8 @@ def test_user_model_errors_and_cache():
     with pytest.raises(_lib.BayesFiltError) as e:
         bfa.gaussian_sum_filter(base._replace(dynamics_function=nl.user_dynamics(bad, 1)), ys, 1, initial_means=np.zeros((1, 1), F32))
     assert e.value.code == _lib.BF_EINVAL and "nosuchfn" in str(e.value)
-    with pytest.raises(TypeError):                                    # a Python callable still cannot run on the device
-        bfa.gaussian_sum_filter(base._replace(dynamics_function=lambda x, q, u: x), ys, 1)
+    with pytest.raises(TypeError):                # a Python callable that leaves NumPy-recordable operations cannot run on the device
+        bfa.gaussian_sum_filter(base._replace(dynamics_function=lambda x, q, u: np.asarray([float(x[0])])), ys, 1)
     f = nl.user_dynamics(GROWTH_SRC, 1)
     bfa.gaussian_sum_filter(base._replace(dynamics_function=f), ys, 1, initial_means=np.zeros((1, 1), F32))
     t0 = time.perf_counter()
@@ -661,3 +661,58 @@ def test_registry_models_at_dimensions_without_a_compiled_instance():
         ref, _ = fn_o(*a_o, initial_means=im)
         for k in ("means", "covariances"):
             assert cm.rel_err(getattr(post, k).cpu().numpy(), getattr(ref, k)) < 3e-5, (fn_e.__name__, k)
+
+
+def test_filters_take_python_functions_of_numpy_operations():
+    """The reference's call sites pass lambdas (docs/experiments/BOT_Experiment_script.py:31-44, :100, :151).  Written with numpy
+    instead of jax.numpy they are accepted as they are: recorded once on symbolic arguments (bayesianfiltering_amd/trace.py),
+    turned into source, compiled at run time -- dynamics, emission and the particle filter's log-density -- and every filter agrees
+    with the registry twin; a function that cannot be recorded says why."""
+    import bayesianfiltering_amd as bfa
+    from tests.test_trace import f_bot, h_bot, DT, ACC
+    nl = bfa.nonlinearities
+    T, B = 20, 3
+    mu0 = np.array([2.0, 0.3, 3.0, -0.2], F32)
+    S0 = np.diag([0.1, 0.005, 0.1, 0.01]).astype(F32)
+    Q, R = 1e-3 * np.eye(2, dtype=F32), np.diag([1e-3, 1e-2]).astype(F32)
+    inputs = np.array([1] * 7 + [0] * 7 + [2] * 6, F32)
+    reg = bfa.ParamsNLSSM(mu0, S0, nl.maneuver_bot(DT, ACC), np.zeros(2, F32), Q, nl.bearing_range(), np.zeros(2, F32), R)
+    lam = bfa.ParamsNLSSM(mu0, S0, f_bot, np.zeros(2, F32), Q, h_bot, np.zeros(2, F32), R)          # plain Python functions
+    po = go.ParamsNLSSM(mu0, S0, om.ManeuverBOT(DT, ACC), np.zeros(2, F32), Q, om.BearingRange(), np.zeros(2, F32), R)
+    ys = np.stack([go.sample_ssm(po, otf.PRNGKey(40 + b), T, inputs.reshape(T, 1))[1] for b in range(B)])
+    K = 4
+    im = (mu0 + 0.05 * np.random.default_rng(3).normal(size=(B, K, 4))).astype(F32)
+    a = bfa.gaussian_sum_filter(reg, ys, K, 1, inputs, initial_means=im)
+    b_ = bfa.gaussian_sum_filter(lam, ys, K, 1, inputs, initial_means=im)
+    for k in FIELDS:
+        assert cm.rel_err(getattr(b_, k).cpu().numpy(), getattr(a, k).cpu().numpy()) < 2e-5, k
+    up = bfa.ParamsUKF(1, 0, 0)
+    ua = bfa.unscented_gaussian_sum_filter(reg, up, ys, K, 1, inputs, initial_means=im)
+    ub = bfa.unscented_gaussian_sum_filter(lam, up, ys, K, 1, inputs, initial_means=im)
+    assert cm.rel_err(ub.means.cpu().numpy(), ua.means.cpu().numpy()) < 2e-5
+    ga, _ = bfa.speedy_augmented_gaussian_sum_filter(reg, ys, (K, 2, 2), None, 1, (0.1, 0.1), inputs, initial_means=im)
+    gb, _ = bfa.speedy_augmented_gaussian_sum_filter(lam, ys, (K, 2, 2), None, 1, (0.1, 0.1), inputs, initial_means=im)
+    assert cm.rel_err(gb.means.cpu().numpy(), ga.means.cpu().numpy()) < 5e-5
+    # the particle filter with a Python log-density: the Gaussian density written out with numpy
+    iR = 1.0 / np.diag(R)
+    cst = -0.5 * np.sum(np.log(2 * np.pi * np.diag(R)))
+
+    def glp(x, y, u):
+        d = y - h_bot(x, np.zeros(2), u)
+        return -0.5 * np.sum(d * d * iR) + cst
+    g_reg = nl.bearing_range()
+    pa = bfa.ParamsBPF(*reg, nl.gaussian_log_prob(g_reg, R))
+    pb = bfa.ParamsBPF(*lam, glp)
+    key = np.array([0, 9], np.uint32)
+    xa = bfa.bootstrap_particle_filter(pa, ys, 500, key, inputs, output="summary")
+    xb = bfa.bootstrap_particle_filter(pb, ys, 500, key, inputs, output="summary")
+    d = np.abs(xa["mean"].cpu().numpy() - xb["mean"].cpu().numpy()).max(axis=2) / np.abs(xa["mean"].cpu().numpy()).max()
+    assert (d[:, :3] < 1e-4).all() and float(xb["resampled"].mean()) > 0     # (the same filter until an ancestor differs by rounding)
+    # sampling
+    keys = np.stack([otf.PRNGKey(1), otf.PRNGKey(2)])
+    sa = bfa.NonlinearSSM(4, 2, 2, 2).sample(reg, keys, T, inputs)
+    sb = bfa.NonlinearSSM(4, 2, 2, 2).sample(lam, keys, T, inputs)
+    assert cm.rel_err(sb[0].cpu().numpy(), sa[0].cpu().numpy()) < 1e-5 and cm.rel_err(sb[1].cpu().numpy(), sa[1].cpu().numpy()) < 1e-5
+    # a function that cannot be recorded
+    with pytest.raises(TypeError, match="truth value"):
+        bfa.gaussian_sum_filter(lam._replace(dynamics_function=lambda x, q, u: x if x[0] > 0 else -x), ys, K, 1, inputs, initial_means=im)
