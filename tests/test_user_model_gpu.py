@@ -716,3 +716,50 @@ def test_filters_take_python_functions_of_numpy_operations():
     # a function that cannot be recorded
     with pytest.raises(TypeError, match="truth value"):
         bfa.gaussian_sum_filter(lam._replace(dynamics_function=lambda x, q, u: x if x[0] > 0 else -x), ys, K, 1, inputs, initial_means=im)
+
+
+def test_readme_call_site():
+    """The ported call site of README.md, as written there: lambdas of numpy operations, one trajectory and a batch."""
+    import bayesianfiltering_amd as gf
+    from bayesianfiltering_amd import ParamsNLSSM
+    m0, P0 = np.array([1.0, 0.0], F32), 0.1 * np.eye(2, dtype=F32)
+    Q, R = np.diag([1e-3, 2e-2]).astype(F32), 5e-2 * np.eye(1, dtype=F32)
+    f = lambda x, q, u: np.array([x[0] + 0.05 * x[1], x[1] - 0.05 * 9.81 * np.sin(x[0])]) + q
+    h = lambda x, r, u: np.array([np.sin(x[0])]) + r
+    params = ParamsNLSSM(m0, P0, f, np.zeros(2), Q, h, np.zeros(1), R)
+    fo = _PendulumPlain()
+    po = go.ParamsNLSSM(m0, P0, fo, np.zeros(2, F32), Q, _SinEmi(), np.zeros(1, F32), R)
+    emissions = go.sample_ssm(po, otf.PRNGKey(5), 40)[1]
+    post = gf.gaussian_sum_filter(params, emissions, 5, 1)
+    assert tuple(post.means.shape) == (5, 40, 2)
+    im = gf.sample_initial_component_means(params, 5)
+    ref = go.gaussian_sum_filter(po, emissions, 5, initial_means=np.asarray(im))
+    assert cm.rel_err(post.means.cpu().numpy(), ref.means) < 2e-5 and cm.rel_err(post.covariances.cpu().numpy(), ref.covariances) < 2e-5
+    batch = gf.gaussian_sum_filter(params, np.stack([emissions, emissions]), 5, 1)
+    assert tuple(batch.means.shape) == (2, 5, 40, 2) and np.array_equal(batch.means[1].cpu().numpy(), post.means.cpu().numpy())
+
+
+class _PendulumPlain(om.Fn):
+    out_dim, noise_dim = 2, 2
+
+    def value(self, x, w, u):
+        return np.array([x[0] + F32(0.05) * x[1], x[1] - F32(0.05 * 9.81) * np.sin(x[0])], F32) + w
+
+    def jac_x(self, x, w, u):
+        return np.array([[1, 0.05], [-0.05 * 9.81 * np.cos(x[0]), 1]], F32)
+
+    def jac_noise(self, x, w, u):
+        return np.eye(2, dtype=F32)
+
+
+class _SinEmi(om.Fn):
+    out_dim, noise_dim = 1, 1
+
+    def value(self, x, w, u):
+        return np.array([np.sin(x[0])], F32) + w
+
+    def jac_x(self, x, w, u):
+        return np.array([[np.cos(x[0]), 0]], F32)
+
+    def jac_noise(self, x, w, u):
+        return np.eye(1, dtype=F32)
