@@ -128,3 +128,19 @@ def test_structural_zeros_and_ones_fold():
     src, n = trace.dynamics_source(lambda x, q, u: np.eye(3) @ x + 0.0 * q + q, 3, 3)
     body = src.split("{", 1)[1]
     assert n == 3 and "*" not in body and "x[0] + q[0]" in body
+
+
+def test_jnp_module_is_numpy_with_a_recorded_where(tmp_path):
+    import bayesianfiltering_amd.jnp as jnp
+
+    def h(x, r, u):      # a saturating range sensor: jnp.where on the state, jnp.linalg-free norm
+        rng = jnp.sqrt(jnp.sum(x[:2] ** 2))
+        return jnp.array([jnp.where(rng > 2.0, 2.0 + 0.1 * (rng - 2.0), rng), jnp.arctan2(x[1], x[0])]) + r
+    src, m = trace.emission_source(h, 2, 2)
+    assert m == 2 and "?" in src
+    lib = _build(tmp_path, src, "emission", 2, 2, 2, "sat")
+    for x in (np.array([0.5, 0.3], F32), np.array([3.0, -2.0], F32)):
+        out = np.zeros(2, F32)
+        lib.f_val(_p(x), _p(np.zeros(2, F32)), ctypes.c_float(0.0), _p(out))
+        assert np.max(np.abs(out - h(x.astype(np.float64), np.zeros(2), [0.0]))) < 1e-6      # (plain numbers: numpy's own where)
+    assert jnp.where(np.array([True, False]), 1.0, 2.0).tolist() == [1.0, 2.0]
