@@ -144,3 +144,35 @@ def test_jnp_module_is_numpy_with_a_recorded_where(tmp_path):
         lib.f_val(_p(x), _p(np.zeros(2, F32)), ctypes.c_float(0.0), _p(out))
         assert np.max(np.abs(out - h(x.astype(np.float64), np.zeros(2), [0.0]))) < 1e-6      # (plain numbers: numpy's own where)
     assert jnp.where(np.array([True, False]), 1.0, 2.0).tolist() == [1.0, 2.0]
+
+
+def test_mvn_log_prob_records_and_matches_scipy(tmp_path):
+    """The reference's particle-filter densities, `MVN(loc = g(x, r0, u), covariance_matrix = R).log_prob(y)`
+    (BOT_Experiment_script.py:45), with bayesianfiltering_amd.distributions.MVN in place of tfp's class: constant covariance and a
+    state-dependent one (adaptive_experiment.py:55-57: M R M^T with M = diag(exp(x / sigma)))."""
+    from scipy.stats import multivariate_normal
+    from bayesianfiltering_amd.distributions import MVN
+    R = np.array([[0.3, 0.05], [0.05, 0.2]])
+    r0 = np.array([0.01, -0.02])
+    lp = lambda x, y, u: MVN(loc=h_bot(x, r0, u), covariance_matrix=R).log_prob(y)
+    x, y = np.array([2.0, 0.3, 3.0, -0.2]), np.array([1.1, 3.4])
+    assert abs(lp(x, y, [0.0]) - multivariate_normal(h_bot(x, r0, [0.0]), R).logpdf(y)) < 1e-10           # plain numbers
+    src = trace.log_prob_source(lp, 4, 2)
+
+    def sv(x, y, u):
+        M = np.diag(np.exp(x[:2] / 5.0))
+        return MVN(loc=0.5 * x[:2], covariance_matrix=M @ R @ M.T).log_prob(y)
+    src2 = trace.log_prob_source(sv, 4, 2)
+    cpp = tmp_path / "lp.cpp"
+    so = tmp_path / "lp.so"
+    prelude = HOST.split('extern "C"')[0].replace("%s", src + src2.replace("log_prob(", "log_prob2("))
+    cpp.write_text(prelude +
+                   'extern "C" float lp1(const float* x, const float* y) { return bfu::log_prob<float>(x, y, 0.f, nullptr); }\n'
+                   'extern "C" float lp2(const float* x, const float* y) { return bfu::log_prob2<float>(x, y, 0.f, nullptr); }\n')
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-o", str(so), str(cpp)])
+    lib = ctypes.CDLL(str(so))
+    lib.lp1.restype = lib.lp2.restype = ctypes.c_float
+    xf, yf = x.astype(F32), y.astype(F32)
+    assert abs(lib.lp1(_p(xf), _p(yf)) - lp(x, y, [0.0])) < 1e-4
+    Ms = np.diag(np.exp(x[:2] / 5.0))
+    assert abs(lib.lp2(_p(xf), _p(yf)) - multivariate_normal(0.5 * x[:2], Ms @ R @ Ms.T).logpdf(y)) < 1e-4

@@ -693,13 +693,9 @@ def test_filters_take_python_functions_of_numpy_operations():
     ga, _ = bfa.speedy_augmented_gaussian_sum_filter(reg, ys, (K, 2, 2), None, 1, (0.1, 0.1), inputs, initial_means=im)
     gb, _ = bfa.speedy_augmented_gaussian_sum_filter(lam, ys, (K, 2, 2), None, 1, (0.1, 0.1), inputs, initial_means=im)
     assert cm.rel_err(gb.means.cpu().numpy(), ga.means.cpu().numpy()) < 5e-5
-    # the particle filter with a Python log-density: the Gaussian density written out with numpy
-    iR = 1.0 / np.diag(R)
-    cst = -0.5 * np.sum(np.log(2 * np.pi * np.diag(R)))
-
-    def glp(x, y, u):
-        d = y - h_bot(x, np.zeros(2), u)
-        return -0.5 * np.sum(d * d * iR) + cst
+    # the particle filter with the reference's Python log-density
+    from bayesianfiltering_amd.distributions import MVN      # (the reference: tfp's MultivariateNormalFullCovariance as MVN)
+    glp = lambda x, y, u: MVN(loc=h_bot(x, np.zeros(2), u), covariance_matrix=R).log_prob(y)     # BOT_Experiment_script.py:45, as written
     g_reg = nl.bearing_range()
     pa = bfa.ParamsBPF(*reg, nl.gaussian_log_prob(g_reg, R))
     pb = bfa.ParamsBPF(*lam, glp)
