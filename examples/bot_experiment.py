@@ -7,8 +7,8 @@ The experiment of the reference's docs/experiments/BOT_Experiment_script.py:20-2
 simulated and filtered in one launch per filter.  Prints the RMSE table of :238-245 (position components
 0 and 2, mean +- std over the runs) and the wall time per filter for the whole batch.
 
-Differences from the reference script, by necessity: the functions come from the device registry instead of
-Python lambdas; the particle filter runs 4096 particles per trajectory by default (the reference: 50 000, which
+Differences from the reference script: the functions come from the device registry by default (--python-functions runs the
+reference's own lambdas, recorded and compiled at first use: same results to rounding, 1-2x the registry's times); the particle filter runs 4096 particles per trajectory by default (the reference: 50 000, which
 --particles 50000 reproduces through the particles-in-HBM kernels); emission noise R = 1e-4 I instead of
 25e-6 I, where the reference's own GSF / UGSF return NaN (BOTExperiment.ipynb cell 7).
 
@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--components", type=int, default=100)
     ap.add_argument("--particles", type=int, default=4096)
+    ap.add_argument("--python-functions", action="store_true",
+                    help="the model as the reference writes it -- Python lambdas (:31-45) with jax.numpy / tfp's MVN replaced by "
+                         "bayesianfiltering_amd.jnp / distributions.MVN -- recorded and compiled at first use, instead of the device registry")
     args = ap.parse_args()
 
     import torch
@@ -45,8 +48,25 @@ def main():
     q0, r0 = np.zeros(2, F32), np.zeros(2, F32)
     f, g = nl.maneuver_bot(dt=0.5, acc=0.5), nl.bearing_range()                       # :40, :43
     inputs = np.array([1] * (2 * T // 5) + [0] * (T // 5) + [2] * (T - 2 * T // 5 - T // 5), F32)   # :46
+    glp = nl.gaussian_log_prob(g, R)
+    if args.python_functions:
+        import bayesianfiltering_amd.jnp as jnp                      # was: import jax.numpy as jnp
+        from bayesianfiltering_amd.distributions import MVN          # was: tfd.MultivariateNormalFullCovariance as MVN
+        dt, acc = 0.5, 0.5
+        FCV = jnp.array([[1, dt, 0, 0], [0, 1, 0, 0], [0, 0, 1, dt], [0, 0, 0, 1.0]])                                        # :31
+
+        def FCT(x, a):                                                                                                   # :33-39
+            omega = 0.1 * a / jnp.sqrt(x[1] ** 2 + x[3] ** 2)
+            return jnp.array([[1, jnp.sin(dt * omega) / omega, 0, -(1 - jnp.cos(dt * omega)) / omega],
+                              [0, jnp.cos(dt * omega), 0, -jnp.sin(dt * omega)],
+                              [0, (1 - jnp.cos(dt * omega)) / omega, 1, jnp.sin(dt * omega) / omega],
+                              [0, jnp.sin(dt * omega), 0, jnp.cos(dt * omega)]])
+        G = jnp.array([[0.5, 0], [1, 0], [0, 0.5], [0, 1.0]])
+        f = lambda x, q, u: (0.5 * (u - 1) * (u - 2) * FCV - u * (u - 2) * FCT(x, acc) + 0.5 * u * (u - 1) * FCT(x, -acc)) @ x + G @ q   # :42
+        g = lambda x, r, u: jnp.array([jnp.arctan2(x[2], x[0]), jnp.sqrt(x[0] ** 2 + x[2] ** 2)]) + r                        # :43-44
+        glp = lambda x, y, u: MVN(loc=g(x, r0, u), covariance_matrix=R).log_prob(y)                                       # :45
     params = ParamsNLSSM(mu0, Sigma0, f, q0, Q, g, r0, R)
-    params_bpf = ParamsBPF(mu0, Sigma0, f, q0, Q, g, r0, R, nl.gaussian_log_prob(g, R))
+    params_bpf = ParamsBPF(mu0, Sigma0, f, q0, Q, g, r0, R, glp)
 
     model = NonlinearSSM(4, 2, 2, 2)
     keys = np.stack([gf.PRNGKey(1000 + i) for i in range(args.nsim)])
