@@ -235,16 +235,25 @@ def kalman_filter(params, emissions, *, initial_means=None, initial_covariances=
     return (post, *extras) if extras else post
 
 
+def _param_dims(params):
+    """(state_dim, state-noise dim, emission-noise dim) read off the parameter arrays (for recording Python functions)."""
+    n0 = int(_host_f32(params.initial_mean).size)
+    Qs, Rs = tuple(np.shape(params.dynamics_noise_covariance)), tuple(np.shape(params.emission_noise_covariance))
+    return n0, (int(Qs[-1]) if len(Qs) >= 2 else 1), (int(Rs[-1]) if len(Rs) >= 2 else 1)
+
+
 class _Model:
     """Host-side build of bf_model from a ParamsNLSSM / ParamsBPF holding registry functions."""
 
     def __init__(self, params, log_prob_source=None):
         # (a plain Python function of NumPy operations is recorded and compiled: its dimensions come from the parameters)
-        n0 = int(np.size(params.initial_mean))
-        dq0 = int(np.shape(params.dynamics_noise_covariance)[-1]) if np.ndim(params.dynamics_noise_covariance) >= 2 else 1
-        dr0 = int(np.shape(params.emission_noise_covariance)[-1]) if np.ndim(params.emission_noise_covariance) >= 2 else 1
-        f = require_device_function(params.dynamics_function, "dynamics", "params.dynamics_function", n0, dq0)
-        h = require_device_function(params.emission_function, "emission", "params.emission_function", n0, dr0)
+        f, h = params.dynamics_function, params.emission_function
+        if not (isinstance(f, DeviceFunction) and isinstance(h, DeviceFunction)):
+            n0, dq0, dr0 = _param_dims(params)
+            f = require_device_function(f, "dynamics", "params.dynamics_function", n0, dq0)
+            h = require_device_function(h, "emission", "params.emission_function", n0, dr0)
+        f = require_device_function(f, "dynamics", "params.dynamics_function")
+        h = require_device_function(h, "emission", "params.emission_function")
         self.n, self.dq, self.m, self.dr = f.out_dim, f.noise_dim, h.out_dim, h.noise_dim
         if f.in_dim != self.n or h.in_dim != self.n:
             raise ValueError("dynamics / emission functions do not match the state dimension")
@@ -651,8 +660,7 @@ def bootstrap_particle_filter(params, emissions, num_particles: int, key=None, i
         # a plain Python function of NumPy operations: recorded and compiled (nonlinearities.trace_log_prob)
         from .nonlinearities import trace_log_prob
         from .trace import TraceError
-        n0 = int(np.size(params.initial_mean))
-        dr0 = int(np.shape(params.emission_noise_covariance)[-1]) if np.ndim(params.emission_noise_covariance) >= 2 else 1
+        n0, _, dr0 = _param_dims(params)
         h0 = require_device_function(params.emission_function, "emission", "params.emission_function", n0, dr0)
         try:
             lp = trace_log_prob(lp, n0, h0.out_dim)
