@@ -25,7 +25,7 @@ int launch_kf_group(const bf_lgssm* p, const bf_cstream* y, long long B, long lo
 int launch_kf_mfma(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
                    const bf_out_desc* out, hipStream_t stream, int K, bool multi, int dyn_kind, const float* dth);
 int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry, const bf_out_desc* out,
-                   hipStream_t stream, int K, bool multi, int dyn_kind, const float* dth);
+                   hipStream_t stream, int K, bool multi, int dyn_kind, const float* dth, bool two_per_wave);
 int launch_kf_generic(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry,
                       const bf_out_desc* out, hipStream_t stream);
 int launch_gsf_generic(const bf_model* p, const bf_cstream* y, const bf_cstream* u, long long B, long long T, int K,
@@ -89,7 +89,7 @@ __global__ void canon_eval_kernel(int op, const float* __restrict__ in, long lon
   out[i] = canon_eval_one(op, in, n, i);
 }
 
-static Option g_kf_small_mode{1, OPT_KF_SMALL_MODE};   // bf_set_option "kf_small_mode": 1 = one-wave matrix-core kernel for 9 <= n <= 32 (default), 0 = off
+static Option g_kf_small_mode{1, OPT_KF_SMALL_MODE};   // bf_set_option "kf_small_mode": 1 = one-wave matrix-core kernel for 9 <= n <= 32 (default), 2 = its two-chains-per-wave variant (same bits, measured slower), 0 = off
 static Option g_force_generic{0, OPT_FORCE_GENERIC};  // 1 = run the run-time-dimension kernel even where a compiled instance exists
 
 // A shape / option the compiled instances do not cover falls through to the run-time-dimension kernel
@@ -165,7 +165,7 @@ static int set_option_impl(const char* name, int value, bool this_call_only) {
     return assign(bf::g_kf_mfma_variant);
   }
   if (name && std::strcmp(name, "kf_small_mode") == 0) {
-    if (value < 0 || value > 1) return bf::set_error(BF_EINVAL, "kf_small_mode must be 0 or 1");
+    if (value < 0 || value > 2) return bf::set_error(BF_EINVAL, "kf_small_mode must be 0, 1 or 2");
     return assign(bf::g_kf_small_mode);
   }
   if (name && std::strcmp(name, "force_generic") == 0) {
@@ -240,7 +240,7 @@ int bf_kalman_filter_f32(const bf_lgssm* model, const bf_cstream* y, int64_t B, 
   // 9 <= n <= 32: one wave per trajectory on single 32 x 32 tiles, 1.8e8 steps/s whatever the size; the run-time-dimension
   // kernel is faster only for the smallest of them (n = 12, m = 4: 1.7e8; n = 16, m = 8: 1.0e8; (32, 32): 3.5e6)
   if (model->n >= 9 && model->n <= 32 && model->m <= 32 && (model->n >= 16 || model->m > 8) && bf::g_kf_small_mode.load() != 0)
-    return bf::with_generic_fallback(bf::launch_kf_bf32(model, y, B, T, carry, out, hs, 1, false, 0, nullptr), generic);
+    return bf::with_generic_fallback(bf::launch_kf_bf32(model, y, B, T, carry, out, hs, 1, false, 0, nullptr, bf::g_kf_small_mode.load() == 2), generic);
   if (model->n >= 24 && model->n <= 64 && model->m <= 32)
     return bf::with_generic_fallback(bf::launch_kf_mfma(model, y, B, T, carry, out, hs, 1, false, 0, nullptr), generic);
   return bf::with_generic_fallback(
@@ -285,10 +285,10 @@ int bf_gsf_ekf_f32(const bf_model* model, const bf_cstream* y, const bf_cstream*
     if (!lin_dyn) {
       float dth[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int i = 0; i < model->n_dyn_theta && i < 8; ++i) dth[i] = model->dyn_theta[i];
-      if (small_tiles) return bf::with_generic_fallback(bf::launch_kf_bf32(&lg, y, B, T, carry, out, hs, K, true, dyn_kind, dth), generic);
+      if (small_tiles) return bf::with_generic_fallback(bf::launch_kf_bf32(&lg, y, B, T, carry, out, hs, K, true, dyn_kind, dth, bf::g_kf_small_mode.load() == 2), generic);
       return bf::with_generic_fallback(bf::launch_kf_mfma(&lg, y, B, T, carry, out, hs, K, true, dyn_kind, dth), generic);
     }
-    if (small_tiles) return bf::with_generic_fallback(bf::launch_kf_bf32(&lg, y, B, T, carry, out, hs, K, K > 1, 0, nullptr), generic);
+    if (small_tiles) return bf::with_generic_fallback(bf::launch_kf_bf32(&lg, y, B, T, carry, out, hs, K, K > 1, 0, nullptr, bf::g_kf_small_mode.load() == 2), generic);
     return bf::with_generic_fallback(bf::launch_kf_mfma(&lg, y, B, T, carry, out, hs, K, K > 1, 0, nullptr), generic);   // 33 <= n <= 64: four waves per trajectory
   }
   return bf::with_generic_fallback(

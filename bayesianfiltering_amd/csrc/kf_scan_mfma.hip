@@ -564,12 +564,31 @@ __device__ __forceinline__ Split3 split_pair(float x0, float x1) {
 //   det S = det S_j (1 - eps g^T g),   v^T S^-1 v = z^T z + eps (g^T z)^2 / (1 - eps g^T g)
 // -- exact identities, evaluated in fp32 (eps g^T g is O(1e-4) for a conditioned S): the separate factorization of S that
 // inference.py:104 implies (a second 1 200-instruction serial chain) is not needed.
-template <bool BF, int NCOL = 64, bool LL = false>
+// DUAL (NCOL = 32 only): TWO chains per wave, chain c in the half-wave of lanes 32 c .. 32 c + 31 -- the single-chain form lets the
+// upper half repeat the lower one's work -- with chain 1's arrays `dual_stride` bytes behind chain 0's.  The column broadcasts
+// then differ between the halves, so they cannot be v_readlane scalars: ds_swizzle (BitMode and = 0, or = j: lane j of each
+// group of 32, through the LDS crossbar without touching memory) delivers them in a vector register.
+template <int J>
+__device__ __forceinline__ float bcast_half(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (J & 31) << 5));
+}
+template <bool BF, int NCOL = 64, bool LL = false, bool DUAL = false>
 __device__ __forceinline__ float chol_w_rows_impl(lds_f* sc, lds_f* sT, lds_f* sv, lds_f* mcur, lds_f* mnxt, lds_f* scv,
-                                                  lds_c* wt, int lane_in) {
+                                                  lds_c* wt, int lane_in, int dual_stride = 0) {
+  static_assert(!DUAL || NCOL == 32, "two chains per wave: 32 columns each");
   constexpr int PP = NCOL + 1, PS = 33, WT_TERM_B = NCOL * 80;
   const int r = lane_in & 31;
   const int lane = NCOL == 64 ? lane_in : r;
+  if constexpr (DUAL) {
+    const int off = (lane_in >> 5) * dual_stride;
+    sc = (lds_f*)((lds_c*)sc + off); sT = (lds_f*)((lds_c*)sT + off); sv = (lds_f*)((lds_c*)sv + off);
+    mcur = (lds_f*)((lds_c*)mcur + off); mnxt = (lds_f*)((lds_c*)mnxt + off); scv = (lds_f*)((lds_c*)scv + off);
+    wt = wt + off;
+  }
+  auto bc = [&](float v, auto J) __attribute__((always_inline)) {
+    if constexpr (DUAL) return bcast_half<decltype(J)::value>(v);
+    else return rdlane_u(v, decltype(J)::value);
+  };
   f32x2 aw[32];  // .x: row r of S + 1e-6 (psd_solve's jitter on every entry, utils.py:258); .y: column `lane` of H P
   BF_UNROLL for (int k = 0; k < 32; ++k) aw[k] = f32x2{sc[r * PS + k] + 1e-6f, sT[k * PP + lane]};
   f32x2 rgz = f32x2{1.0f, sv[r]};  // residuals of g = L^-1 1, z = L^-1 v (row r)
@@ -578,9 +597,9 @@ __device__ __forceinline__ float chol_w_rows_impl(lds_f* sc, lds_f* sT, lds_f* s
   Split3 wsp[4];
   static_for<0, 32>([&](auto J) {
     constexpr int j = decltype(J)::value;
-    const float rinv = rsqrt_newton(rdlane_u(aw[j].x, j));            // 1 / L[j][j], wave-uniform
+    const float rinv = rsqrt_newton(bc(aw[j].x, J));                  // 1 / L[j][j], wave-uniform (DUAL: per half-wave)
     const f32x2 lw = aw[j] * rinv;                                     // L[r][j] (meaningful for r >= j), W[j][lane] (final)
-    const f32x2 gz = f32x2{rdlane_u(rgz.x, j), rdlane_u(rgz.y, j)} * rinv;  // g[j], z[j]: wave-uniform
+    const f32x2 gz = f32x2{bc(rgz.x, J), bc(rgz.y, J)} * rinv;         // g[j], z[j]: wave-uniform
     aw[j] = lw;
     rgz = __builtin_elementwise_fma(f32x2{-lw.x, -lw.x}, gz, rgz);
     acc_cm = __builtin_elementwise_fma(f32x2{lw.y, lw.y}, gz, acc_cm);
@@ -598,7 +617,7 @@ __device__ __forceinline__ float chol_w_rows_impl(lds_f* sc, lds_f* sT, lds_f* s
       constexpr int k0 = j + 1 + decltype(Cb)::value * BF_MFMA_RDB;
       constexpr int nk = (32 - k0) < BF_MFMA_RDB ? (32 - k0) : BF_MFMA_RDB;
       float sb[BF_MFMA_RDB];
-      static_for<0, nk>([&](auto I) { sb[decltype(I)::value] = rdlane_u(aw[k0 + decltype(I)::value].x, j); });
+      static_for<0, nk>([&](auto I) { sb[decltype(I)::value] = bc(aw[k0 + decltype(I)::value].x, J); });
       __builtin_amdgcn_sched_barrier(0);
       static_for<0, nk>([&](auto I) {
         constexpr int k = k0 + decltype(I)::value;
@@ -653,6 +672,12 @@ __device__ __attribute__((noinline)) float chol_w_rows_bf_ll(lds_f* sc, lds_f* s
 __device__ __attribute__((noinline)) float chol_w_rows_bf32(lds_f* sc, lds_f* sT, lds_f* sv, lds_f* mcur, lds_f* mnxt, lds_f* scv, lds_c* wt,
                                                             int lane) {
   return chol_w_rows_impl<true, 32, true>(sc, sT, sv, mcur, mnxt, scv, wt, lane);
+}
+// two chains per wave (kf_scan_bf32x2_kernel): pointers of chain 0, chain 1's arrays `stride` bytes behind; lanes of half c
+// return chain c's log-likelihood
+__device__ __attribute__((noinline)) float chol_w_rows_bf32x2(lds_f* sc, lds_f* sT, lds_f* sv, lds_f* mcur, lds_f* mnxt, lds_f* scv, lds_c* wt,
+                                                              int lane, int stride) {
+  return chol_w_rows_impl<true, 32, true, true>(sc, sT, sv, mcur, mnxt, scv, wt, lane, stride);
 }
 // out of line for variants 2 / 4 (a register allocation of its own); variant 5 inlines the body (it holds 112 operand
 // registers across the factorization, which a call would spill and reload)
@@ -1701,6 +1726,221 @@ kf_scan_bf32_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry,
 }
 
 
+// Two chains per wave.  In kf_scan_bf32_kernel the factorization -- two thirds of a step's instructions -- works on the 32 rows of S
+// in lanes 0 .. 31 while lanes 32 .. 63 repeat them.  Here the upper half-wave carries a SECOND chain (the next trajectory, or the
+// next component of a Gaussian sum) through the same instruction stream: one factorization serves two chains (its column
+// broadcasts by ds_swizzle instead of v_readlane, chol_w_rows_impl<.., DUAL>), the matrix-core phases run once per chain on that
+// chain's LDS block (33.2 KB per wave, 128-thread workgroups, two per CU: one wave per SIMD with the 512-register budget), and the
+// two chains' independent product phases interleave in the one wave's issue slots.
+template <bool MULTI, bool TV, int DYN = 0>
+__global__ void __launch_bounds__(128, 1)
+kf_scan_bf32x2_kernel(const Bf32Const* __restrict__ cst, CView y, CarryView carry, OutViews out, long long B, long long T, int nr, int mr,
+                      int K, const float* __restrict__ tvq, const float* __restrict__ tvr) {
+  constexpr int PITCH = 80, TERM = 32 * PITCH, PS = 33;
+  const int lane = threadIdx.x & 63;
+  const int lr = lane & 31, lk = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long b0 = ((long long)blockIdx.x * 2 + wv) * 2;
+  if (b0 >= B) return;   // (no workgroup barrier anywhere below)
+  long long b[2], bt[2];
+  int kc[2];
+  bool ok[2];
+  BF_UNROLL for (int c = 0; c < 2; ++c) {
+    ok[c] = b0 + c < B;
+    b[c] = ok[c] ? b0 + c : b0;            // an odd tail: the second slot shadows the first and stores nothing
+    bt[c] = MULTI ? b[c] / K : b[c];
+    kc[c] = MULTI ? (int)(b[c] % K) : 0;
+  }
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  lds_c* L0 = (lds_c*)reinterpret_cast<char*>(lds) + wv * (2 * BF32_WAVE_LDS);
+  auto Pn = [&](int c) { return L0 + c * BF32_WAVE_LDS; };                        // [3][32][80 B]  P- / P+, transposed terms
+  auto Zn = [&](int c) { return L0 + c * BF32_WAVE_LDS + BF32_PN_BYTES; };        // Z = (H P-)^T; later W^T, then Y^T
+  auto sHP = [&](int c) { return reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + wv * (2 * BF32_WAVE_LDS) + c * BF32_WAVE_LDS); };
+  auto sc = [&](int c) { return sHP(c) + 32 * PS; };
+  auto sm = [&](int c) { return reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + wv * (2 * BF32_WAVE_LDS) + c * BF32_WAVE_LDS + BF32_PN_BYTES + 3 * TERM); };
+  auto sm2 = [&](int c) { return sm(c) + 32; };
+  auto sv = [&](int c) { return sm(c) + 64; };
+  auto scv = [&](int c) { return sm(c) + 96; };
+
+  u32x4 hop[3][2], aop[2][3][2];       // row lr of H, and of A (DYN: of each chain's F) as bf16 terms
+  BF_UNROLL for (int q = 0; q < 3; ++q) BF_UNROLL for (int c = 0; c < 2; ++c) {
+    hop[q][c] = *reinterpret_cast<const u32x4*>(&cst->H3[q][lr * 32 + 16 * c + 8 * lk]);
+    if constexpr (DYN == 0) aop[0][q][c] = aop[1][q][c] = *reinterpret_cast<const u32x4*>(&cst->A3[q][lr * 32 + 16 * c + 8 * lk]);
+  }
+  const float dr0 = cst->Dr0[lr], gq0 = cst->Gq0[lr];
+  f32x16 Pacc[2];
+  float w[2], ynext[2];
+  BF_UNROLL for (int c = 0; c < 2; ++c) {
+    BF_UNROLL for (int r = 0; r < 16; ++r) {
+      const int row = c_row(r, lane);
+      Pacc[c][r] = (lr < nr && row < nr) ? carry.P_in[b[c] * nr * nr + row * nr + lr] : 0.f;
+    }
+    store_terms_transposed(Pn(c), TERM, PITCH, 0, 0, lane, Pacc[c]);
+    sm(c)[lr] = lr < nr ? carry.m_in[b[c] * nr + lr] : 0.f;
+    w[c] = (!MULTI && carry.w_in) ? carry.w_in[b[c]] : 1.0f;
+    ynext[c] = lr < mr ? y.p[bt[c] * y.sB + lr * y.sE] : 0.f;
+  }
+  const float ll_pad = 0.5f * 1.8378770664093453f * (float)(32 - mr);
+  wave_lds_order();
+
+  for (long long t = 0; t < T; ++t) {
+    float yv[2];
+    BF_UNROLL for (int c = 0; c < 2; ++c) {
+      yv[c] = ynext[c];
+      const long long tn = t + 1 < T ? t + 1 : t;
+      if (lr < mr) ynext[c] = y.p[bt[c] * y.sB + tn * y.sT + lr * y.sE];
+    }
+    gl_cf* const drd_t = TV && tvr ? per_step(tvr + t * 1024) : per_step(cst->DRD);
+    gl_cf* const gqg_t = TV && tvq ? per_step(tvq + t * 1024) : per_step(cst->GQG);
+    // ---- Z = P-^T H^T; H P- in fp32 for the forward substitution; innovation
+    BF_UNROLL for (int c = 0; c < 2; ++c) {
+      f32x16 z = {0};
+      BF_UNROLL for (int cc = 0; cc < 2; ++cc) {
+        u32x4 a[3];
+        load_terms(a, Pn(c), TERM, PITCH, lr, cc, lk);
+        const u32x4 bh[3] = {hop[0][cc], hop[1][cc], hop[2][cc]};
+        z = mfma_bf6(a, bh, z);
+      }
+      wave_lds_order();   // P-'s terms have been read: their buffer now takes H P (fp32) and, below, S
+      BF_UNROLL for (int r = 0; r < 16; ++r) sHP(c)[lr * PS + c_row(r, lane)] = z[r];
+      store_terms_transposed(Zn(c), TERM, PITCH, 0, 0, lane, z);
+      float s = dot_terms32(hop, sm(c), lk);
+      s += __shfl_xor(s, 32, 64);
+      sv(c)[lr] = yv[c] - (s + dr0);
+    }
+    wave_lds_order();
+    // ---- S^T = H Z + (D R D^T)^T
+    BF_UNROLL for (int c = 0; c < 2; ++c) {
+      f32x16 acc;
+      BF_UNROLL for (int r = 0; r < 16; ++r) acc[r] = drd_t[lr * 32 + c_row(r, lane)];
+      BF_UNROLL for (int cc = 0; cc < 2; ++cc) {
+        u32x4 bz[3];
+        load_terms(bz, Zn(c), TERM, PITCH, lr, cc, lk);
+        const u32x4 ah[3] = {hop[0][cc], hop[1][cc], hop[2][cc]};
+        acc = mfma_bf6(ah, bz, acc);
+      }
+      BF_UNROLL for (int r = 0; r < 16; ++r) sc(c)[lr * PS + c_row(r, lane)] = acc[r];
+    }
+    wave_lds_order();
+    // ---- ONE factorization for both chains (chain c in half-wave c)
+    const float ll2 = chol_w_rows_bf32x2((lds_f*)sc(0), (lds_f*)sHP(0), (lds_f*)sv(0), (lds_f*)sm(0), (lds_f*)sm2(0), (lds_f*)scv(0), Zn(0), lane,
+                                         BF32_WAVE_LDS) + ll_pad;
+    wave_lds_order();
+    float llc[2];
+    llc[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ll2), 0));
+    llc[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ll2), 32));
+    // ---- P+ = P- - W^T W + c c^T; filtered streams
+    BF_UNROLL for (int c = 0; c < 2; ++c) {
+      f32x16 acc = Pacc[c];
+      BF_UNROLL for (int cc = 0; cc < 2; ++cc) {
+        u32x4 a[3], bw[3];
+        load_terms(bw, Zn(c), TERM, PITCH, lr, cc, lk);
+        BF_UNROLL for (int q = 0; q < 3; ++q) a[q] = bw[q] ^ 0x80008000u;
+        acc = mfma_bf6(a, bw, acc);
+      }
+      const float cv = lk == 0 ? scv(c)[lr] : 0.f;
+      acc = mfma2(cv, cv, acc);
+      if (ok[c]) store_tile32(out.P, bt[c], t, lane, acc, nr, kc[c]);
+      wave_lds_order();   // (W^T's terms are read before Y^T overwrites them below; P-'s before P+'s here)
+      store_terms_transposed(Pn(c), TERM, PITCH, 0, 0, lane, acc);
+      if (ok[c] && out.m.p && lane < nr) out.m.p[bt[c] * out.m.sB + kc[c] * out.m.sK + t * out.m.sT + lane * out.m.sE] = sm2(c)[lane];
+      if (ok[c] && lane == 0) {
+        if constexpr (!MULTI) {
+          w[c] = reweight_single(llc[c], w[c]);
+          if (out.w.p) out.w.p[b[c] * out.w.sB + t * out.w.sT] = w[c];
+        }
+        if (out.ll.p) out.ll.p[bt[c] * out.ll.sB + kc[c] * out.ll.sK + t * out.ll.sT] = llc[c];
+      }
+    }
+    wave_lds_order();
+    float fval[2] = {0.f, 0.f};
+    if constexpr (DYN != 0) {   // each chain's F row lr at its filtered mean, and f_lr(m+)
+      gl_cf* th = per_step(cst->dth);
+      BF_UNROLL for (int c = 0; c < 2; ++c) {
+        float fr[2][8];
+        BF_UNROLL for (int cc = 0; cc < 2; ++cc) BF_UNROLL for (int e = 0; e < 8; ++e) fr[cc][e] = 0.f;
+        if (lr < nr) {
+          if constexpr (DYN == 1) {
+            const float alpha = th[0], beta = th[1], gamma = th[2], dt = th[3];
+            const bool mp = th[4] != 0.f;
+            const int im1 = (lr + nr - 1) % nr, ip1 = (lr + 1) % nr, im2 = (lr + 2 * nr - 2) % nr;
+            const float xi = sm2(c)[lr], ax = sm2(c)[im1];
+            const float bx = mp ? (sm2(c)[ip1] - sm2(c)[im2]) : 0.f;
+            fval[c] = xi + dt * (alpha * (ax * bx) - beta * xi + gamma);
+            BF_UNROLL for (int cc = 0; cc < 2; ++cc) BF_UNROLL for (int e = 0; e < 8; ++e) {
+              const int j = 16 * cc + 8 * lk + e;
+              float v = 0.f;
+              if (j == lr) v += 1.0f - dt * beta;
+              if (mp) {
+                if (j == im1) v += dt * alpha * bx;
+                if (j == ip1) v += dt * alpha * ax;
+                if (j == im2) v -= dt * alpha * ax;
+              }
+              fr[cc][e] = v;
+            }
+          } else {
+            const float w0 = th[0], xi = sm2(c)[lr];
+            fval[c] = sinf(w0 * xi);
+            const float d = w0 * cosf(w0 * xi);
+            BF_UNROLL for (int cc = 0; cc < 2; ++cc) BF_UNROLL for (int e = 0; e < 8; ++e) fr[cc][e] = (16 * cc + 8 * lk + e == lr) ? d : 0.f;
+          }
+        }
+        BF_UNROLL for (int cc = 0; cc < 2; ++cc) BF_UNROLL for (int d = 0; d < 4; ++d) {
+          const Split3 sp = split_pair(fr[cc][2 * d], fr[cc][2 * d + 1]);
+          aop[c][0][cc][d] = sp.hi; aop[c][1][cc][d] = sp.mid; aop[c][2][cc][d] = sp.lo;
+        }
+      }
+    }
+    // ---- Y^T = P+^T A^T; m- = A m+ + G q0 (DYN: f(m+) + F_q q0)
+    BF_UNROLL for (int c = 0; c < 2; ++c) {
+      f32x16 acc = {0};
+      BF_UNROLL for (int cc = 0; cc < 2; ++cc) {
+        u32x4 a[3];
+        load_terms(a, Pn(c), TERM, PITCH, lr, cc, lk);
+        const u32x4 ba[3] = {aop[c][0][cc], aop[c][1][cc], aop[c][2][cc]};
+        acc = mfma_bf6(a, ba, acc);
+      }
+      store_terms_transposed(Zn(c), TERM, PITCH, 0, 0, lane, acc);
+      if constexpr (DYN == 0) {
+        float s = dot_terms32(aop[c], sm2(c), lk);
+        s += __shfl_xor(s, 32, 64);
+        sm(c)[lr] = s + gq0;
+      } else {
+        sm(c)[lr] = fval[c] + gq0;
+      }
+    }
+    wave_lds_order();
+    // ---- P- = Y A^T + G Q G^T; predicted streams
+    BF_UNROLL for (int c = 0; c < 2; ++c) {
+      float gq[16];
+      BF_UNROLL for (int r = 0; r < 16; ++r) gq[r] = gqg_t[c_row(r, lane) * 32 + lr];
+      BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[c][r] = 0.f;
+      BF_UNROLL for (int cc = 0; cc < 2; ++cc) {
+        u32x4 a[3];
+        load_terms(a, Zn(c), TERM, PITCH, lr, cc, lk);
+        const u32x4 ba[3] = {aop[c][0][cc], aop[c][1][cc], aop[c][2][cc]};
+        Pacc[c] = mfma_bf6(a, ba, Pacc[c]);
+      }
+      BF_UNROLL for (int r = 0; r < 16; ++r) Pacc[c][r] += gq[r];
+      if (ok[c]) store_tile32(out.pP, bt[c], t, lane, Pacc[c], nr, kc[c]);
+      store_terms_transposed(Pn(c), TERM, PITCH, 0, 0, lane, Pacc[c]);
+      if (ok[c] && out.pm.p && lane < nr) out.pm.p[bt[c] * out.pm.sB + kc[c] * out.pm.sK + t * out.pm.sT + lane * out.pm.sE] = sm(c)[lane];
+    }
+    wave_lds_order();
+  }
+
+  BF_UNROLL for (int c = 0; c < 2; ++c) {
+    if (!ok[c]) continue;
+    if (carry.P_out && lr < nr) BF_UNROLL for (int r = 0; r < 16; ++r) {
+        const int row = c_row(r, lane);
+        if (row < nr) carry.P_out[b[c] * nr * nr + row * nr + lr] = Pacc[c][r];
+      }
+    if (carry.m_out && lane < nr) carry.m_out[b[c] * nr + lane] = sm(c)[lane];
+    if (!MULTI && carry.w_out && lane == 0) carry.w_out[b[c]] = w[c];
+  }
+}
+
+
 // The weight recursion of the Gaussian-sum filter (inference.py:347-350) on stored per-step log-likelihoods: one wave per
 // trajectory, component k in lane k (K <= 64), w_t = exp(ll_t - max ll_t) w_{t-1} / sum, the max and the sum as xor-butterflies
 // over the lanes = the oracle's adjacent-pair trees (lanes beyond K carry -inf / 0, the trees' identities).
@@ -1791,7 +2031,7 @@ static int tv_table_on_device(const float* W_host, const float* C_host, long lon
 // dyn_kind: 0 = linear (p->A), 1 = Lorenz-96, 2 = sine with scalars dth (identity noise input: p->G == NULL, dq == n); nonlinear
 // chains always run as `multi` (K >= 1).
 int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long long T, const bf_carry* carry, const bf_out_desc* out,
-                   hipStream_t stream, int K, bool multi, int dyn_kind, const float* dth) {
+                   hipStream_t stream, int K, bool multi, int dyn_kind, const float* dth, bool two_per_wave) {
   constexpr int N = 32;
   const int nr = p->n, mr = p->m, dq = p->dq, dr = p->dr;
   if (nr > N || mr > N) return set_error(BF_EUNSUPPORTED, "one-wave matrix-core Kalman kernel: n <= 32 and m <= 32");
@@ -1905,7 +2145,18 @@ int launch_kf_bf32(const bf_lgssm* p, const bf_cstream* y, long long B, long lon
     const int rc = begin_multi(out, B, T, K, stream, ov, &llscratch);
     if (rc != BF_OK) { free_tables(); return rc; }
   }
-  if (multi && dyn_kind == 1) {
+  if (two_per_wave) {   // kf_scan_bf32x2_kernel: two chains per wave, four per 128-thread workgroup
+    const dim3 grid2((unsigned)((chains + 3) / 4));
+    const int lds2 = 4 * BF32_WAVE_LDS;
+    auto go = [&](auto kern) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds2) != hipSuccess) (void)hipGetLastError();
+      hipLaunchKernelGGL(kern, grid2, block, lds2, stream, dc, yv, cv, ov, chains, T, nr, mr, multi ? K : 1, tv ? d_tvq : nullptr, tv ? d_tvr : nullptr);
+    };
+    if (multi && dyn_kind == 1) { if (tv) go(kf_scan_bf32x2_kernel<true, true, 1>); else go(kf_scan_bf32x2_kernel<true, false, 1>); }
+    else if (multi && dyn_kind == 2) { if (tv) go(kf_scan_bf32x2_kernel<true, true, 2>); else go(kf_scan_bf32x2_kernel<true, false, 2>); }
+    else if (multi) { if (tv) go(kf_scan_bf32x2_kernel<true, true>); else go(kf_scan_bf32x2_kernel<true, false>); }
+    else { if (tv) go(kf_scan_bf32x2_kernel<false, true>); else go(kf_scan_bf32x2_kernel<false, false>); }
+  } else if (multi && dyn_kind == 1) {
     if (tv) hipLaunchKernelGGL((kf_scan_bf32_kernel<true, true, 1>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, chains, T, nr, mr, K, d_tvq, d_tvr);
     else hipLaunchKernelGGL((kf_scan_bf32_kernel<true, false, 1>), grid, block, 2 * BF32_WAVE_LDS, stream, dc, yv, cv, ov, chains, T, nr, mr, K, nullptr, nullptr);
   } else if (multi && dyn_kind == 2) {

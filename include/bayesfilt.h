@@ -132,7 +132,8 @@ int bf_device_count(void);
  *                   sets the default.
  *   "kf_small_mode": 1 (default) = Kalman models with 9 <= n <= 32, m <= 32 run on the one-wave-per-trajectory matrix-core
  *                   kernel (single 32 x 32 tiles, bf16 three-term products); 0 = off (n >= 24 then rides padded in the
- *                   (64, 32) kernel, smaller n on the run-time-dimension kernel).
+ *                   (64, 32) kernel, smaller n on the run-time-dimension kernel); 2 = the same kernel with two chains per wave
+ *                   (one factorization serves both half-waves; identical bits, measured 10-20 % slower: kept for experiments).
  *   "force_generic": 1 = bf_kalman_filter_f32 / bf_gsf_ekf_f32 run the run-time-dimension kernel (any n, m, K; state in
  *                   LDS) even where a compile-time-dimension instance exists (test hook; default 0).
  *   "gsf_structured": 1 (default) lets bf_gsf_ekf_f32 use the structure-aware kernel instances

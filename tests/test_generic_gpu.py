@@ -335,3 +335,36 @@ def test_extended_kalman_chains_on_the_matrix_cores(model, n, K, tv):
         assert torch.equal(torch.cat([getattr(h1, k), getattr(h2, k)], dim=2), getattr(post, k)), k
     for x, y_ in zip(c2, carry):
         assert torch.equal(x, y_)
+
+
+@pytest.mark.parametrize("case", ["kalman_odd_batch", "gaussian_sum_tv", "lorenz96_chains"])
+def test_two_chains_per_wave_variant_of_the_one_wave_kernel(case):
+    """kf_small_mode = 2: the one-wave matrix-core kernel with a second chain in the upper half-wave (one factorization for two
+    chains, column broadcasts by ds_swizzle).  Same operations on the same values: every output bit equal to the default
+    variant's, odd chain counts included.  (Measured slower -- one wave per SIMD loses more than the shared factorization wins --
+    so it stays an option)"""
+    import torch
+    import bayesianfiltering_amd as bfa
+    nl = bfa.nonlinearities
+    if case == "lorenz96_chains":
+        n, K, B, T = 24, 5, 33, 20
+        m = n // 2
+        p = bfa.ParamsNLSSM(8 * np.ones(n, F32), np.eye(n, dtype=F32), nl.lorenz96(n), np.zeros(n, F32), (1e-2 * np.eye(n)).astype(F32),
+                            nl.pick_even(n), np.zeros(m, F32), (1e-1 * np.eye(m)).astype(F32))
+        y = cm.device_observations(p, (n, n, m, m), B, T, seed=n)
+        init = 8.0 + torch.randn((B, K, n), device="cuda")
+    else:
+        n, m, K, B, T = (32, 16, 1, 77, 25) if case == "kalman_odd_batch" else (20, 12, 3, 41, 20)
+        a = cm.random_stable_lgssm(n, m, seed=n)
+        p = cm.product_params(a)
+        if case == "gaussian_sum_tv":
+            rng = np.random.default_rng(1)
+            p = p._replace(dynamics_noise_covariance=np.stack([(0.6 + rng.random()) * a["Q"] for _ in range(T)]).astype(F32))
+        y = cm.device_observations(cm.product_params(a), (n, n, m, m), B, T, seed=n)
+        init = torch.as_tensor(a["m0"], device="cuda") + 0.3 * torch.randn((B, K, n), device="cuda")
+    outs = [bfa.gaussian_sum_filter(p, y, K, 1, initial_means=init, return_carry=True, options={"kf_small_mode": mode}) for mode in (1, 2)]
+    for k in ("weights", "means", "covariances", "predicted_means", "predicted_covariances"):
+        x, z = getattr(outs[0][0], k), getattr(outs[1][0], k)
+        assert bool(((x == z) | (torch.isnan(x) & torch.isnan(z))).all()), k
+    for x, z in zip(outs[0][1], outs[1][1]):
+        assert bool(((x == z) | (torch.isnan(x) & torch.isnan(z))).all())
