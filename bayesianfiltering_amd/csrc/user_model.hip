@@ -152,6 +152,8 @@ __device__ inline bool operator<(Dual a, Dual b) { return a.v < b.v; }
 __device__ inline bool operator>(Dual a, Dual b) { return a.v > b.v; }
 __device__ inline bool operator<=(Dual a, Dual b) { return a.v <= b.v; }
 __device__ inline bool operator>=(Dual a, Dual b) { return a.v >= b.v; }
+__device__ inline bool operator==(Dual a, Dual b) { return a.v == b.v; }
+__device__ inline bool operator!=(Dual a, Dual b) { return a.v != b.v; }
 )BFSRC";
 const char* const kLibmMath = R"BFSRC(
 __device__ inline float sin(float x) { return ::sinf(x); }

@@ -142,6 +142,8 @@ class Sym:
     def __le__(self, o): return self._cmp(o, "<=")
     def __gt__(self, o): return self._cmp(o, ">")
     def __ge__(self, o): return self._cmp(o, ">=")
+    def __eq__(self, o): return self._cmp(o, "==")     # (so that `if u[0] == 1:` stops the recording instead of silently taking
+    def __ne__(self, o): return self._cmp(o, "!=")     #  the identity comparison's False branch)
     __hash__ = None
 
     def __bool__(self):

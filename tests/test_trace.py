@@ -122,6 +122,10 @@ def test_untraceable_functions_say_why():
         trace.dynamics_source(lambda x, q, u: np.linalg.inv(np.outer(x, x)) @ q, 2, 2)
     with pytest.raises(trace.TraceError):
         trace.emission_source(lambda x, r, u: "not numbers", 2, 1)
+    with pytest.raises(trace.TraceError, match="truth value"):     # a switch on the input written as a Python branch
+        trace.dynamics_source(lambda x, q, u: 0.9 * x + q if u[0] == 1 else x + q, 2, 2)
+    sw = trace.dynamics_source(lambda x, q, u: trace.where(u[0] == 1, 0.9, 1.0) * x + q, 2, 2)[0]      # ... and as a recorded select
+    assert "u == " in sw and "?" in sw
 
 
 def test_structural_zeros_and_ones_fold():
