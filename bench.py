@@ -459,6 +459,15 @@ def main():
                                                 "source": src}
                 except KeyError:
                     pass
+        if args.config == "gsf32" and args.mode == "full5" and w["extra"]["batch_total"] == 16384 and args.chunk == 500 and world == 1:
+            prof, src = profiled("r03_pmc_gsf32_traffic.json")     # HBM bytes per 500-step chunk from separate rocprofv3 --pmc passes
+            if prof and "pmc" in prof:
+                try:
+                    roof["traffic_profiled"] = {"bytes_per_chunk_launch": (prof["pmc"]["WRITE_SIZE"]["mean_per_dispatch"] +
+                                                                           prof["pmc"]["FETCH_SIZE"]["mean_per_dispatch"]) * 1024.0,
+                                                "algorithmic_bytes_per_chunk_launch": prof.get("algorithmic_bytes_per_dispatch"), "source": src}
+                except KeyError:
+                    pass
         line = {
             "metric": "filter timesteps/sec (batch x T)", "value": w["total_units"] * args.steps / elapsed, "unit": "timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,

@@ -109,3 +109,27 @@ if [[ $what == *others* ]]; then
     rm -rf $out/t_$tag
   done
 fi
+
+if [[ $what == *gsf32pmc* ]]; then
+  echo "== gsf32 (as_written) HBM traffic per 500-step chunk"
+  for c in WRITE_SIZE FETCH_SIZE; do
+    rocprofv3 --pmc $c --output-format csv -d $out/pmc_gsf32_$c -- python3 $root/bench.py --config gsf32 --l96-mode as_written --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_gsf32_$c.log 2>&1
+  done
+  python3 - <<PY
+import csv, glob, json, collections
+out = "$out"
+summary = {"tag": "r03 gsf32 as_written", "launch": "bench.py --config gsf32 --l96-mode as_written --steps 1 --warmup 0 (10 chunks of 500 steps, B = 16384, K = 32, FULL5)",
+           "algorithmic_bytes_per_dispatch": 18576 * 16384 * 500, "note": "KiB per dispatch of gsf_scan_kernel"}
+for c in ("WRITE_SIZE", "FETCH_SIZE"):
+    for f in glob.glob(out + "/pmc_gsf32_%s/**/*counter_collection.csv" % c, recursive=True):
+        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "gsf_scan_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c]
+        if v: summary.setdefault("pmc", {})[c] = {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)}
+json.dump(summary, open(out + "/pmc_gsf32_traffic.json", "w"), indent=1)
+print(json.dumps(summary.get("pmc", {})))
+PY
+  rm -rf $out/pmc_gsf32_WRITE_SIZE $out/pmc_gsf32_FETCH_SIZE
+fi
+if [[ $what == *kalman64pmc* ]]; then
+  echo "== kalman64 SQ counters (bench launch: B = 32768, 100-step chunks)"
+  pmc kalman64 kf_scan_mfma5_kernel $out/pmc_kalman64.json '{"script": "bench.py --config kalman64 --steps 1 --warmup 0", "steps_per_dispatch": 3276800}' -- python3 $root/bench.py --config kalman64 --steps 1 --warmup 0 --no-cpu-baseline
+fi
