@@ -186,3 +186,52 @@ def test_constant_cache_under_eviction_pressure():
     assert torch.isfinite(out.means).all()
     again = bfa.gaussian_sum_filter(model(0), ys, 2, 1, initial_means=np.zeros((B, 2, n), F32))
     assert torch.equal(again.covariances, keep)
+
+
+def test_concurrent_callers_with_different_options_and_cache_pressure():
+    """Four host threads call the library at once for a while: each with its own model, its own per-call options (two of them the
+    run-time-dimension kernel), its own torch stream, and per-step covariance tables that churn the constant cache (more distinct
+    blocks than it holds, so evictions run while other threads' calls are in flight).  Every result equals the same call made
+    alone: per-call options are thread-local, cache entries are pinned while a call holds them, the entry points are re-entrant."""
+    import threading
+    import torch
+    import bayesianfiltering_amd as bfa
+    nl = bfa.nonlinearities
+    T, B, n, m, K = 8, 6, 4, 2, 3
+    ys = torch.randn((B, T, m), device="cuda")
+    im = np.zeros((B, K, n), F32)
+
+    def model(i):
+        r = np.random.default_rng(1000 + i)
+        A = (0.9 * np.eye(n) + 0.02 * r.normal(size=(n, n))).astype(F32)
+        H = r.normal(size=(m, n)).astype(F32)
+        Qt = np.stack([(0.05 + 0.01 * t) * np.eye(n) for t in range(T)]).astype(F32) * (1 + 0.001 * i)
+        return bfa.ParamsNLSSM(np.zeros(n, F32), np.eye(n, dtype=F32), nl.linear_dynamics(A), np.zeros(n, F32), Qt, nl.linear_emission(H),
+                               np.zeros(m, F32), 0.3 * np.eye(m, dtype=F32))
+    per_thread, rounds = 60, 2
+    opts = [None, {"force_generic": 1}, None, {"force_generic": 1}]
+    expected = {}
+    for th in range(4):
+        for i in range(per_thread):
+            expected[(th, i)] = bfa.gaussian_sum_filter(model(th * per_thread + i), ys, K, 1, initial_means=im, options=opts[th]).covariances.clone()
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(th):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for _ in range(rounds):
+                    for i in range(per_thread):
+                        out = bfa.gaussian_sum_filter(model(th * per_thread + i), ys, K, 1, initial_means=im, options=opts[th])
+                        stream.synchronize()
+                        if not torch.equal(out.covariances, expected[(th, i)]):
+                            errors.append((th, i))
+        except Exception as e:      # noqa: BLE001
+            errors.append((th, repr(e)))
+    threads = [threading.Thread(target=worker, args=(th,)) for th in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
