@@ -188,6 +188,20 @@ def test_model_outside_the_registry_against_the_oracle(K):
         assert cm.rel_err(ll[b].cpu().numpy(), rll) < 5e-5
     # the host twin is callable like a reference lambda
     assert np.allclose(pp.dynamics_function(m0, q0, 0.0), fo.value(m0, q0, np.zeros(1, F32)))
+    # per-step covariances (inference.py:21,337-340) on the register kernel of the source model, and two chunks through the carry
+    rng = np.random.default_rng(8)
+    Qt = np.stack([(0.6 + rng.random()) * Q for _ in range(T)]).astype(F32)
+    Rt = np.stack([(0.6 + rng.random()) * R for _ in range(T)]).astype(F32)
+    ptv, otv = pp._replace(dynamics_noise_covariance=Qt, emission_noise_covariance=Rt), po._replace(dynamics_noise_covariance=Qt, emission_noise_covariance=Rt)
+    tv = bfa.gaussian_sum_filter(ptv, ys, K, 1, initial_means=im)
+    for b in range(B):
+        ref = go.gaussian_sum_filter(otv, ys[b], K, initial_means=im[b])
+        for k in FIELDS[1:]:
+            assert cm.rel_err(getattr(tv, k)[b].cpu().numpy(), getattr(ref, k)) < 2e-5, (b, k)
+    h1, c1 = bfa.gaussian_sum_filter(pp, ys[:, :20], K, 1, initial_means=im, return_carry=True)
+    h2 = bfa.gaussian_sum_filter(pp, ys[:, 20:], K, 1, carry=c1)
+    import torch
+    assert torch.equal(torch.cat([h1.means, h2.means], dim=2), post.means) and torch.equal(torch.cat([h1.weights, h2.weights], dim=2), post.weights)
 
 
 def test_user_model_errors_and_cache():
