@@ -200,7 +200,11 @@ typedef struct bf_model {
  * numbers (what jacfwd computes), F_q Q F_q^T / H_r R H_r^T are formed on the device every step.  Either source may be
  * NULL (that side stays a registry function).  Compiled models are cached by source (memory + $BAYESFILT_CACHE_DIR,
  * default .jit_cache next to the library); a source that does not compile returns BF_EINVAL with the compiler's first error in
- * bf_last_error().  Use: set bf_model.user and dyn_id / emi_id = BF_FN_USER, then call bf_gsf_ekf_f32. */
+ * bf_last_error().  Use: set bf_model.user and dyn_id / emi_id = BF_FN_USER, then call bf_gsf_ekf_f32.  For n, dq, m, dr <= 8 (both
+ * functions from source, or the other one the registry's linear function; no legacy flags, no collapsed streams) the handle also
+ * builds, on first use, the Gaussian-sum scan with the state in REGISTERS (one lane per (trajectory, component), the same dual-number
+ * Jacobians): two orders of magnitude faster than the run-time-dimension kernel and the default there ("force_generic" = 1 keeps
+ * the LDS kernel). */
 #define BF_FN_USER 100
 typedef struct bf_user_model bf_user_model;
 int bf_user_model_create(const char* dynamics_src, const char* emission_src, int32_t n, int32_t dq, int32_t m, int32_t dr,
@@ -208,7 +212,9 @@ int bf_user_model_create(const char* dynamics_src, const char* emission_src, int
 /* ... and for the bootstrap particle filter (bf_bpf_f32), whose model is f, the emission log-density and nothing else
  * (gaussfiltax/inference.py:1344-1349: x' = f(x, q, u), lls = emission_distribution_log_prob(x', y, u), any callables):
  * the same handle also compiles the particle-filter kernel with the caller's functions, on first use and per particle
- * capacity (<= 4096 particles for state_dim <= 16, <= 1024 beyond).  The density is either Gaussian around the (registry or
+ * capacity (particles in registers up to 4096 for state_dim <= 16 / 1024 beyond; above that the particles-in-HBM kernel, up to
+ * 2^20 per trajectory) -- and, likewise on first use, the unscented (bf_ugsf_ukf_f32) and augmented (bf_agsf_ekf_f32 /
+ * bf_agsf_ukf_f32) scans and the data generator (bf_sample_ssm_f32) around the same functions (dimensions up to 8; sampler 32).  The density is either Gaussian around the (registry or
  * source) emission function, MVN(h(x, r_eval, u), lp_cov) as for registry models, or -- log_prob_src -- the caller's own
  *
  *     template <class T> __device__ T log_prob(const T* x, const float* y, T u, const float* theta);   // theta = bf_bpf_model.lp_theta
