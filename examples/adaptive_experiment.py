@@ -8,7 +8,8 @@ filters of its loop (:106-164): GSF with 5 components, the augmented GSF [5, 2, 
 bootstrap particle filter with 100 particles under the state-dependent log-density lmsvlp (:55-57).  The reference's
 `for i in range(Nsim)` loop becomes the batch axis: every filter runs all Nsim trajectories in one launch.
 
-Differences by necessity: the functions come from the device registry; all trajectories of a launch share the filter's
+Differences: the functions come from the device registry by default (--python-functions runs the reference's own lambdas of
+:47-57, recorded and compiled at first use: the same RMSEs to five digits); all trajectories of a launch share the filter's
 PRNG key (the reference draws one per run); opt_args[1] = 1e4 makes P- - Lambda indefinite, so -- exactly as in the
 reference, containers.py:121 -- every s-sample falls back to its node mean; and once the input switches the emission
 to the multiplicative form, H_x = 0 at r0 = 0, nothing shrinks the leaf covariance Lambda = 1e4 P- any more: it grows
@@ -32,6 +33,9 @@ def main():
     ap.add_argument("--nsim", type=int, default=100)
     ap.add_argument("--particles", type=int, default=100)
     ap.add_argument("--agsf-lambda", type=float, default=1e4, help="opt_args[1] of the augmented filter (:126)")
+    ap.add_argument("--python-functions", action="store_true",
+                    help="the model as the reference writes it -- the lambdas of :47-57 with jax.numpy / tfp's MVN replaced by "
+                         "bayesianfiltering_amd.jnp / distributions.MVN, recorded and compiled at first use -- instead of the device registry")
     args = ap.parse_args()
 
     import torch
@@ -46,8 +50,21 @@ def main():
     f = nl.linear_dynamics(0.8 * np.eye(n, dtype=F32))                                # fmsv  :48-49
     g = nl.stoch_vol(n, sigma=5.0, beta=0.5, c=0.1)                                   # glmsv :51-54
     inputs = np.array([0] * (T // 2) + [1] * (T // 2), F32)                           # :67
+    glp = nl.stoch_vol_log_prob(g, R) if not args.python_functions else None            # lmsvlp :55-57
+    if args.python_functions:
+        import bayesianfiltering_amd.jnp as jnp                      # was: import jax.numpy as jnp
+        from bayesianfiltering_amd.distributions import MVN          # was: tfd.MultivariateNormalFullCovariance as MVN
+        Phi = 0.8 * jnp.eye(n)                                                                                       # :48
+        f = lambda x, q, u: Phi @ x + q                                                                              # :49
+        sigma, beta = 5.0, 0.5                                                                                       # :51-52
+        H0 = 0.1 * jnp.eye(n, n)                                                                                     # :53
+        g = lambda x, r, u: u * beta * jnp.multiply(jnp.exp(x / sigma), r) + (1 - u) * (H0 @ x + r)                   # :54
+
+        def glp(x, y, u):                                                                                            # :55-57
+            Mx = u * beta * jnp.diag(jnp.exp(x / sigma)) + (1 - u) * jnp.eye(n)
+            return MVN(loc=g(x, r0, u), covariance_matrix=Mx @ R @ Mx.T).log_prob(y)
     params = ParamsNLSSM(mu0, Sigma0, f, q0, Q, g, r0, R)
-    params_bpf = ParamsBPF(mu0, Sigma0, f, q0, Q, g, r0, R, nl.stoch_vol_log_prob(g, R))   # lmsvlp :55-57
+    params_bpf = ParamsBPF(mu0, Sigma0, f, q0, Q, g, r0, R, glp)
 
     # key, next_key = jr.split(next_key) from PRNGKey(10), one data key per run                   :103, :107
     from bayesianfiltering_amd import legacy

@@ -180,3 +180,38 @@ def test_mvn_log_prob_records_and_matches_scipy(tmp_path):
     assert abs(lib.lp1(_p(xf), _p(yf)) - lp(x, y, [0.0])) < 1e-4
     Ms = np.diag(np.exp(x[:2] / 5.0))
     assert abs(lib.lp2(_p(xf), _p(yf)) - multivariate_normal(0.5 * x[:2], Ms @ R @ Ms.T).logpdf(y)) < 1e-4
+
+
+def test_adaptive_experiment_lambdas_record(tmp_path):
+    """docs/experiments/adaptive_experiment.py:47-57 with `jnp` = bayesianfiltering_amd.jnp and `MVN` = distributions.MVN: the
+    input-switched linear / stochastic-volatility emission and its state-dependent log-density (covariance M R M^T with
+    M = u beta diag(exp(x / sigma)) + (1 - u) I) record as written; the generated log-density equals the NumPy evaluation."""
+    from scipy.stats import multivariate_normal
+    import bayesianfiltering_amd.jnp as jnp
+    from bayesianfiltering_amd.distributions import MVN
+    state_dim = emission_dim = 3
+    r0 = jnp.zeros(3)
+    R = 1e-3 * jnp.eye(3)
+    Phi = 0.8 * jnp.eye(state_dim)
+    fmsv = lambda x, q, u: Phi @ x + q
+    sigma, beta = 5.0, 0.5
+    H0 = 0.1 * jnp.eye(emission_dim, state_dim)
+    glmsv = lambda x, r, u: u * beta * jnp.multiply(jnp.exp(x / sigma), r) + (1 - u) * (H0 @ x + r)
+
+    def lmsvlp(x, y, u):
+        M = u * beta * jnp.diag(jnp.exp(x / sigma)) + (1 - u) * jnp.eye(emission_dim)
+        return MVN(loc=glmsv(x, r0, u), covariance_matrix=M @ R @ M.T).log_prob(y)
+    assert trace.dynamics_source(fmsv, 3, 3)[1] == 3 and trace.emission_source(glmsv, 3, 3)[1] == 3
+    src = trace.log_prob_source(lmsvlp, 3, 3)
+    prelude = HOST.split('extern "C"')[0].replace("%s", src)
+    cpp, so = tmp_path / "sv.cpp", tmp_path / "sv.so"
+    cpp.write_text(prelude + 'extern "C" float lp(const float* x, const float* y, float u) { return bfu::log_prob<float>(x, y, u, nullptr); }\n')
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-o", str(so), str(cpp)])
+    lib = ctypes.CDLL(str(so))
+    lib.lp.restype = ctypes.c_float
+    x, y = np.array([1.0, -2.0, 0.5]), np.array([0.02, -0.01, 0.03])
+    for u in (0.0, 1.0):
+        M = u * beta * np.diag(np.exp(x / sigma)) + (1 - u) * np.eye(3)
+        ref = multivariate_normal(glmsv(x, np.zeros(3), np.array([u])), M @ (1e-3 * np.eye(3)) @ M.T).logpdf(y)
+        got = lib.lp(_p(x.astype(F32)), _p(y.astype(F32)), ctypes.c_float(u))
+        assert abs(got - ref) < 2e-3 * max(1.0, abs(ref)), (u, got, ref)
