@@ -70,3 +70,17 @@ def test_split_chain_recorded_by_the_reference(golden_dir):
     for k0_ref, k_ref in zip(d["key0"], d["key"]):
         k0, k, nk = tf.split(nk, 3)
         assert k0.tolist() == k0_ref and k.tolist() == k_ref
+
+
+def test_random_module_mirrors_jax_random_calls():
+    """bayesianfiltering_amd.random (`import ... as jr`): PRNGKey / split / normal / multivariate_normal on the library's host
+    Threefry, equal to the oracle's restatement (itself pinned by the reference-recorded keys and draws above)."""
+    import bayesianfiltering_amd.random as jr
+    key = jr.PRNGKey(1)
+    assert np.array_equal(key, tf.PRNGKey(1))
+    k0, k, nk = jr.split(key, 3)
+    assert np.array_equal(np.stack([k0, k, nk]), tf.split(tf.PRNGKey(1), 3))
+    assert np.array_equal(jr.normal(k, (4, 3)).view(np.uint32), tf.normal_canonical(k, 12).reshape(4, 3).view(np.uint32)) or \
+        np.allclose(jr.normal(k, (4, 3)), tf.normal(k, 12).reshape(4, 3), atol=3e-7)
+    x = jr.multivariate_normal(jr.PRNGKey(0), np.ones(3), np.eye(3), (10,))
+    assert x.shape == (10, 3) and np.allclose(x, 1.0 + tf.normal(tf.PRNGKey(0), 30).reshape(10, 3), atol=1e-6)
