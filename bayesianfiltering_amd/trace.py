@@ -13,7 +13,9 @@ the ufuncs sin cos tan exp log sqrt tanh arctan arctan2 abs square power(x, numb
 :func:`where` (``np.where`` asks the condition for its truth value, which a symbol does not have; compare single elements with
 the operators, whole arrays with :data:`greater` / :data:`less` / ...).  Data-dependent Python
 control flow (``if x[0] > 0:``) cannot -- it raises ``TraceError`` with this explanation.  Closure constants become
-literals of the source (float32).
+literals of the source (float32): a function is compiled once per distinct set of constants (1-2 s by hiprtc, cached on disk by
+source), so a sweep over thousands of parameter values is better served by ``nonlinearities.user_dynamics(source, theta=...)``,
+whose ``theta`` is a run-time argument.
 """
 import numpy as np
 
